@@ -1,0 +1,169 @@
+"""Synthetic RGB-D frames for the dense-alignment hot path.
+
+An analytic room corner (floor y=+1.2, wall z=+3.0, wall x=-1.6, all in the reference-camera
+frame) is ray-cast from an arbitrary camera pose, so depth is exact and the ground-truth
+relative pose of any two frames is known.  Texture = a smooth sinusoid + integer-hash value
+noise of the in-plane coordinates; a hash-selected 2 % of the depth pixels and one 40x40 block
+are NaN (invalid), as a structured-light sensor would produce.
+
+Inputs follow the reference's contract (dvo_benchmark/src/benchmark_slam.cpp:46-93): intensity is
+float32 in 0..255, depth is float32 metres with NaN = invalid, TUM fr1 intrinsics by default
+(benchmark_slam.cpp:384).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+SEED = 20131103
+TUM_FR1 = (517.3, 516.5, 318.6, 255.3)  # fx, fy, ox, oy at 640x480
+
+XI_GT_PAIR = np.array([0.012, -0.006, 0.009, 0.004, -0.007, 0.003])      # config 2 / 3
+XI_STEP_STREAM = np.array([0.004, -0.002, 0.003, 0.0015, -0.002, 0.001])  # config 4
+
+
+def intrinsics_for(width: int, height: int):
+    """TUM fr1 intrinsics scaled from 640x480 to (width, height)."""
+    s = width / 640.0
+    fx, fy, ox, oy = TUM_FR1
+    return (np.float32(fx * s), np.float32(fy * s), np.float32(ox * s), np.float32(oy * s))
+
+
+def _hat(w):
+    return np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]], dtype=np.float64)
+
+
+def se3_exp(xi) -> np.ndarray:
+    """4x4 matrix of exp(xi), xi = (upsilon, omega) -- the tangent order of Sophus::SE3d."""
+    xi = np.asarray(xi, dtype=np.float64)
+    ups, om = xi[:3], xi[3:]
+    th = np.linalg.norm(om)
+    O = _hat(om)
+    if th < 1e-10:
+        R = np.eye(3) + O + 0.5 * O @ O
+        V = np.eye(3) + 0.5 * O + O @ O / 6.0
+    else:
+        R = np.eye(3) + np.sin(th) / th * O + (1 - np.cos(th)) / th**2 * O @ O
+        V = np.eye(3) + (1 - np.cos(th)) / th**2 * O + (th - np.sin(th)) / th**3 * O @ O
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = V @ ups
+    return T
+
+
+def se3_log(T) -> np.ndarray:
+    T = np.asarray(T, dtype=np.float64)
+    R, t = T[:3, :3], T[:3, 3]
+    c = np.clip((np.trace(R) - 1) / 2, -1, 1)
+    th = np.arccos(c)
+    if th < 1e-10:
+        om = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / 2
+    else:
+        om = th / (2 * np.sin(th)) * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    O = _hat(om)
+    if th < 1e-10:
+        Vi = np.eye(3) - 0.5 * O + O @ O / 12.0
+    else:
+        Vi = np.eye(3) - 0.5 * O + (1 - th * np.cos(th / 2) / (2 * np.sin(th / 2))) / th**2 * O @ O
+    return np.concatenate([Vi @ t, om])
+
+
+def pose_error(T_a, T_b) -> float:
+    """|| log(T_a^-1 T_b) ||_2 over the 6-vector (upsilon, omega): the parity metric of BASELINE.json."""
+    return float(np.linalg.norm(se3_log(np.linalg.inv(np.asarray(T_a, dtype=np.float64)) @ np.asarray(T_b, dtype=np.float64))))
+
+
+def _hash_u32(x, y, seed):
+    h = (x.astype(np.uint32) * np.uint32(0x9E3779B1)) ^ (y.astype(np.uint32) * np.uint32(0x85EBCA77)) ^ np.uint32(seed & 0xFFFFFFFF)
+    h ^= h >> np.uint32(15)
+    h = h * np.uint32(0x2C1B3C6D)
+    h ^= h >> np.uint32(12)
+    h = h * np.uint32(0x297A2D39)
+    h ^= h >> np.uint32(15)
+    return h
+
+
+def _value_noise(a, b, seed):
+    a0 = np.floor(a)
+    b0 = np.floor(b)
+    fa = a - a0
+    fb = b - b0
+    ia = a0.astype(np.int64)
+    ib = b0.astype(np.int64)
+
+    def lattice(dx, dy):
+        return _hash_u32((ia + dx) & 0xFFFFFFFF, (ib + dy) & 0xFFFFFFFF, seed).astype(np.float64) / 4294967296.0
+
+    sa = fa * fa * (3 - 2 * fa)
+    sb = fb * fb * (3 - 2 * fb)
+    top = lattice(0, 0) * (1 - sa) + lattice(1, 0) * sa
+    bot = lattice(0, 1) * (1 - sa) + lattice(1, 1) * sa
+    return (top * (1 - sb) + bot * sb) * 2.0 - 1.0
+
+
+def render(width: int, height: int, T_cam=None, seed: int = SEED, frame_id: int = 0, nan_fraction: float = 0.02,
+           hole: bool = True, K=None):
+    """Ray-cast the room corner from camera pose T_cam (camera -> scene, 4x4).  Returns (intensity, depth) float32."""
+    fx, fy, ox, oy = (K if K is not None else intrinsics_for(width, height))
+    T = np.eye(4) if T_cam is None else np.asarray(T_cam, dtype=np.float64)
+    u, v = np.meshgrid(np.arange(width, dtype=np.float64), np.arange(height, dtype=np.float64))
+    d_c = np.stack([(u - float(ox)) / float(fx), (v - float(oy)) / float(fy), np.ones_like(u)], axis=-1)
+    d = d_c @ T[:3, :3].T
+    o = T[:3, 3]
+    big = 1e30
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t_floor = np.where(d[..., 1] > 1e-9, (1.2 - o[1]) / d[..., 1], big)
+        t_wz = np.where(d[..., 2] > 1e-9, (3.0 - o[2]) / d[..., 2], big)
+        t_wx = np.where(d[..., 0] < -1e-9, (-1.6 - o[0]) / d[..., 0], big)
+    t_floor = np.where(t_floor > 0, t_floor, big)
+    t_wz = np.where(t_wz > 0, t_wz, big)
+    t_wx = np.where(t_wx > 0, t_wx, big)
+    t = np.minimum(np.minimum(t_floor, t_wz), t_wx)
+    which = np.where(t == t_floor, 0, np.where(t == t_wz, 1, 2))
+    P = o + d * t[..., None]
+    a = np.where(which == 0, P[..., 0], np.where(which == 1, P[..., 0], P[..., 2]))
+    b = np.where(which == 0, P[..., 2], P[..., 1])
+    tex = 127.5 + 50.0 * np.sin(7.1 * a) * np.cos(5.3 * b)
+    for pid in range(3):
+        m = which == pid
+        if m.any():
+            tex[m] += 35.0 * _value_noise(a[m] * 8.0, b[m] * 8.0, seed + 17 * pid)
+    intensity = np.clip(tex, 0.0, 255.0).astype(np.float32)
+    depth = t.astype(np.float32)  # z in the camera frame because d_c.z == 1
+    depth[t >= big] = np.nan
+    if nan_fraction > 0:
+        ui = u.astype(np.int64)
+        vi = v.astype(np.int64)
+        h = _hash_u32(ui, vi, seed + 1 + 7919 * frame_id)
+        depth[h < np.uint32(int(nan_fraction * 4294967296.0))] = np.nan
+    if hole and width >= 160 and height >= 120:
+        s = max(1, width // 16)
+        y0, x0 = height // 3, (2 * width) // 3
+        depth[y0:y0 + s, x0:x0 + s] = np.nan
+    return intensity, depth
+
+
+def make_pair(width: int = 640, height: int = 480, xi_gt=XI_GT_PAIR, seed: int = SEED, frame_id: int = 0):
+    """Reference frame at the scene origin, current frame at exp(xi_gt).  The expected DenseTracker result
+    (cur <- ref convention, dense_tracking.cpp:371) is T = exp(xi_gt)."""
+    T_gt = se3_exp(xi_gt)
+    ref = render(width, height, None, seed, 2 * frame_id)
+    cur = render(width, height, T_gt, seed, 2 * frame_id + 1)
+    return ref, cur, T_gt
+
+
+def stream_poses(n_frames: int, xi_step=XI_STEP_STREAM):
+    """Config 4: camera pose of frame t is exp(t * xi_step)."""
+    return [se3_exp(np.asarray(xi_step) * t) for t in range(n_frames)]
+
+
+def loop_closure_poses(n_candidates: int = 32, seed: int = SEED + 2, max_trans: float = 0.15, max_rot_deg: float = 5.0):
+    """Config 5: candidate frames at hashed poses around the keyframe."""
+    out = []
+    for i in range(n_candidates):
+        hs = [_hash_u32(np.array([i]), np.array([k]), seed)[0] / 4294967296.0 * 2 - 1 for k in range(8)]
+        ups = np.array(hs[0:3])
+        ups = ups / max(np.linalg.norm(ups), 1e-9) * max_trans * abs(hs[6])
+        om = np.array(hs[3:6])
+        om = om / max(np.linalg.norm(om), 1e-9) * np.deg2rad(max_rot_deg) * abs(hs[7])
+        out.append(se3_exp(np.concatenate([ups, om])))
+    return out

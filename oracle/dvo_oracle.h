@@ -1,0 +1,136 @@
+/*
+ * dvo_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C + SSE3 intrinsics) of the dense RGB-D alignment hot path of
+ * jesusbriales/dvo_slam: dvo::DenseTracker::match() over dvo::core::RgbdImagePyramid.
+ * It is the checker the HIP path in dvo_slam_amd/ is compared against.  Nothing in the
+ * product path may include, link or call this file: only tests/, __graft_entry__.smoke()
+ * and the cpu_baseline leg of bench.py do.
+ *
+ * PARITY UNPINNED: the reference ships no tests, fixtures or golden vectors for this path
+ *  and cannot be compiled here (it needs Eigen, OpenCV, Sophus, Boost,
+ * none of which are installed), so this restatement is pinned only by its own unit tests
+ * (textbook identities, finite differences, hand-computed 8x8 images) and by the committed
+ * fixtures it generated itself (tests/golden/).
+ *
+ * Every function cites the reference file:line (relative to /root/reference) it follows.
+ */
+#ifndef DVO_ORACLE_H_
+#define DVO_ORACLE_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_LEVELS 8
+
+/* how the projection / weight reciprocal is formed */
+enum {
+  ORC_RCP_SSE = 0,  /* _mm_rcp_ps, as the reference (dense_tracking_impl.cpp:192,700): host specific */
+  ORC_RCP_EXACT = 1 /* IEEE division in the same rounding mode: portable, what the HIP path does   */
+};
+
+/* dense_tracking.h:71-81 */
+enum {
+  ORC_TERM_ITERATIONS_EXCEEDED = 0,
+  ORC_TERM_INCREMENT_TOO_SMALL = 1,
+  ORC_TERM_LOGLIKELIHOOD_DECREASED = 2,
+  ORC_TERM_TOO_FEW_CONSTRAINTS = 3,
+  ORC_TERM_UNSET = -1
+};
+
+/* live fields of DenseTracker::Config (dense_tracking.h:42-69, defaults dense_tracking_config.cpp:27-41) */
+typedef struct {
+  int first_level, last_level;
+  int max_iterations_per_level;
+  double precision;
+  double mu;
+  int use_initial_estimate;
+  float intensity_derivative_threshold;
+  float depth_derivative_threshold;
+  int rcp_mode;
+} orc_config;
+
+/* DenseTracker::IterationStats (dense_tracking.h:83-100) + the linear system of that iteration */
+typedef struct {
+  int id;
+  int valid_constraints;
+  double tdist_loglik;       /* = -ll */
+  double tdist_mean[2];
+  double tdist_precision[4]; /* column-major 2x2 */
+  double prior_loglik;
+  double increment[6];       /* only valid if has_increment */
+  double information[36];    /* A_d, only valid if has_increment */
+  double rhs[6];             /* b_d, extra (not in the reference's stats) */
+  float scale[4];            /* 2x2 before inversion, extra */
+  int has_increment;
+} orc_iteration_stats;
+
+/* DenseTracker::LevelStats (dense_tracking.h:103-116) */
+typedef struct {
+  int id;
+  int max_valid_pixels;
+  int valid_pixels;
+  int termination;
+  int n_iterations;
+  int first_iteration; /* index of this level's first entry in orc_result.iterations */
+} orc_level_stats;
+
+/* DenseTracker::Result (dense_tracking.h:125-140) */
+typedef struct {
+  double T[16];           /* column-major 4x4, Result::Transformation */
+  double information[36]; /* Result::Information */
+  double loglik;          /* Result::LogLikelihood */
+  int n_levels;
+  orc_level_stats levels[ORC_MAX_LEVELS];
+  int n_iterations;                 /* entries written to iterations[] */
+  orc_iteration_stats *iterations;  /* caller provided, may be NULL */
+  int iterations_capacity;
+  int is_nan;                       /* Result::isNaN() */
+} orc_result;
+
+typedef struct orc_pyramid orc_pyramid;
+
+void orc_default_config(orc_config *cfg);
+
+/* RgbdCameraPyramid(w,h,K) + create(intensity, depth) + build(levels): rgbd_image.cpp:141-172,264-296 */
+orc_pyramid *orc_pyramid_create(const float *intensity, const float *depth, int width, int height,
+                                float fx, float fy, float ox, float oy, int levels);
+void orc_pyramid_destroy(orc_pyramid *p);
+
+/* accessors used by the stage-wise parity tests */
+int orc_pyramid_levels(const orc_pyramid *p);
+void orc_level_size(const orc_pyramid *p, int level, int *w, int *h);
+void orc_level_intrinsics(const orc_pyramid *p, int level, float k[4]);
+/* plane: 0 I, 1 Z, 2 Ix, 3 Iy, 4 Zx, 5 Zy */
+const float *orc_level_plane(orc_pyramid *p, int level, int plane);
+/* 48-byte records {x,y,z,1, I,Z,Ix,Iy,Zx,Zy,0,0} of the selected points: point_selection.cpp:89-152 */
+int orc_select(orc_pyramid *p, int level, float ti, float td, const float **records);
+/* pixel index (y*w+x) of every selected record, same order */
+const int *orc_select_index(orc_pyramid *p, int level, float ti, float td);
+
+/*
+ * computeResidualsSse (dense_tracking_impl.cpp:133-393) on one level for the float transform T (column-major 4x4).
+ * out_points_error: n x 12 floats, out_residuals: n x 2 floats, out_valid: one byte per processed selected point
+ * (the Debug=true template), any may be NULL.  Returns n.
+ */
+int orc_compute_residuals(orc_pyramid *ref, orc_pyramid *cur, int level, float ti, float td, const float *T,
+                          int rcp_mode, float *out_points_error, float *out_residuals, unsigned char *out_valid);
+
+/* DenseTracker::match(RgbdImagePyramid&, RgbdImagePyramid&, Result&): dense_tracking.cpp:123-376 */
+int orc_match(const orc_config *cfg, orc_pyramid *ref, orc_pyramid *cur, const double *T_init, orc_result *res);
+
+/* small pieces exported for unit tests */
+void orc_se3_exp(const double xi[6], double T[16]);
+void orc_se3_log(const double T[16], double xi[6]);
+void orc_jacobian(const float p[3], float Jw[12], float Jz[6]); /* dense_tracking.cpp:448-476, row-major 2x6 */
+/* math_sse.cpp:82-207: A(6x6 col-major) += J^T alpha J via the packed 2x2 block accumulator */
+void orc_rank_update(const float *J2x6_colmajor, const float *alpha_colmajor, int n, float *A36);
+float orc_weights_scale_loglik(const float *residuals, int n, const float *prec_in, int unit_weights, int rcp_mode,
+                               float *weights_out, float *scale_out, float *prec_out);
+float orc_host_rcp(float x); /* _mm_rcp_ps lane 0 on this host */
+
+#ifdef __cplusplus
+}
+#endif
+#endif
