@@ -1,0 +1,52 @@
+"""Builds libdvo_amd.so (HIP kernels + host driver + C ABI) in-tree with hipcc for gfx950."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "libdvo_amd.so")
+SOURCES = ["dvo_kernels.hip", "dvo_tracker.cpp"]
+HEADERS = ["dvo_types.h", "se3.h", os.path.join("..", "..", "include", "dvo_amd.h")]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP library cannot be built (there is no CPU fallback)")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile for gfx950 (cross-compiles without a GPU).  Returns the path of the shared library."""
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = [
+        _hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+        "-ffp-contract=off",          # the warp/residual stage must round every product and sum separately
+        "-fno-fast-math",
+        "-Wall", "-Wno-unused-function",
+        "-x", "hip",
+    ] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH + ".tmp"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+        print(res.stderr)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stderr[-4000:])
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,339 @@
+"""ctypes binding of include/dvo_amd.h plus a thin Python mirror of the reference interface.
+
+``DenseTracker`` / ``RgbdImagePyramid`` / ``Config`` / ``Result`` carry the same names, argument meaning and error
+behaviour as dvo::DenseTracker, dvo::core::RgbdImagePyramid and their nested types
+(dvo_core/include/dvo/dense_tracking.h:39-213, dvo_core/include/dvo/core/rgbd_image.h:242-262), so that the parity
+tests read like calls into the reference.  All compute goes through the C ABI of libdvo_amd.so (HIP, gfx950): there is
+no CPU path here, and loading fails loudly if the library is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+MAX_LEVELS = 8
+TERMINATION = {0: "IterationsExceeded", 1: "IncrementTooSmall", 2: "LogLikelihoodDecreased", 3: "TooFewConstraints",
+               -1: "Unset"}
+
+EXPORTS = [
+    "dvo_amd_abi_version", "dvo_amd_status_string", "dvo_amd_last_error", "dvo_amd_device_count",
+    "dvo_amd_default_config", "dvo_amd_context_create", "dvo_amd_context_destroy", "dvo_amd_configure",
+    "dvo_amd_get_config", "dvo_amd_pyramid_create", "dvo_amd_pyramid_create_from_device", "dvo_amd_pyramid_retain",
+    "dvo_amd_pyramid_release", "dvo_amd_pyramid_levels", "dvo_amd_pyramid_timestamp", "dvo_amd_pyramid_level_info",
+    "dvo_amd_pyramid_download_plane", "dvo_amd_pyramid_select", "dvo_amd_match", "dvo_amd_match_batch",
+    "dvo_amd_residuals", "dvo_amd_error_image", "dvo_amd_kernel_timing",
+]
+
+
+class CConfig(C.Structure):
+    _fields_ = [("first_level", C.c_int), ("last_level", C.c_int), ("max_iterations_per_level", C.c_int),
+                ("precision", C.c_double), ("mu", C.c_double), ("use_initial_estimate", C.c_int),
+                ("intensity_derivative_threshold", C.c_float), ("depth_derivative_threshold", C.c_float)]
+
+
+class CIterationStats(C.Structure):
+    _fields_ = [("id", C.c_int), ("valid_constraints", C.c_int), ("tdist_loglik", C.c_double),
+                ("tdist_mean", C.c_double * 2), ("tdist_precision", C.c_double * 4), ("prior_loglik", C.c_double),
+                ("increment", C.c_double * 6), ("information", C.c_double * 36), ("has_increment", C.c_int),
+                ("reserved", C.c_int)]
+
+
+class CLevelStats(C.Structure):
+    _fields_ = [("id", C.c_int), ("max_valid_pixels", C.c_int), ("valid_pixels", C.c_int), ("termination", C.c_int),
+                ("n_iterations", C.c_int), ("first_iteration", C.c_int)]
+
+
+class CResult(C.Structure):
+    _fields_ = [("transformation", C.c_double * 16), ("information", C.c_double * 36), ("loglik", C.c_double),
+                ("is_nan", C.c_int), ("n_levels", C.c_int), ("levels", CLevelStats * MAX_LEVELS),
+                ("n_iterations", C.c_int), ("iterations_capacity", C.c_int),
+                ("iterations", C.POINTER(CIterationStats)), ("n_ticks", C.c_int), ("n_residual_passes", C.c_int),
+                ("alg_bytes", C.c_double)]
+
+
+class DvoAmdError(RuntimeError):
+    def __init__(self, status: int, where: str):
+        L = lib()
+        msg = L.dvo_amd_status_string(status).decode()
+        detail = L.dvo_amd_last_error().decode()
+        super().__init__(f"{where}: {msg}" + (f" [{detail}]" if detail else ""))
+        self.status = status
+
+
+_lib = None
+
+
+def lib():
+    """Load libdvo_amd.so (building it in-tree with hipcc if the sources are newer)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if _build.needs_build():
+        path = _build.build()
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: build it with `python -m dvo_slam_amd._build` (no CPU fallback exists)")
+    L = C.CDLL(path)
+    fp = C.POINTER(C.c_float)
+    dp = C.POINTER(C.c_double)
+    vp = C.c_void_p
+    L.dvo_amd_abi_version.restype = C.c_int
+    L.dvo_amd_status_string.restype = C.c_char_p
+    L.dvo_amd_status_string.argtypes = [C.c_int]
+    L.dvo_amd_last_error.restype = C.c_char_p
+    L.dvo_amd_device_count.restype = C.c_int
+    L.dvo_amd_default_config.argtypes = [C.POINTER(CConfig)]
+    L.dvo_amd_context_create.argtypes = [C.c_int, C.POINTER(CConfig), C.POINTER(vp)]
+    L.dvo_amd_context_destroy.argtypes = [vp]
+    L.dvo_amd_context_destroy.restype = None
+    L.dvo_amd_configure.argtypes = [vp, C.POINTER(CConfig)]
+    L.dvo_amd_get_config.argtypes = [vp, C.POINTER(CConfig)]
+    L.dvo_amd_pyramid_create.argtypes = [C.c_int, fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                         C.c_float, C.c_int, C.c_double, C.POINTER(vp)]
+    L.dvo_amd_pyramid_create_from_device.argtypes = [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                                     C.c_float, C.c_float, C.c_int, C.c_double, C.POINTER(vp)]
+    L.dvo_amd_pyramid_retain.argtypes = [vp]
+    L.dvo_amd_pyramid_retain.restype = None
+    L.dvo_amd_pyramid_release.argtypes = [vp]
+    L.dvo_amd_pyramid_release.restype = None
+    L.dvo_amd_pyramid_levels.argtypes = [vp]
+    L.dvo_amd_pyramid_timestamp.argtypes = [vp]
+    L.dvo_amd_pyramid_timestamp.restype = C.c_double
+    L.dvo_amd_pyramid_level_info.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), fp]
+    L.dvo_amd_pyramid_download_plane.argtypes = [vp, C.c_int, C.c_int, fp]
+    L.dvo_amd_pyramid_select.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_ubyte)]
+    L.dvo_amd_match.argtypes = [vp, vp, vp, dp, C.POINTER(CResult)]
+    L.dvo_amd_match_batch.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), dp, C.POINTER(CResult)]
+    L.dvo_amd_residuals.argtypes = [vp, vp, vp, C.c_int, fp, fp, C.POINTER(C.c_int)]
+    L.dvo_amd_error_image.argtypes = [vp, vp, vp, dp, C.c_int, fp]
+    L.dvo_amd_kernel_timing.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_longlong), C.c_int]
+    _lib = L
+    return L
+
+
+def _check(status: int, where: str):
+    if status != 0:
+        raise DvoAmdError(status, where)
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class Config:
+    """DenseTracker::Config (live fields), defaults from dense_tracking_config.cpp:27-41."""
+
+    def __init__(self, **kw):
+        c = CConfig()
+        lib().dvo_amd_default_config(C.byref(c))
+        self.FirstLevel = c.first_level
+        self.LastLevel = c.last_level
+        self.MaxIterationsPerLevel = c.max_iterations_per_level
+        self.Precision = c.precision
+        self.Mu = c.mu
+        self.UseInitialEstimate = bool(c.use_initial_estimate)
+        self.IntensityDerivativeThreshold = c.intensity_derivative_threshold
+        self.DepthDerivativeThreshold = c.depth_derivative_threshold
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise AttributeError(k)
+            setattr(self, k, v)
+
+    def getNumLevels(self) -> int:
+        return self.FirstLevel + 1
+
+    def IsSane(self) -> bool:
+        return self.FirstLevel >= self.LastLevel
+
+    def _c(self) -> CConfig:
+        return CConfig(self.FirstLevel, self.LastLevel, self.MaxIterationsPerLevel, self.Precision, self.Mu,
+                       int(self.UseInitialEstimate), self.IntensityDerivativeThreshold, self.DepthDerivativeThreshold)
+
+
+class RgbdImagePyramid:
+    """RgbdCameraPyramid(w, h, K).create(intensity, depth) with `levels` levels built on the GPU."""
+
+    def __init__(self, intensity, depth, K, levels: int, device: int = 0, timestamp: float = 0.0):
+        intensity = np.ascontiguousarray(intensity, dtype=np.float32)
+        depth = np.ascontiguousarray(depth, dtype=np.float32)
+        if intensity.shape != depth.shape or intensity.ndim != 2:
+            raise ValueError("intensity and depth must be 2-D arrays of the same shape")
+        h, w = intensity.shape
+        fx, fy, ox, oy = [float(k) for k in K]
+        self._h = C.c_void_p()
+        _check(lib().dvo_amd_pyramid_create(device, _fp(intensity), _fp(depth), w, h, w, fx, fy, ox, oy, levels,
+                                            timestamp, C.byref(self._h)), "dvo_amd_pyramid_create")
+        self.device = device
+
+    @classmethod
+    def from_device(cls, d_intensity: int, d_depth: int, width: int, height: int, K, levels: int, device: int = 0,
+                    timestamp: float = 0.0, stride: int | None = None):
+        """Planes already resident in HBM (raw device pointers, e.g. torch.Tensor.data_ptr())."""
+        self = cls.__new__(cls)
+        fx, fy, ox, oy = [float(k) for k in K]
+        self._h = C.c_void_p()
+        _check(lib().dvo_amd_pyramid_create_from_device(device, C.c_void_p(d_intensity), C.c_void_p(d_depth), width,
+                                                        height, stride or width, fx, fy, ox, oy, levels, timestamp,
+                                                        C.byref(self._h)), "dvo_amd_pyramid_create_from_device")
+        self.device = device
+        return self
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().dvo_amd_pyramid_release(h)
+            self._h = None
+
+    def levels(self) -> int:
+        return lib().dvo_amd_pyramid_levels(self._h)
+
+    def timestamp(self) -> float:
+        return lib().dvo_amd_pyramid_timestamp(self._h)
+
+    def level_info(self, level: int):
+        w, h = C.c_int(), C.c_int()
+        k = np.zeros(4, np.float32)
+        _check(lib().dvo_amd_pyramid_level_info(self._h, level, C.byref(w), C.byref(h), _fp(k)), "level_info")
+        return w.value, h.value, k
+
+    def plane(self, level: int, plane: int) -> np.ndarray:
+        """0 I, 1 Z, 2 Ix, 3 Iy, 4 Zx, 5 Zy of a level, downloaded."""
+        w, h, _ = self.level_info(level)
+        out = np.empty((h, w), np.float32)
+        _check(lib().dvo_amd_pyramid_download_plane(self._h, level, plane, _fp(out)), "download_plane")
+        return out
+
+    def select(self, level: int, ti: float = 0.0, td: float = 0.0):
+        """PointSelection::select: (count, mask[h, w])."""
+        w, h, _ = self.level_info(level)
+        mask = np.empty((h, w), np.uint8)
+        cnt = C.c_int()
+        _check(lib().dvo_amd_pyramid_select(self._h, level, ti, td, C.byref(cnt),
+                                            mask.ctypes.data_as(C.POINTER(C.c_ubyte))), "pyramid_select")
+        return cnt.value, mask
+
+
+class Result:
+    """DenseTracker::Result: Transformation (4x4), Information (6x6), LogLikelihood, Statistics.Levels."""
+
+    def __init__(self, c: CResult, its):
+        self.Transformation = np.array(c.transformation[:]).reshape(4, 4).T.copy()
+        self.Information = np.array(c.information[:]).reshape(6, 6).T.copy()
+        self.LogLikelihood = c.loglik
+        self._is_nan = bool(c.is_nan)
+        self.n_ticks = c.n_ticks
+        self.n_residual_passes = c.n_residual_passes
+        self.alg_bytes = c.alg_bytes
+        self.Levels = []
+        for l in range(c.n_levels):
+            L = c.levels[l]
+            iters = []
+            for k in range(L.n_iterations if its is not None else 0):
+                it = its[L.first_iteration + k]
+                iters.append({
+                    "Id": it.id, "ValidConstraints": it.valid_constraints,
+                    "TDistributionLogLikelihood": it.tdist_loglik,
+                    "TDistributionPrecision": np.array(it.tdist_precision[:]).reshape(2, 2).T.copy(),
+                    "PriorLogLikelihood": it.prior_loglik, "has_increment": bool(it.has_increment),
+                    "EstimateIncrement": np.array(it.increment[:]),
+                    "EstimateInformation": np.array(it.information[:]).reshape(6, 6).T.copy(),
+                })
+            self.Levels.append({"Id": L.id, "MaxValidPixels": L.max_valid_pixels, "ValidPixels": L.valid_pixels,
+                                "TerminationCriterion": L.termination, "Iterations": iters})
+
+    def isNaN(self) -> bool:
+        return self._is_nan
+
+
+class DenseTracker:
+    """dvo::DenseTracker: configure(), match(reference, current, T_init) -> Result.  One HIP stream; not thread-safe."""
+
+    def __init__(self, config: Config | None = None, device: int = 0):
+        self._cfg = config or Config()
+        if not self._cfg.IsSane():
+            raise DvoAmdError(5, "DenseTracker.configure")
+        self._h = C.c_void_p()
+        c = self._cfg._c()
+        _check(lib().dvo_amd_context_create(device, C.byref(c), C.byref(self._h)), "dvo_amd_context_create")
+        self.device = device
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().dvo_amd_context_destroy(h)
+            self._h = None
+
+    def configuration(self) -> Config:
+        return self._cfg
+
+    def configure(self, config: Config):
+        c = config._c()
+        _check(lib().dvo_amd_configure(self._h, C.byref(c)), "dvo_amd_configure")
+        self._cfg = config
+
+    def _alloc_results(self, n):
+        cap = (self._cfg.FirstLevel - self._cfg.LastLevel + 1) * (self._cfg.MaxIterationsPerLevel + 1)
+        res = (CResult * n)()
+        its = []
+        for i in range(n):
+            buf = (CIterationStats * cap)()
+            its.append(buf)
+            res[i].iterations = C.cast(buf, C.POINTER(CIterationStats))
+            res[i].iterations_capacity = cap
+        return res, its
+
+    def match(self, reference: RgbdImagePyramid, current: RgbdImagePyramid, T_init=None) -> Result:
+        res, its = self._alloc_results(1)
+        T0 = None
+        if T_init is not None:
+            T0a = np.ascontiguousarray(np.asarray(T_init, dtype=np.float64).T)
+            T0 = T0a.ctypes.data_as(C.POINTER(C.c_double))
+        _check(lib().dvo_amd_match(self._h, reference._h, current._h, T0, C.byref(res[0])), "dvo_amd_match")
+        return Result(res[0], its[0])
+
+    def match_batch(self, references, currents, T_inits=None, stats: bool = True):
+        """n independent match() calls advanced in lock step on this tracker's GPU."""
+        n = len(references)
+        assert len(currents) == n
+        if stats:
+            res, its = self._alloc_results(n)
+        else:
+            res, its = (CResult * n)(), [None] * n
+        refs = (C.c_void_p * n)(*[r._h for r in references])
+        curs = (C.c_void_p * n)(*[c._h for c in currents])
+        T0 = None
+        if T_inits is not None:
+            T0a = np.ascontiguousarray(np.stack([np.asarray(T, dtype=np.float64).T for T in T_inits]))
+            T0 = T0a.ctypes.data_as(C.POINTER(C.c_double))
+        _check(lib().dvo_amd_match_batch(self._h, n, refs, curs, T0, res), "dvo_amd_match_batch")
+        if not stats:
+            return [Result(res[i], None) for i in range(n)]
+        return [Result(res[i], its[i]) for i in range(n)]
+
+    def residuals(self, reference: RgbdImagePyramid, current: RgbdImagePyramid, level: int, T):
+        """computeResidualsAndValidFlagsSse: (residuals[h, w, 2] with NaN = invalid, n_valid)."""
+        w, h, _ = reference.level_info(level)
+        out = np.empty((h, w, 2), np.float32)
+        Tf = np.ascontiguousarray(np.asarray(T, dtype=np.float64).astype(np.float32).T)
+        n = C.c_int()
+        _check(lib().dvo_amd_residuals(self._h, reference._h, current._h, level, _fp(Tf), _fp(out), C.byref(n)),
+               "dvo_amd_residuals")
+        return out, n.value
+
+    def computeIntensityErrorImage(self, reference, current, T, level: int = 0) -> np.ndarray:
+        w, h, _ = reference.level_info(level)
+        out = np.empty((h, w), np.float32)
+        Td = np.ascontiguousarray(np.asarray(T, dtype=np.float64).T)
+        _check(lib().dvo_amd_error_image(self._h, reference._h, current._h, Td.ctypes.data_as(C.POINTER(C.c_double)),
+                                         level, _fp(out)), "dvo_amd_error_image")
+        return out
+
+    def kernel_timing(self, enable: bool, reset: bool = False):
+        ms = C.c_double()
+        n = C.c_longlong()
+        _check(lib().dvo_amd_kernel_timing(self._h, int(enable), C.byref(ms), C.byref(n), int(reset)), "kernel_timing")
+        return ms.value, n.value

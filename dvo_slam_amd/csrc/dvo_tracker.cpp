@@ -1,0 +1,1121 @@
+// Host side of the MI355X dense tracking core: device pyramids, the Gauss-Newton driver and the C ABI (include/dvo_amd.h).
+//
+// The driver restates DenseTracker::match (dvo_core/src/dense_tracking.cpp:131-376) as a per-pair state machine that is
+// advanced in "ticks".  One tick = one k_tick launch (+ one k_finalize) + one stream synchronisation, for all pairs of a
+// batch at once.  Within a level the log-likelihood of iteration k (which needs the precision matrix of iteration k, which
+// needs a global reduction over iteration k's residuals) is evaluated in the same launch as the residual pass of iteration
+// k+1: the increment x_k is applied speculatively and rolled back if the likelihood test of iteration k fails
+// (dense_tracking.cpp:312-322), which ends the level anyway.  So a level costs (iterations + 1) round trips.
+//
+// The 6x6 solve, SE(3) exp/log and the 2x2 inverse stay on the host (se3.h), as in the reference.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/dvo_amd.h"
+#include "dvo_types.h"
+#include "se3.h"
+
+using namespace dvo_amd;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail_hip(const char *what, hipError_t e) {
+  g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+  return e == hipErrorOutOfMemory ? DVO_AMD_ERR_OUT_OF_MEMORY : DVO_AMD_ERR_HIP;
+}
+
+#define HIP_TRY(expr)                                    \
+  do {                                                   \
+    hipError_t e_ = (expr);                              \
+    if (e_ != hipSuccess) return fail_hip(#expr, e_);    \
+  } while (0)
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- per-device shared state: a prep stream and a pool of pyramid slabs ------------------------------------------
+struct DeviceState {
+  std::mutex mu;
+  hipStream_t prep_stream = nullptr;
+  std::vector<std::pair<size_t, void *>> free_slabs;
+};
+constexpr int kMaxDevices = 16;
+DeviceState g_dev[kMaxDevices];
+
+int device_prep_stream(int device, hipStream_t *s) {
+  DeviceState &d = g_dev[device];
+  std::lock_guard<std::mutex> lk(d.mu);
+  if (!d.prep_stream) HIP_TRY(hipStreamCreateWithFlags(&d.prep_stream, hipStreamNonBlocking));
+  *s = d.prep_stream;
+  return DVO_AMD_OK;
+}
+
+int slab_alloc(int device, size_t bytes, void **out) {
+  DeviceState &d = g_dev[device];
+  {
+    std::lock_guard<std::mutex> lk(d.mu);
+    for (size_t i = 0; i < d.free_slabs.size(); ++i)
+      if (d.free_slabs[i].first == bytes) {
+        *out = d.free_slabs[i].second;
+        d.free_slabs.erase(d.free_slabs.begin() + (long)i);
+        return DVO_AMD_OK;
+      }
+  }
+  HIP_TRY(hipMalloc(out, bytes));
+  return DVO_AMD_OK;
+}
+
+void slab_free(int device, size_t bytes, void *p) {
+  DeviceState &d = g_dev[device];
+  std::lock_guard<std::mutex> lk(d.mu);
+  if (d.free_slabs.size() < 64) {
+    d.free_slabs.emplace_back(bytes, p);
+  } else {
+    (void)hipFree(p);
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+// pyramid
+// ------------------------------------------------------------------------------------------------------------------
+
+struct Selection {
+  float ti, td;
+  float *zsel[DVO_AMD_MAX_LEVELS];
+  int count[DVO_AMD_MAX_LEVELS];  // PointSelection size (includes an odd trailing point)
+  int last[DVO_AMD_MAX_LEVELS];   // index of the last selected pixel
+  void *extra_slab;               // owned allocation (null for the selection carved from the pyramid slab)
+  size_t extra_bytes;
+};
+
+struct LevelData {
+  int w, h, n, n_pad;
+  float fx, fy, ox, oy;
+  float *i_plane, *z_plane;
+  float4 *c_a;
+  float2 *c_b;
+  float *r_i, *r_ix, *r_iy;
+  float *tx, *ty;
+  float *zsel0;  // room for the first selection
+};
+
+struct dvo_amd_pyramid {
+  std::atomic<int> refs{1};
+  int device = 0;
+  int n_levels = 0;
+  double timestamp = 0.0;
+  LevelData lv[DVO_AMD_MAX_LEVELS];
+  void *slab = nullptr;
+  size_t slab_bytes = 0;
+  int *counters = nullptr;  // device, [levels][2], inside the slab
+  std::mutex mu;
+  std::vector<Selection> selections;
+};
+
+namespace {
+
+size_t pyramid_layout(dvo_amd_pyramid *p, char *base) {
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    char *ptr = base ? base + off : nullptr;
+    off += align_up(bytes, 256);
+    return ptr;
+  };
+  for (int l = 0; l < p->n_levels; ++l) {
+    LevelData &L = p->lv[l];
+    L.i_plane = (float *)carve(sizeof(float) * L.n);
+    L.z_plane = (float *)carve(sizeof(float) * L.n);
+    L.c_a = (float4 *)carve(sizeof(float4) * L.n);
+    L.c_b = (float2 *)carve(sizeof(float2) * L.n);
+    L.r_i = (float *)carve(sizeof(float) * L.n_pad);
+    L.r_ix = (float *)carve(sizeof(float) * L.n_pad);
+    L.r_iy = (float *)carve(sizeof(float) * L.n_pad);
+    L.zsel0 = (float *)carve(sizeof(float) * L.n_pad);
+    L.tx = (float *)carve(sizeof(float) * L.w);
+    L.ty = (float *)carve(sizeof(float) * L.h);
+  }
+  p->counters = (int *)carve(sizeof(int) * 2 * DVO_AMD_MAX_LEVELS);
+  return off;
+}
+
+int pyramid_build(int device, const float *src_i, const float *src_z, bool src_on_device, int width, int height, int stride,
+                  float fx, float fy, float ox, float oy, int levels, double timestamp, dvo_amd_pyramid **out) {
+  if (!out) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (!src_i || !src_z || width < 4 || height < 2 || stride < width || levels < 1 || levels > DVO_AMD_MAX_LEVELS)
+    return DVO_AMD_ERR_INVALID_ARGUMENT;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return DVO_AMD_ERR_NO_DEVICE;
+  if (device < 0 || device >= ndev || device >= kMaxDevices) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  {
+    int w = width, h = height;
+    for (int l = 0; l < levels; ++l, w /= 2, h /= 2)
+      if (w < 4 || h < 2 || (w % 4) != 0) return DVO_AMD_ERR_INVALID_ARGUMENT;  // see header: width % 4 on every level
+  }
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t st;
+  int rc = device_prep_stream(device, &st);
+  if (rc) return rc;
+
+  dvo_amd_pyramid *p = new dvo_amd_pyramid();
+  p->device = device;
+  p->n_levels = levels;
+  p->timestamp = timestamp;
+  for (int l = 0; l < levels; ++l) {
+    LevelData &L = p->lv[l];
+    if (l == 0) {
+      L.w = width, L.h = height, L.fx = fx, L.fy = fy, L.ox = ox, L.oy = oy;
+    } else {
+      // RgbdCameraPyramid::build (rgbd_image.cpp:283-296) with IntrinsicMatrix::scale(0.5f) (intrinsic_matrix.cpp:90-93)
+      const LevelData &P = p->lv[l - 1];
+      L.w = P.w / 2, L.h = P.h / 2;
+      L.fx = P.fx * 0.5f, L.fy = P.fy * 0.5f, L.ox = P.ox * 0.5f, L.oy = P.oy * 0.5f;
+    }
+    L.n = L.w * L.h;
+    L.n_pad = (int)align_up((size_t)L.n, kPlanePad);
+  }
+  p->slab_bytes = pyramid_layout(p, nullptr);
+  rc = slab_alloc(device, p->slab_bytes, &p->slab);
+  if (rc) {
+    delete p;
+    return rc;
+  }
+  pyramid_layout(p, (char *)p->slab);
+
+  // everything below is enqueued on the device's prep stream; the mutex serialises users of that stream's ordering needs
+  auto bail = [&](int code) {
+    slab_free(device, p->slab_bytes, p->slab);
+    delete p;
+    return code;
+  };
+  LevelData &L0 = p->lv[0];
+  hipError_t e;
+  if (src_on_device) {
+    if (stride == width) {
+      e = hipMemcpyAsync(L0.i_plane, src_i, sizeof(float) * L0.n, hipMemcpyDeviceToDevice, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(L0.z_plane, src_z, sizeof(float) * L0.n, hipMemcpyDeviceToDevice, st);
+    } else {
+      e = launch_copy_strided(src_i, stride, L0.i_plane, width, height, st);
+      if (e == hipSuccess) e = launch_copy_strided(src_z, stride, L0.z_plane, width, height, st);
+    }
+  } else {
+    e = hipMemcpy2DAsync(L0.i_plane, sizeof(float) * width, src_i, sizeof(float) * stride, sizeof(float) * width, height,
+                         hipMemcpyHostToDevice, st);
+    if (e == hipSuccess)
+      e = hipMemcpy2DAsync(L0.z_plane, sizeof(float) * width, src_z, sizeof(float) * stride, sizeof(float) * width, height,
+                           hipMemcpyHostToDevice, st);
+  }
+  if (e != hipSuccess) return bail(fail_hip("pyramid upload", e));
+  for (int l = 0; l < levels; ++l) {
+    LevelData &L = p->lv[l];
+    if (l > 0) {
+      const LevelData &P = p->lv[l - 1];
+      e = launch_pyr_down(P.i_plane, P.z_plane, P.w, L.i_plane, L.z_plane, L.w, L.h, st);
+      if (e != hipSuccess) return bail(fail_hip("pyr_down", e));
+    }
+    e = launch_level_planes(L.i_plane, L.z_plane, L.w, L.h, L.n_pad, L.fx, L.fy, L.ox, L.oy, L.c_a, L.c_b, L.r_i, L.r_ix,
+                            L.r_iy, L.tx, L.ty, L.h, st);
+    if (e != hipSuccess) return bail(fail_hip("level_planes", e));
+  }
+  e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return bail(fail_hip("pyramid build", e));
+  *out = p;
+  return DVO_AMD_OK;
+}
+
+// PointSelection::select for every level, cached per threshold pair (the reference caches per PointSelection object until
+// setRgbdImagePyramid, point_selection.cpp:51-59,100; pyramids are immutable here, so the cache never goes stale)
+int pyramid_selection(dvo_amd_pyramid *p, float ti, float td, int *index) {
+  std::lock_guard<std::mutex> lk(p->mu);
+  for (size_t i = 0; i < p->selections.size(); ++i)
+    if (p->selections[i].ti == ti && p->selections[i].td == td) {
+      *index = (int)i;
+      return DVO_AMD_OK;
+    }
+  HIP_TRY(hipSetDevice(p->device));
+  hipStream_t st;
+  int rc = device_prep_stream(p->device, &st);
+  if (rc) return rc;
+  Selection s;
+  s.ti = ti, s.td = td, s.extra_slab = nullptr, s.extra_bytes = 0;
+  if (p->selections.empty()) {
+    for (int l = 0; l < p->n_levels; ++l) s.zsel[l] = p->lv[l].zsel0;
+  } else {
+    size_t bytes = 0;
+    for (int l = 0; l < p->n_levels; ++l) bytes += align_up(sizeof(float) * p->lv[l].n_pad, 256);
+    HIP_TRY(hipMalloc(&s.extra_slab, bytes));
+    s.extra_bytes = bytes;
+    size_t off = 0;
+    for (int l = 0; l < p->n_levels; ++l) {
+      s.zsel[l] = (float *)((char *)s.extra_slab + off);
+      off += align_up(sizeof(float) * p->lv[l].n_pad, 256);
+    }
+  }
+  for (int l = 0; l < p->n_levels; ++l) {
+    const LevelData &L = p->lv[l];
+    hipError_t e = launch_select(L.z_plane, L.c_a, L.c_b, L.n, L.n_pad, ti, td, s.zsel[l], p->counters + 2 * l, st);
+    if (e != hipSuccess) return fail_hip("select", e);
+  }
+  int host_counters[2 * DVO_AMD_MAX_LEVELS];
+  HIP_TRY(hipMemcpyAsync(host_counters, p->counters, sizeof(int) * 2 * p->n_levels, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  for (int l = 0; l < p->n_levels; ++l) s.count[l] = host_counters[2 * l], s.last[l] = host_counters[2 * l + 1];
+  p->selections.push_back(s);
+  *index = (int)p->selections.size() - 1;
+  return DVO_AMD_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+// context + Gauss-Newton driver
+// ------------------------------------------------------------------------------------------------------------------
+
+struct JobSlot {
+  float2 *res[2] = {nullptr, nullptr};
+  float *records = nullptr;
+  double *ll_partials = nullptr;
+  int *cut[2] = {nullptr, nullptr};
+  FinOut *out = nullptr;  // pinned host memory, device-visible
+  void *dev_block = nullptr;
+};
+
+struct dvo_amd_context {
+  int device = 0;
+  dvo_amd_config cfg;
+  hipStream_t stream = nullptr;
+  std::vector<JobSlot> slots;
+  int slot_n_pad = 0;  // capacity every slot was sized for
+  FinOut *out_host = nullptr;
+  int out_capacity = 0;
+  // optional kernel timing (bench.py roofline section)
+  bool timing = false;
+  double timing_ms = 0.0;
+  long long timing_launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  size_t events_used = 0;
+};
+
+namespace {
+
+// one Gauss-Newton iteration whose residual pass has been submitted
+struct IterCtx {
+  int k = 0;
+  int buf = 0;
+  int rounds = 1;
+  int n_blocks = 0;
+  SE3 inc;
+  SE3 initial_before, estimate_before;
+  SE3 initial_after, estimate_after;
+  double x_before[6];
+  // after the residual pass
+  int n = 0;
+  float cov[4], P[4];
+  double A[36], b[6], x_new[6], prior = 0.0;
+  bool cont = false;
+  int stats_index = -1;
+};
+
+struct Job {
+  dvo_amd_pyramid *ref = nullptr, *cur = nullptr;
+  int sel = 0;
+  dvo_amd_result *result = nullptr;
+  JobSlot *slot = nullptr;
+  const dvo_amd_config *cfg = nullptr;
+  // reference-visible state (names follow dense_tracking.cpp:131-376)
+  int level = 0, iteration = 0;
+  SE3 inc, initial, estimate;
+  double x[6];
+  double error = DBL_MAX, last_error = DBL_MAX;
+  float precision[4] = {0, 0, 0, 0};
+  bool done = false;
+  int status = DVO_AMD_OK;
+  // in flight
+  bool have_a = false, have_b = false;  // a: iteration awaiting its likelihood; b: iteration whose residual pass is in flight
+  bool sub_ll = false, sub_res = false;
+  IterCtx a, b;
+  // the last two iteration entries of the current level (the final result reads one of them, dense_tracking.cpp:368-373)
+  dvo_amd_iteration_stats recent[2];
+  int recent_count = 0;
+  int level_first_iteration = 0;
+  double alg_px = 0.0;
+};
+
+dvo_amd_iteration_stats *stats_push(Job &j) {
+  dvo_amd_result *r = j.result;
+  dvo_amd_level_stats &ls = r->levels[r->n_levels - 1];
+  ls.n_iterations++;
+  if (j.recent_count == 2) j.recent[0] = j.recent[1], j.recent_count = 1;
+  dvo_amd_iteration_stats *e = &j.recent[j.recent_count++];
+  std::memset(e, 0, sizeof(*e));
+  r->n_iterations++;
+  return e;
+}
+
+// mirror the newest entry of `recent` into the caller's array (if it has room)
+void stats_publish(Job &j) {
+  dvo_amd_result *r = j.result;
+  const int idx = r->n_iterations - 1;
+  if (r->iterations && idx < r->iterations_capacity) r->iterations[idx] = j.recent[j.recent_count - 1];
+}
+
+void begin_iteration(Job &j, IterCtx &it, int k) {
+  // dense_tracking.cpp:259-261
+  it.k = k;
+  std::memcpy(it.x_before, j.x, sizeof(j.x));
+  it.inc = se3_exp(j.x);
+  it.initial_before = j.initial;
+  it.estimate_before = j.estimate;
+  j.inc = it.inc;
+  j.initial = se3_compose(se3_inverse(it.inc), j.initial);
+  j.estimate = se3_compose(it.inc, j.estimate);
+  it.initial_after = j.initial;
+  it.estimate_after = j.estimate;
+  it.buf = k & 1;
+}
+
+void finish_job(Job &j) {
+  // dense_tracking.cpp:368-373
+  dvo_amd_result *r = j.result;
+  const dvo_amd_level_stats &last = r->levels[r->n_levels - 1];
+  const int want = last.termination != DVO_AMD_TERM_LOGLIKELIHOOD_DECREASED ? last.n_iterations - 1 : last.n_iterations - 2;
+  const dvo_amd_iteration_stats *e = nullptr;
+  if (want >= 0) {
+    const int back = (last.n_iterations - 1) - want;  // 0 or 1 entries before the newest
+    if (back < j.recent_count) e = &j.recent[j.recent_count - 1 - back];
+  }
+  se3_matrix(se3_inverse(j.estimate), r->transformation);
+  if (e && e->has_increment) {
+    for (int i = 0; i < 36; ++i) r->information[i] = e->information[i] * 0.008 * 0.008;
+    r->loglik = e->tdist_loglik + e->prior_loglik;
+  } else {
+    // the reference reads an IterationStats that was never filled (uninitialised Eigen storage) or indexes before the
+    // start of the vector here; report NaN so that Result::isNaN() fires
+    for (int i = 0; i < 36; ++i) r->information[i] = NAN;
+    r->loglik = NAN;
+  }
+  double s = 0.0, si = 0.0;
+  for (int i = 0; i < 16; ++i) s += r->transformation[i];
+  for (int i = 0; i < 36; ++i) si += r->information[i];
+  r->is_nan = !(std::isfinite(s) && std::isfinite(si));
+  r->alg_bytes = 56.0 * j.alg_px;
+  j.done = true;
+}
+
+void start_level(Job &j);
+
+void end_level(Job &j) {
+  dvo_amd_result *r = j.result;
+  dvo_amd_level_stats &ls = r->levels[r->n_levels - 1];
+  // dense_tracking.cpp:359-363, evaluated after a break as well
+  if (inf_norm6(j.x) <= j.cfg->precision) ls.termination = DVO_AMD_TERM_INCREMENT_TOO_SMALL;
+  if (j.iteration >= j.cfg->max_iterations_per_level) ls.termination = DVO_AMD_TERM_ITERATIONS_EXCEEDED;
+  j.have_a = j.have_b = false;
+  j.level--;
+  if (j.level < j.cfg->last_level)
+    finish_job(j);
+  else
+    start_level(j);
+}
+
+void start_level(Job &j) {
+  dvo_amd_result *r = j.result;
+  dvo_amd_level_stats &ls = r->levels[r->n_levels++];
+  const Selection &sel = j.ref->selections[j.sel];
+  const LevelData &L0 = j.ref->lv[0];
+  ls.id = j.level;
+  // PointSelection::getMaximumNumberOfPoints, point_selection.cpp:68-71
+  ls.max_valid_pixels = (int)(size_t)((double)((size_t)L0.w * L0.h) * std::pow(0.25, (double)j.level));
+  ls.valid_pixels = sel.count[j.level];
+  ls.termination = DVO_AMD_TERM_UNSET;
+  ls.n_iterations = 0;
+  ls.first_iteration = r->n_iterations;
+  j.level_first_iteration = r->n_iterations;
+  j.recent_count = 0;
+  j.iteration = 0;
+  j.error = DBL_MAX;  // dense_tracking.cpp:209-210
+  j.last_error = DBL_MAX;
+  std::memset(j.precision, 0, sizeof(j.precision));
+  se3_log(j.inc, j.x);  // :238 (Q1: re-applies the last applied or rejected increment)
+  begin_iteration(j, j.b, 0);
+  j.have_a = false;
+  j.have_b = true;
+}
+
+// K * T[0:3,0:4] in float, evaluated like Eigen's coefficient-based 3x3 * 3x4 product (dense_tracking_impl.cpp:142-152)
+void make_kt(const LevelData &C, const SE3 &estimate, float kt[12]) {
+  double Td[16];
+  se3_matrix(estimate, Td);
+  float T[16];
+  for (int i = 0; i < 16; ++i) T[i] = (float)Td[i];  // estimate().matrix().cast<float>(), dense_tracking.cpp:263
+  const float K[9] = {C.fx, 0.0f, C.ox, 0.0f, C.fy, C.oy, 0.0f, 0.0f, 1.0f};
+  for (int i = 0; i < 3; ++i)
+    for (int c = 0; c < 4; ++c)
+      kt[i * 4 + c] = (K[i * 3 + 0] * T[c * 4 + 0] + K[i * 3 + 1] * T[c * 4 + 1]) + K[i * 3 + 2] * T[c * 4 + 2];
+}
+
+void fill_level_fields(WorkItem &w, const dvo_amd_pyramid *ref, int sel, const dvo_amd_pyramid *cur, int level) {
+  const LevelData &R = ref->lv[level];
+  const LevelData &C = cur->lv[level];
+  w.w = C.w, w.h = C.h;
+  w.r_zsel = ref->selections[sel].zsel[level];
+  w.r_i = R.r_i, w.r_ix = R.r_ix, w.r_iy = R.r_iy;
+  w.tx = R.tx, w.ty = R.ty;
+  w.c_a = C.c_a, w.c_b = C.c_b;
+  // wcur / wref, dense_tracking.cpp:215-220
+  const float wcur_id = 0.5f, wref_id = 0.5f, wcur_zd = 1.0f;
+  w.wc[0] = 1.0f / 255.0f, w.wc[1] = 1.0f;
+  w.wc[2] = wcur_id * C.fx / 255.0f, w.wc[3] = wcur_id * C.fy / 255.0f;
+  w.wc[4] = wcur_zd * C.fx, w.wc[5] = wcur_zd * C.fy;
+  w.wr[0] = -1.0f / 255.0f, w.wr[1] = -1.0f;
+  w.wr[2] = wref_id * C.fx / 255.0f, w.wr[3] = wref_id * C.fy / 255.0f;
+  w.ub_x = (float)(size_t)(C.w - 2), w.ub_y = (float)(size_t)(C.h - 2);
+}
+
+int blocks_for(int n, int rounds) {
+  const int px_per_block = kSegPxPerRound * kWavesPerBlock * rounds;
+  return (n + px_per_block - 1) / px_per_block;
+}
+
+// the residual pass of iteration `it` came back: dense_tracking.cpp:273-347 minus the likelihood test
+void process_residual(Job &j, IterCtx &it, const FinOut &o) {
+  dvo_amd_iteration_stats *e = stats_push(j);
+  e->id = it.k;
+  it.n = o.valid;
+  e->valid_constraints = it.n;
+  it.stats_index = j.result->n_iterations - 1;
+  if (it.n < 6) {  // :276-284
+    j.initial = it.initial_before;
+    j.estimate = it.estimate_before;
+    j.result->levels[j.result->n_levels - 1].termination = DVO_AMD_TERM_TOO_FEW_CONSTRAINTS;
+    stats_publish(j);
+    end_level(j);
+    return;
+  }
+  // computeScaleSse's 1/(n-2-1) and the 2x2 inverse (:295); S holds the unscaled pair sums
+  const float scale = 1.0f / (float)(size_t)(it.n - 2 - 1);
+  it.cov[0] = (float)(o.S[0] * (double)scale);
+  it.cov[1] = it.cov[2] = (float)(o.S[1] * (double)scale);
+  it.cov[3] = (float)(o.S[2] * (double)scale);
+  inverse2x2f(it.cov, it.P);
+  std::memcpy(j.precision, it.P, sizeof(it.P));
+
+  double xi_initial[6];
+  se3_log(it.initial_after, xi_initial);
+  double sq = 0.0;
+  for (int i = 0; i < 6; ++i) sq += xi_initial[i] * xi_initial[i];
+  it.prior = j.cfg->mu * sq;  // :302
+
+  // A = sum w J^T P J, b = -sum w J^T P r from the P-free moments; + Mu terms (:345-346)
+  const double p00 = it.P[0], p10 = it.P[1], p01 = it.P[2], p11 = it.P[3];
+  const double pab = 0.5 * (p01 + p10);
+  int t = 0;
+  for (int r = 0; r < 6; ++r)
+    for (int c = r; c < 6; ++c, ++t) {
+      const double v = p00 * o.acc[kAccAA + t] + pab * o.acc[kAccAB + t] + p11 * o.acc[kAccBB + t];
+      it.A[c * 6 + r] = v;
+      it.A[r * 6 + c] = v;
+    }
+  for (int i = 0; i < 6; ++i) {
+    it.A[i * 6 + i] += j.cfg->mu;
+    const double bi = -(p00 * o.acc[kAccAR0 + i] + p10 * o.acc[kAccBR0 + i] + p01 * o.acc[kAccAR1 + i] +
+                        p11 * o.acc[kAccBR1 + i]);
+    it.b[i] = bi + j.cfg->mu * xi_initial[i];
+  }
+  solve_ldlt6(it.A, it.b, it.x_new);  // :347
+  it.cont = inf_norm6(it.x_new) > j.cfg->precision && !(it.k + 1 >= j.cfg->max_iterations_per_level);
+
+  // this iteration now waits for its likelihood; if the loop would go on, run the next residual pass alongside
+  j.a = it;
+  j.have_a = true;
+  j.have_b = false;
+  if (j.a.cont) {
+    double keep_x[6];
+    std::memcpy(keep_x, j.x, sizeof(keep_x));
+    std::memcpy(j.x, j.a.x_new, sizeof(j.x));
+    begin_iteration(j, j.b, j.a.k + 1);
+    std::memcpy(j.x, keep_x, sizeof(keep_x));  // x is only committed once iteration a is accepted
+    j.have_b = true;
+  }
+}
+
+// the likelihood of iteration a came back: dense_tracking.cpp:297-322 and the tail of the loop (:351-357)
+void process_loglik(Job &j, const FinOut *outs) {
+  IterCtx &a = j.a;
+  const FinOut &o = outs[0];
+  const float det = a.P[0] * a.P[3] - a.P[1] * a.P[2];
+  // computeCompleteDataLogLikelihood, dense_tracking_impl.cpp:424
+  const float ll = (float)(0.5 * (double)(size_t)a.n * (double)std::log(det) - 0.5 * (5.0 + 2.0) * o.ll_sum);
+  dvo_amd_iteration_stats *e = &j.recent[j.recent_count - 1];
+  e->tdist_loglik = -(double)ll;
+  e->tdist_mean[0] = e->tdist_mean[1] = 0.0;
+  for (int i = 0; i < 4; ++i) e->tdist_precision[i] = a.P[i];
+  e->prior_loglik = a.prior;
+  j.last_error = j.error;
+  j.error = -(double)ll;
+  const bool accept = j.error < j.last_error;  // :312
+  if (!accept) {
+    // :314-322: roll back iteration a (and the speculative iteration b, if any)
+    j.initial = a.initial_before;
+    j.estimate = a.estimate_before;
+    j.inc = a.inc;
+    j.result->levels[j.result->n_levels - 1].termination = DVO_AMD_TERM_LOGLIKELIHOOD_DECREASED;
+    stats_publish(j);
+    end_level(j);
+    return;
+  }
+  std::memcpy(e->increment, a.x_new, sizeof(a.x_new));
+  std::memcpy(e->information, a.A, sizeof(a.A));
+  e->has_increment = 1;
+  stats_publish(j);
+  std::memcpy(j.x, a.x_new, sizeof(j.x));
+  j.iteration = a.k + 1;
+  if (!a.cont) {
+    end_level(j);
+    return;
+  }
+  // iteration b's residual pass ran in the same tick
+  j.have_a = false;
+  IterCtx b = j.b;
+  process_residual(j, b, o);
+}
+
+int ensure_slots(dvo_amd_context *ctx, int n_jobs, int n_pad) {
+  if ((int)ctx->slots.size() >= n_jobs && ctx->slot_n_pad >= n_pad) return DVO_AMD_OK;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const int new_pad = std::max(n_pad, ctx->slot_n_pad);
+  for (JobSlot &s : ctx->slots)
+    if (s.dev_block) (void)hipFree(s.dev_block);
+  ctx->slots.clear();
+  const int n_slots = std::max(n_jobs, 1);
+  if (ctx->out_capacity < n_slots) {
+    if (ctx->out_host) (void)hipHostFree(ctx->out_host);
+    ctx->out_host = nullptr;
+    HIP_TRY(hipHostMalloc((void **)&ctx->out_host, sizeof(FinOut) * n_slots, hipHostMallocMapped));
+    ctx->out_capacity = n_slots;
+  }
+  const int max_blocks = new_pad / (kSegPxPerRound * kWavesPerBlock);
+  const size_t b_res = align_up(sizeof(float2) * new_pad, 256);
+  const size_t b_rec = align_up(sizeof(float) * kRecStride * max_blocks, 256);
+  const size_t b_ll = align_up(sizeof(double) * max_blocks, 256);
+  const size_t b_cut = 256;
+  const size_t total = 2 * b_res + b_rec + b_ll + 2 * b_cut;
+  ctx->slots.resize(n_slots);
+  for (int i = 0; i < n_slots; ++i) {
+    JobSlot &s = ctx->slots[i];
+    HIP_TRY(hipMalloc(&s.dev_block, total));
+    char *p = (char *)s.dev_block;
+    s.res[0] = (float2 *)p, p += b_res;
+    s.res[1] = (float2 *)p, p += b_res;
+    s.records = (float *)p, p += b_rec;
+    s.ll_partials = (double *)p, p += b_ll;
+    s.cut[0] = (int *)p, p += b_cut;
+    s.cut[1] = (int *)p, p += b_cut;
+    FinOut *dev_out = nullptr;
+    HIP_TRY(hipHostGetDevicePointer((void **)&dev_out, ctx->out_host + i, 0));
+    s.out = dev_out;
+  }
+  ctx->slot_n_pad = new_pad;
+  return DVO_AMD_OK;
+}
+
+int pick_rounds(long long total_px) {
+  // keep roughly <= 6144 waves in a launch (256 CUs x 8 waves x 3): more work per wave amortises the 93-value reduction
+  const long long waves1 = total_px / kSegPxPerRound;
+  int rounds = 1;
+  while (rounds < kMaxRounds && waves1 / rounds > 6144) rounds *= 2;
+  return rounds;
+}
+
+int timing_begin(dvo_amd_context *ctx, size_t *slot) {
+  if (ctx->events_used == ctx->events.size()) {
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    ctx->events.emplace_back(a, b);
+  }
+  *slot = ctx->events_used++;
+  HIP_TRY(hipEventRecord(ctx->events[*slot].first, ctx->stream));
+  return DVO_AMD_OK;
+}
+
+int timing_collect(dvo_amd_context *ctx) {
+  for (size_t i = 0; i < ctx->events_used; ++i) {
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->events[i].first, ctx->events[i].second));
+    ctx->timing_ms += ms;
+    ctx->timing_launches++;
+  }
+  ctx->events_used = 0;
+  return DVO_AMD_OK;
+}
+
+// submit what every unfinished job needs, wait, advance the jobs
+int run_tick(dvo_amd_context *ctx, std::vector<Job> &jobs) {
+  long long total_px = 0;
+  for (Job &j : jobs)
+    if (!j.done && j.have_b) total_px += j.ref->lv[j.level].n;
+  const int rounds_now = pick_rounds(total_px);
+
+  std::vector<WorkItem> items;
+  FinArgs fin;
+  fin.n_items = 0;
+  auto flush_fin = [&]() -> int {
+    if (fin.n_items > 0) {
+      hipError_t e = launch_finalize(fin, ctx->stream);
+      if (e != hipSuccess) return fail_hip("launch_finalize", e);
+      fin.n_items = 0;
+    }
+    return DVO_AMD_OK;
+  };
+  std::vector<FinItem> fin_items;
+
+  for (size_t ji = 0; ji < jobs.size(); ++ji) {
+    Job &j = jobs[ji];
+    if (j.done) continue;
+    j.sub_ll = j.sub_res = false;
+    FinItem f;
+    f.records = nullptr, f.n_blocks = 0, f.n_ll_blocks = 0, f.ll_partials = j.slot->ll_partials;
+    f.cut_out = j.slot->cut[0], f.out = j.slot->out;
+    if (j.have_a) {
+      WorkItem w;
+      std::memset(&w, 0, sizeof(w));
+      w.type = kWorkLogLik;
+      fill_level_fields(w, j.ref, j.sel, j.cur, j.level);
+      w.rounds = j.a.rounds;
+      w.n_blocks = j.a.n_blocks;
+      w.res = j.slot->res[j.a.buf];
+      w.records = (float *)j.slot->ll_partials;
+      w.cut = j.slot->cut[j.a.buf];
+      std::memcpy(w.P, j.a.P, sizeof(w.P));
+      items.push_back(w);
+      f.n_ll_blocks = w.n_blocks;
+      j.sub_ll = true;
+    }
+    if (j.have_b) {
+      WorkItem w;
+      std::memset(&w, 0, sizeof(w));
+      w.type = kWorkResidual;
+      fill_level_fields(w, j.ref, j.sel, j.cur, j.level);
+      j.b.rounds = rounds_now;
+      j.b.n_blocks = blocks_for(j.ref->lv[j.level].n, rounds_now);
+      w.rounds = j.b.rounds;
+      w.n_blocks = j.b.n_blocks;
+      w.unit_weights = j.b.k == 0 ? 1 : 0;  // dense_tracking.cpp:286-293
+      w.res = j.slot->res[j.b.buf];
+      w.records = j.slot->records;
+      make_kt(j.cur->lv[j.level], j.b.estimate_after, w.kt);
+      // weights of iteration k use the precision of iteration k-1, which is iteration a's (or stale zeros at k = 0)
+      std::memcpy(w.P, j.have_a ? j.a.P : j.precision, sizeof(w.P));
+      items.push_back(w);
+      f.records = j.slot->records;
+      f.n_blocks = w.n_blocks;
+      f.cut_out = j.slot->cut[j.b.buf];
+      j.sub_res = true;
+      j.result->n_residual_passes++;
+      j.alg_px += (double)j.ref->selections[j.sel].count[j.level];
+    }
+    if (j.sub_ll || j.sub_res) {
+      fin_items.push_back(f);
+      j.result->n_ticks++;
+    }
+  }
+
+  // residual / likelihood work, kMaxItemsPerLaunch items per launch
+  for (size_t first = 0; first < items.size(); first += kMaxItemsPerLaunch) {
+    TickArgs ta;
+    ta.n_items = (int)std::min<size_t>(kMaxItemsPerLaunch, items.size() - first);
+    ta.pad = 0;
+    int max_blocks = 0;
+    for (int i = 0; i < ta.n_items; ++i) {
+      ta.items[i] = items[first + i];
+      max_blocks = std::max(max_blocks, ta.items[i].n_blocks);
+    }
+    size_t ev = 0;
+    if (ctx->timing) {
+      int rc = timing_begin(ctx, &ev);
+      if (rc) return rc;
+    }
+    hipError_t e = launch_tick(ta, max_blocks, ctx->stream);
+    if (e != hipSuccess) return fail_hip("launch_tick", e);
+    if (ctx->timing) HIP_TRY(hipEventRecord(ctx->events[ev].second, ctx->stream));
+  }
+  for (size_t i = 0; i < fin_items.size(); ++i) {
+    fin.items[fin.n_items++] = fin_items[i];
+    if (fin.n_items == kMaxFinItems) {
+      int rc = flush_fin();
+      if (rc) return rc;
+    }
+  }
+  {
+    int rc = flush_fin();
+    if (rc) return rc;
+  }
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ctx->timing) {
+    int rc = timing_collect(ctx);
+    if (rc) return rc;
+  }
+
+  for (size_t ji = 0; ji < jobs.size(); ++ji) {
+    Job &j = jobs[ji];
+    if (j.done || !(j.sub_ll || j.sub_res)) continue;
+    const FinOut *o = ctx->out_host + (j.slot - ctx->slots.data());
+    if (j.sub_ll) {
+      process_loglik(j, o);
+    } else {
+      IterCtx b = j.b;
+      process_residual(j, b, *o);
+    }
+  }
+  return DVO_AMD_OK;
+}
+
+int check_config(const dvo_amd_config *c) {
+  if (!c) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  if (c->first_level < c->last_level) return DVO_AMD_ERR_INSANE_CONFIG;  // Config::IsSane
+  if (c->last_level < 0 || c->first_level >= DVO_AMD_MAX_LEVELS || c->max_iterations_per_level < 1)
+    return DVO_AMD_ERR_INVALID_ARGUMENT;
+  return DVO_AMD_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+int dvo_amd_abi_version(void) { return DVO_AMD_ABI_VERSION; }
+
+const char *dvo_amd_status_string(int s) {
+  switch (s) {
+    case DVO_AMD_OK: return "ok";
+    case DVO_AMD_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case DVO_AMD_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
+    case DVO_AMD_ERR_HIP: return "HIP runtime error";
+    case DVO_AMD_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case DVO_AMD_ERR_INSANE_CONFIG: return "configuration is not sane (FirstLevel < LastLevel)";
+    case DVO_AMD_ERR_TOO_FEW_LEVELS: return "pyramid has fewer levels than FirstLevel + 1";
+    case DVO_AMD_ERR_CAPACITY: return "caller-provided array too small";
+    case DVO_AMD_ERR_DEVICE_MISMATCH: return "pyramid and context live on different devices";
+    case DVO_AMD_ERR_NAN_INIT: return "initial estimate is NaN";
+    case DVO_AMD_ERR_COMM: return "communicator error";
+    default: return "unknown status";
+  }
+}
+
+const char *dvo_amd_last_error(void) { return g_last_error.c_str(); }
+
+int dvo_amd_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void dvo_amd_default_config(dvo_amd_config *c) {
+  if (!c) return;
+  c->first_level = 3;
+  c->last_level = 1;
+  c->max_iterations_per_level = 100;
+  c->precision = 5e-7;
+  c->mu = 0.0;
+  c->use_initial_estimate = 0;
+  c->intensity_derivative_threshold = 0.0f;
+  c->depth_derivative_threshold = 0.0f;
+}
+
+int dvo_amd_context_create(int device, const dvo_amd_config *cfg, dvo_amd_context **out) {
+  if (!out) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return DVO_AMD_ERR_NO_DEVICE;
+  if (device < 0 || device >= ndev || device >= kMaxDevices) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  dvo_amd_config c;
+  dvo_amd_default_config(&c);
+  if (cfg) c = *cfg;
+  int rc = check_config(&c);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(device));
+  dvo_amd_context *ctx = new dvo_amd_context();
+  ctx->device = device;
+  ctx->cfg = c;
+  hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete ctx;
+    return fail_hip("hipStreamCreate", e);
+  }
+  *out = ctx;
+  return DVO_AMD_OK;
+}
+
+void dvo_amd_context_destroy(dvo_amd_context *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (JobSlot &s : ctx->slots)
+    if (s.dev_block) (void)hipFree(s.dev_block);
+  if (ctx->out_host) (void)hipHostFree(ctx->out_host);
+  for (auto &ev : ctx->events) {
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int dvo_amd_configure(dvo_amd_context *ctx, const dvo_amd_config *cfg) {
+  if (!ctx) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  int rc = check_config(cfg);
+  if (rc) return rc;
+  ctx->cfg = *cfg;
+  return DVO_AMD_OK;
+}
+
+int dvo_amd_get_config(const dvo_amd_context *ctx, dvo_amd_config *cfg) {
+  if (!ctx || !cfg) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  *cfg = ctx->cfg;
+  return DVO_AMD_OK;
+}
+
+int dvo_amd_pyramid_create(int device, const float *intensity, const float *depth, int width, int height, int stride,
+                           float fx, float fy, float ox, float oy, int levels, double timestamp, dvo_amd_pyramid **out) {
+  return pyramid_build(device, intensity, depth, false, width, height, stride, fx, fy, ox, oy, levels, timestamp, out);
+}
+
+int dvo_amd_pyramid_create_from_device(int device, const float *d_intensity, const float *d_depth, int width, int height,
+                                       int stride, float fx, float fy, float ox, float oy, int levels, double timestamp,
+                                       dvo_amd_pyramid **out) {
+  return pyramid_build(device, d_intensity, d_depth, true, width, height, stride, fx, fy, ox, oy, levels, timestamp, out);
+}
+
+void dvo_amd_pyramid_retain(dvo_amd_pyramid *p) {
+  if (p) p->refs.fetch_add(1);
+}
+
+void dvo_amd_pyramid_release(dvo_amd_pyramid *p) {
+  if (!p) return;
+  if (p->refs.fetch_sub(1) != 1) return;
+  (void)hipSetDevice(p->device);
+  for (Selection &s : p->selections)
+    if (s.extra_slab) (void)hipFree(s.extra_slab);
+  slab_free(p->device, p->slab_bytes, p->slab);
+  delete p;
+}
+
+int dvo_amd_pyramid_levels(const dvo_amd_pyramid *p) { return p ? p->n_levels : 0; }
+double dvo_amd_pyramid_timestamp(const dvo_amd_pyramid *p) { return p ? p->timestamp : 0.0; }
+
+int dvo_amd_pyramid_level_info(const dvo_amd_pyramid *p, int level, int *width, int *height, float k[4]) {
+  if (!p || level < 0 || level >= p->n_levels) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  const LevelData &L = p->lv[level];
+  if (width) *width = L.w;
+  if (height) *height = L.h;
+  if (k) k[0] = L.fx, k[1] = L.fy, k[2] = L.ox, k[3] = L.oy;
+  return DVO_AMD_OK;
+}
+
+int dvo_amd_pyramid_download_plane(const dvo_amd_pyramid *p, int level, int plane, float *dst) {
+  if (!p || !dst || level < 0 || level >= p->n_levels || plane < 0 || plane > 5) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(p->device));
+  hipStream_t st;
+  int rc = device_prep_stream(p->device, &st);
+  if (rc) return rc;
+  const LevelData &L = p->lv[level];
+  float *tmp = nullptr;
+  HIP_TRY(hipMalloc((void **)&tmp, sizeof(float) * L.n));
+  hipError_t e = launch_unpack_plane(L.c_a, L.c_b, plane, L.n, tmp, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(dst, tmp, sizeof(float) * L.n, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) return fail_hip("download_plane", e);
+  return DVO_AMD_OK;
+}
+
+int dvo_amd_pyramid_select(dvo_amd_pyramid *p, int level, float ti, float td, int *count, unsigned char *mask) {
+  if (!p || level < 0 || level >= p->n_levels) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  int idx = 0;
+  int rc = pyramid_selection(p, ti, td, &idx);
+  if (rc) return rc;
+  Selection s;
+  {
+    std::lock_guard<std::mutex> lk(p->mu);
+    s = p->selections[idx];
+  }
+  if (count) *count = s.count[level];
+  if (mask) {
+    HIP_TRY(hipSetDevice(p->device));
+    hipStream_t st;
+    rc = device_prep_stream(p->device, &st);
+    if (rc) return rc;
+    const LevelData &L = p->lv[level];
+    unsigned char *tmp = nullptr;
+    HIP_TRY(hipMalloc((void **)&tmp, L.n));
+    const int dropped = (s.count[level] & 1) ? s.last[level] : -1;
+    hipError_t e = launch_mask_from_zsel(s.zsel[level], L.n, dropped, tmp, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(mask, tmp, L.n, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail_hip("select mask", e);
+  }
+  return DVO_AMD_OK;
+}
+
+int dvo_amd_match_batch(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *references, dvo_amd_pyramid *const *currents,
+                        const double *T_inits, dvo_amd_result *results) {
+  if (!ctx || n < 0 || (n > 0 && (!references || !currents || !results))) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  if (n == 0) return DVO_AMD_OK;
+  const dvo_amd_config &cfg = ctx->cfg;
+  int rc = check_config(&cfg);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int need_levels = cfg.first_level + 1;  // Config::getNumLevels
+  int n_pad = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!references[i] || !currents[i]) return DVO_AMD_ERR_INVALID_ARGUMENT;
+    if (references[i]->device != ctx->device || currents[i]->device != ctx->device) return DVO_AMD_ERR_DEVICE_MISMATCH;
+    if (references[i]->n_levels < need_levels || currents[i]->n_levels < need_levels) return DVO_AMD_ERR_TOO_FEW_LEVELS;
+    for (int l = cfg.last_level; l <= cfg.first_level; ++l)
+      if (references[i]->lv[l].w != currents[i]->lv[l].w || references[i]->lv[l].h != currents[i]->lv[l].h)
+        return DVO_AMD_ERR_INVALID_ARGUMENT;
+    n_pad = std::max(n_pad, references[i]->lv[cfg.last_level].n_pad);
+    const int its_needed = (cfg.first_level - cfg.last_level + 1) * (cfg.max_iterations_per_level + 1);
+    if (results[i].iterations && results[i].iterations_capacity > 0 && results[i].iterations_capacity < its_needed)
+      return DVO_AMD_ERR_CAPACITY;
+  }
+  rc = ensure_slots(ctx, n, n_pad);
+  if (rc) return rc;
+
+  std::vector<Job> jobs((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    Job &j = jobs[(size_t)i];
+    j.ref = references[i], j.cur = currents[i];
+    j.result = &results[i];
+    j.slot = &ctx->slots[(size_t)i];
+    j.cfg = &ctx->cfg;
+    rc = pyramid_selection(j.ref, cfg.intensity_derivative_threshold, cfg.depth_derivative_threshold, &j.sel);
+    if (rc) return rc;
+    dvo_amd_result *r = j.result;
+    r->n_levels = 0, r->n_iterations = 0, r->n_ticks = 0, r->n_residual_passes = 0, r->alg_bytes = 0.0, r->is_nan = 0;
+    if (!r->iterations) r->iterations_capacity = 0;
+    // dense_tracking.cpp:137-150
+    if (cfg.use_initial_estimate) {
+      if (!T_inits) return DVO_AMD_ERR_INVALID_ARGUMENT;
+      const double *T0 = T_inits + 16 * (size_t)i;
+      double s = 0.0;
+      for (int k = 0; k < 16; ++k) s += T0[k];
+      if (!std::isfinite(s)) return DVO_AMD_ERR_NAN_INIT;
+      j.inc = se3_from_matrix(T0);
+    } else {
+      j.inc = SE3::identity();
+    }
+    j.initial = j.inc;
+    j.estimate = SE3::identity();
+    j.level = cfg.first_level;
+    start_level(j);
+  }
+  for (;;) {
+    bool any = false;
+    for (const Job &j : jobs) any = any || !j.done;
+    if (!any) break;
+    rc = run_tick(ctx, jobs);
+    if (rc) return rc;
+  }
+  return DVO_AMD_OK;
+}
+
+int dvo_amd_match(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, const double *T_init,
+                  dvo_amd_result *result) {
+  dvo_amd_pyramid *r[1] = {reference}, *c[1] = {current};
+  return dvo_amd_match_batch(ctx, 1, r, c, T_init, result);
+}
+
+int dvo_amd_residuals(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, int level, const float *T,
+                      float *residuals, int *n_valid) {
+  if (!ctx || !reference || !current || !T || level < 0) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  if (level >= reference->n_levels || level >= current->n_levels) return DVO_AMD_ERR_TOO_FEW_LEVELS;
+  if (reference->device != ctx->device || current->device != ctx->device) return DVO_AMD_ERR_DEVICE_MISMATCH;
+  const LevelData &R = reference->lv[level];
+  const LevelData &C = current->lv[level];
+  if (R.w != C.w || R.h != C.h) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(ctx->device));
+  int sel = 0;
+  int rc = pyramid_selection(reference, ctx->cfg.intensity_derivative_threshold, ctx->cfg.depth_derivative_threshold, &sel);
+  if (rc) return rc;
+  rc = ensure_slots(ctx, 1, R.n_pad);
+  if (rc) return rc;
+  JobSlot &s = ctx->slots[0];
+  TickArgs ta;
+  std::memset(&ta, 0, sizeof(ta));
+  ta.n_items = 1;
+  WorkItem &w = ta.items[0];
+  w.type = kWorkResidual;
+  fill_level_fields(w, reference, sel, current, level);
+  w.rounds = 1;
+  w.n_blocks = blocks_for(R.n, 1);
+  w.unit_weights = 1;
+  w.res = s.res[0];
+  w.records = s.records;
+  const float K[9] = {C.fx, 0.0f, C.ox, 0.0f, C.fy, C.oy, 0.0f, 0.0f, 1.0f};
+  for (int i = 0; i < 3; ++i)
+    for (int c = 0; c < 4; ++c)
+      w.kt[i * 4 + c] = (K[i * 3 + 0] * T[c * 4 + 0] + K[i * 3 + 1] * T[c * 4 + 1]) + K[i * 3 + 2] * T[c * 4 + 2];
+  hipError_t e = launch_tick(ta, w.n_blocks, ctx->stream);
+  if (e != hipSuccess) return fail_hip("launch_tick", e);
+  FinArgs fa;
+  fa.n_items = 1;
+  fa.items[0].records = s.records;
+  fa.items[0].n_blocks = w.n_blocks;
+  fa.items[0].n_ll_blocks = 0;
+  fa.items[0].ll_partials = s.ll_partials;
+  fa.items[0].cut_out = s.cut[0];
+  fa.items[0].out = s.out;
+  e = launch_finalize(fa, ctx->stream);
+  if (e != hipSuccess) return fail_hip("launch_finalize", e);
+  if (residuals)
+    HIP_TRY(hipMemcpyAsync(residuals, s.res[0], sizeof(float2) * R.n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (n_valid) *n_valid = ctx->out_host[0].valid;
+  return DVO_AMD_OK;
+}
+
+int dvo_amd_error_image(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, const double *T,
+                        int level, float *image) {
+  if (!ctx || !reference || !current || !T || !image || level < 0) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  if (level >= reference->n_levels) return DVO_AMD_ERR_TOO_FEW_LEVELS;
+  const int n = reference->lv[level].n;
+  std::vector<float> res((size_t)n * 2);
+  float Tf[16];
+  for (int i = 0; i < 16; ++i) Tf[i] = (float)T[i];  // transformation.cast<float>(), dense_tracking.cpp:413
+  int rc = dvo_amd_residuals(ctx, reference, current, level, Tf, res.data(), nullptr);
+  if (rc) return rc;
+  for (int i = 0; i < n; ++i) {
+    const float r0 = res[(size_t)2 * i];
+    image[i] = (r0 == r0) ? std::fabs(r0) : 0.0f;  // :426-438
+  }
+  return DVO_AMD_OK;
+}
+
+int dvo_amd_kernel_timing(dvo_amd_context *ctx, int enable, double *ms_residual_pass, long long *n_launches, int reset) {
+  if (!ctx) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  if (ms_residual_pass) *ms_residual_pass = ctx->timing_ms;
+  if (n_launches) *n_launches = ctx->timing_launches;
+  if (reset) ctx->timing_ms = 0.0, ctx->timing_launches = 0;
+  ctx->timing = enable != 0;
+  return DVO_AMD_OK;
+}
+
+}  // extern "C"

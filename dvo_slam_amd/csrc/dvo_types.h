@@ -1,0 +1,112 @@
+// Shared host/device declarations of the dense-tracking kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dvo_amd {
+
+// ---- geometry of one residual pass -------------------------------------------------------------------------------
+// A level's pixels are processed in row-major scan order (the order PointSelection::selectPointsFromImage walks them,
+// point_selection.cpp:128-149).  A wave owns one contiguous "segment" of kSegPxPerRound*rounds pixels, a 256-thread
+// block four consecutive segments; lane l of round r handles the 4 consecutive pixels seg_start + 256 r + 4 l ... +3.
+constexpr int kWave = 64;
+constexpr int kBlockThreads = 256;
+constexpr int kWavesPerBlock = kBlockThreads / kWave;
+constexpr int kPxPerLane = 4;
+constexpr int kSegPxPerRound = kWave * kPxPerLane;            // 256
+constexpr int kMaxRounds = 16;
+constexpr int kPlanePad = kSegPxPerRound * kMaxRounds * kWavesPerBlock;  // 16384: planes are padded to a multiple of this
+
+// ---- per-block record written by the residual pass ----------------------------------------------------------------
+// [0] count (int bits)  [1] first_w  [2] last_r0  [3] last_r1
+// [4..6] S under start parity 0 (xx, xy, yy)   [7..9] S under start parity 1
+// [10..13] per-wave valid counts (int bits)    [14..15] unused
+// [16..102] the 87 plain sums (see kAcc* below)
+constexpr int kRecCount = 0, kRecFirstW = 1, kRecLastR = 2, kRecS0 = 4, kRecS1 = 7, kRecWaveCnt = 10, kRecAcc = 16;
+constexpr int kNumAcc = 87;
+constexpr int kRecStride = 104;
+// layout of the 87 sums: for the 21 pairs (i<=j) in row-major upper-triangular order:
+//   [0..20]  sum w Ja_i Ja_j      [21..41] sum w (Ja_i Jb_j + Jb_i Ja_j)      [42..62] sum w Jb_i Jb_j
+//   [63..68] sum w Ja_i r0   [69..74] sum w Ja_i r1   [75..80] sum w Jb_i r0   [81..86] sum w Jb_i r1
+constexpr int kAccAA = 0, kAccAB = 21, kAccBB = 42, kAccAR0 = 63, kAccAR1 = 69, kAccBR0 = 75, kAccBR1 = 81;
+
+enum WorkType : int { kWorkResidual = 0, kWorkLogLik = 1 };
+
+// One unit of device work of a tick, passed by value in the kernel arguments (no H2D copy per iteration).
+struct WorkItem {
+  int type;          // WorkType
+  int n_blocks;      // blocks this item uses (grid.x may be larger)
+  int rounds;        // rounds per wave
+  int w, h;          // level size
+  int unit_weights;  // first iteration on a level: weights = 1 (dense_tracking.cpp:286-289)
+  int pad0, pad1;
+  // reference level (planar, padded to kPlanePad, zsel = NaN where the pixel is not selected)
+  const float *r_zsel, *r_i, *r_ix, *r_iy;
+  const float *tx, *ty;  // ((float)x - ox)/fx, ((float)y - oy)/fy
+  // current level, gather layout
+  const float4 *c_a;  // {I, Z, Ix, Iy} per pixel
+  const float2 *c_b;  // {Zx, Zy} per pixel
+  float2 *res;        // residual buffer of this iteration (written by kWorkResidual, read by kWorkLogLik), NaN = invalid
+  float *records;     // kWorkResidual: n_blocks x kRecStride floats;  kWorkLogLik: n_blocks doubles
+  const int *cut;     // kWorkLogLik: {cut_seg, cut_local} written by the finalize kernel of that iteration
+  float kt[12];       // K * T[0:3,0:4], row-major, float (dense_tracking_impl.cpp:142-152)
+  float P[4];         // precision, column-major: previous iteration's for kWorkResidual, this iteration's for kWorkLogLik
+  float wc[6];        // wcur: {1/255, 1, .5fx/255, .5fy/255, fx, fy}  (dense_tracking.cpp:219)
+  float wr[4];        // wref: {-1/255, -1, .5fx/255, .5fy/255}        (dense_tracking.cpp:220)
+  float ub_x, ub_y;   // (float)(w-2), (float)(h-2)
+};
+
+constexpr int kMaxItemsPerLaunch = 14;
+struct TickArgs {
+  int n_items;
+  int pad;
+  WorkItem items[kMaxItemsPerLaunch];
+};
+static_assert(sizeof(TickArgs) <= 3800, "kernel argument block too large");
+
+// what the finalize kernel hands to the host for one job (lives in pinned host memory)
+struct FinOut {
+  int valid;       // V: number of valid constraints of the residual pass
+  int has_res;     // a residual pass was reduced
+  int has_ll;
+  int pad;
+  double S[3];     // sum over pairs (w_2j + w_2j+1) r_2j r_2j^T  (xx, xy, yy), unscaled (Q5 pairing)
+  double acc[kNumAcc];
+  double ll_sum;   // sum of log(1 + 0.2 r^T P r) over the first 50*floor(V/50) valid residuals (Q6)
+};
+
+struct FinItem {
+  const float *records;   // residual-pass block records (or null)
+  int n_blocks;
+  int n_ll_blocks;
+  const double *ll_partials;
+  int *cut_out;           // {cut_seg, cut_local} for the residual pass just reduced
+  FinOut *out;
+};
+constexpr int kMaxFinItems = 64;
+struct FinArgs {
+  int n_items;
+  int pad;
+  FinItem items[kMaxFinItems];
+};
+static_assert(sizeof(FinArgs) <= 3800, "kernel argument block too large");
+
+// ---- launch wrappers (dvo_kernels.hip) ----------------------------------------------------------------------------
+hipError_t launch_tick(const TickArgs &args, int max_blocks, hipStream_t stream);
+hipError_t launch_finalize(const FinArgs &args, hipStream_t stream);
+
+// prep (pyramid construction) kernels
+hipError_t launch_pyr_down(const float *i_prev, const float *z_prev, int w_prev, float *i_out, float *z_out, int w, int h,
+                           hipStream_t stream);
+hipError_t launch_level_planes(const float *i_plane, const float *z_plane, int w, int h, int n_pad, float fx, float fy,
+                               float ox, float oy, float4 *c_a, float2 *c_b, float *r_i, float *r_ix, float *r_iy,
+                               float *tx, float *ty, int ty_len, hipStream_t stream);
+// selection: writes zsel (n_pad floats), counters[0] = count, counters[1] = index of last selected pixel (or -1);
+// then un-selects the last selected pixel if count is odd (Q3).
+hipError_t launch_select(const float *z_plane, const float4 *c_a, const float2 *c_b, int n, int n_pad, float ti, float td,
+                         float *zsel, int *counters, hipStream_t stream);
+hipError_t launch_copy_strided(const float *src, int stride, float *dst, int w, int h, hipStream_t stream);
+hipError_t launch_mask_from_zsel(const float *zsel, int n, int last_dropped, unsigned char *mask, hipStream_t stream);
+hipError_t launch_unpack_plane(const float4 *c_a, const float2 *c_b, int plane, int n, float *dst, hipStream_t stream);
+
+}  // namespace dvo_amd

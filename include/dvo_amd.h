@@ -1,0 +1,179 @@
+/*
+ * dvo_amd.h -- C ABI of the MI355X-native dense RGB-D tracking core.
+ *
+ * Drop-in boundary for ONE path of jesusbriales/dvo_slam: dvo::DenseTracker::match() over
+ * dvo::core::RgbdImagePyramid (dvo_core/include/dvo/dense_tracking.h:39-213,
+ * dvo_core/include/dvo/core/rgbd_image.h:127-262).  The reference has no FFI layer (its seam is a
+ * C++ class using Eigen / cv::Mat / boost::shared_ptr types), so this header declares the POD
+ * interface a binding would use; include/dvo_amd/dense_tracking.hpp re-declares the reference's
+ * class / field names on top of it.  Plain pointers and sizes only; no exceptions cross the ABI;
+ * every entry point returns a dvo_amd_status.
+ *
+ * Conventions (same as the reference):
+ *  - intensity: float32, 0..255 (benchmark_slam.cpp:60-68); depth: float32 metres, NaN = invalid
+ *    (surface_pyramid.cpp:65-105); both row-major, same size; width of every used pyramid level must
+ *    be a multiple of 4 (the reference's SSE derivative needs this too: rgbd_image_sse.cpp:258).
+ *  - 4x4 transforms are column-major double[16] (Eigen::Affine3d::matrix().data()).
+ *  - 6x6 matrices are column-major double[36] (symmetric anyway).
+ *  - Result transformation maps current-frame points into the reference frame
+ *    (dense_tracking.cpp:371: estimate^-1).
+ */
+#ifndef DVO_AMD_H_
+#define DVO_AMD_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVO_AMD_MAX_LEVELS 8
+#define DVO_AMD_ABI_VERSION 1
+
+typedef enum {
+  DVO_AMD_OK = 0,
+  DVO_AMD_ERR_INVALID_ARGUMENT = 1,
+  DVO_AMD_ERR_NO_DEVICE = 2,        /* HIP runtime / GPU not usable: the library never falls back to a CPU path */
+  DVO_AMD_ERR_HIP = 3,              /* a HIP call failed; see dvo_amd_last_error() */
+  DVO_AMD_ERR_OUT_OF_MEMORY = 4,
+  DVO_AMD_ERR_INSANE_CONFIG = 5,    /* Config::IsSane() false (dense_tracking_config.cpp:55-58) */
+  DVO_AMD_ERR_TOO_FEW_LEVELS = 6,   /* pyramid holds fewer levels than FirstLevel + 1 */
+  DVO_AMD_ERR_CAPACITY = 7,         /* caller-provided iteration array too small */
+  DVO_AMD_ERR_DEVICE_MISMATCH = 8,
+  DVO_AMD_ERR_NAN_INIT = 9,         /* UseInitialEstimate with a NaN transform (dense_tracking.cpp:139 assert) */
+  DVO_AMD_ERR_COMM = 10
+} dvo_amd_status;
+
+/* DenseTracker::TerminationCriteria::Enum, dense_tracking.h:71-81 */
+typedef enum {
+  DVO_AMD_TERM_ITERATIONS_EXCEEDED = 0,
+  DVO_AMD_TERM_INCREMENT_TOO_SMALL = 1,
+  DVO_AMD_TERM_LOGLIKELIHOOD_DECREASED = 2,
+  DVO_AMD_TERM_TOO_FEW_CONSTRAINTS = 3,
+  DVO_AMD_TERM_UNSET = -1
+} dvo_amd_termination;
+
+/* The live fields of DenseTracker::Config (dense_tracking.h:42-69); defaults dense_tracking_config.cpp:27-41.
+ * UseWeighting / UseParallel / InfluenceFunction* / ScaleEstimator* are never read by match() and are not mirrored. */
+typedef struct {
+  int first_level;                /* FirstLevel, default 3 */
+  int last_level;                 /* LastLevel, default 1 */
+  int max_iterations_per_level;   /* MaxIterationsPerLevel, default 100 */
+  double precision;               /* Precision, default 5e-7 */
+  double mu;                      /* Mu, default 0 */
+  int use_initial_estimate;       /* UseInitialEstimate, default 0 */
+  float intensity_derivative_threshold; /* IntensityDerivativeThreshold, default 0 */
+  float depth_derivative_threshold;     /* DepthDerivativeThreshold, default 0 */
+} dvo_amd_config;
+
+/* DenseTracker::IterationStats, dense_tracking.h:83-100 */
+typedef struct {
+  int id;
+  int valid_constraints;
+  double tdist_loglik;
+  double tdist_mean[2];
+  double tdist_precision[4];  /* column-major 2x2 */
+  double prior_loglik;
+  double increment[6];        /* EstimateIncrement (upsilon, omega); valid if has_increment */
+  double information[36];     /* EstimateInformation; valid if has_increment */
+  int has_increment;          /* 0 for the iteration a level broke out of (TooFewConstraints / LogLikelihoodDecreased) */
+  int reserved;
+} dvo_amd_iteration_stats;
+
+/* DenseTracker::LevelStats, dense_tracking.h:103-116 */
+typedef struct {
+  int id;
+  int max_valid_pixels;
+  int valid_pixels;
+  int termination;      /* dvo_amd_termination */
+  int n_iterations;
+  int first_iteration;  /* index of the level's first entry in dvo_amd_result.iterations */
+} dvo_amd_level_stats;
+
+/* DenseTracker::Result, dense_tracking.h:125-140 */
+typedef struct {
+  double transformation[16];
+  double information[36];
+  double loglik;
+  int is_nan;                               /* Result::isNaN(), dense_tracking_config.cpp:96 */
+  int n_levels;
+  dvo_amd_level_stats levels[DVO_AMD_MAX_LEVELS];
+  int n_iterations;                         /* entries written */
+  int iterations_capacity;                  /* in: size of iterations[] (0 / NULL: per-iteration stats are dropped) */
+  dvo_amd_iteration_stats *iterations;      /* caller-provided */
+  /* instrumentation (not in the reference) */
+  int n_ticks;                              /* host<->device round trips spent */
+  int n_residual_passes;                    /* fused warp+residual+normal-equation launches (incl. discarded speculative ones) */
+  double alg_bytes;                         /* 56 B x selected points x residual passes */
+} dvo_amd_result;
+
+typedef struct dvo_amd_context dvo_amd_context; /* one DenseTracker instance: one HIP stream + scratch; NOT thread-safe */
+typedef struct dvo_amd_pyramid dvo_amd_pyramid; /* one RgbdImagePyramid: refcounted, immutable after create, shareable */
+
+int dvo_amd_abi_version(void);
+const char *dvo_amd_status_string(int status);
+/* text of the most recent HIP failure on the calling thread ("" if none) */
+const char *dvo_amd_last_error(void);
+int dvo_amd_device_count(void);
+
+/* DenseTracker::Config::Config(), dense_tracking_config.cpp:27-41 */
+void dvo_amd_default_config(dvo_amd_config *cfg);
+
+/* DenseTracker::DenseTracker(cfg) / configure(), dense_tracking.cpp:54-97 */
+int dvo_amd_context_create(int device, const dvo_amd_config *cfg, dvo_amd_context **out);
+void dvo_amd_context_destroy(dvo_amd_context *ctx);
+int dvo_amd_configure(dvo_amd_context *ctx, const dvo_amd_config *cfg);
+int dvo_amd_get_config(const dvo_amd_context *ctx, dvo_amd_config *cfg);
+
+/*
+ * RgbdCameraPyramid(w,h,K).create(intensity, depth) + RgbdImagePyramid::build(levels) + everything match() would build
+ * lazily (derivatives, point-cloud rays, gather layout): rgbd_image.cpp:141-172,245-296,419-489,534-543.
+ * stride is in floats (>= width).  The host overload copies the two base planes H2D; the device overload reads planes that
+ * are already resident in HBM on `device` (no PCIe traffic).  All work is enqueued on an internal stream and complete on return.
+ */
+int dvo_amd_pyramid_create(int device, const float *intensity, const float *depth, int width, int height, int stride,
+                           float fx, float fy, float ox, float oy, int levels, double timestamp, dvo_amd_pyramid **out);
+int dvo_amd_pyramid_create_from_device(int device, const float *d_intensity, const float *d_depth, int width, int height,
+                                       int stride, float fx, float fy, float ox, float oy, int levels, double timestamp,
+                                       dvo_amd_pyramid **out);
+void dvo_amd_pyramid_retain(dvo_amd_pyramid *p);
+void dvo_amd_pyramid_release(dvo_amd_pyramid *p);
+int dvo_amd_pyramid_levels(const dvo_amd_pyramid *p);
+double dvo_amd_pyramid_timestamp(const dvo_amd_pyramid *p);
+/* RgbdImagePyramid::level(l): size and intrinsics {fx,fy,ox,oy} of a level */
+int dvo_amd_pyramid_level_info(const dvo_amd_pyramid *p, int level, int *width, int *height, float k[4]);
+/* download one plane of a level: 0 I, 1 Z, 2 Ix, 3 Iy, 4 Zx, 5 Zy (RgbdImage::intensity, depth, *_dx, *_dy) */
+int dvo_amd_pyramid_download_plane(const dvo_amd_pyramid *p, int level, int plane, float *dst);
+/* PointSelection::select(level) (point_selection.cpp:89-117): number of selected pixels for the thresholds, and optionally
+ * the per-pixel mask (1 = selected, row-major) */
+int dvo_amd_pyramid_select(dvo_amd_pyramid *p, int level, float intensity_threshold, float depth_threshold, int *count,
+                           unsigned char *mask);
+
+/* DenseTracker::match(RgbdImagePyramid& reference, RgbdImagePyramid& current, Result&), dense_tracking.cpp:123-376.
+ * T_init (may be NULL) is read only if use_initial_estimate (dense_tracking.cpp:137-144). */
+int dvo_amd_match(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, const double *T_init,
+                  dvo_amd_result *result);
+
+/* n independent match() calls advanced in lock step on one GPU (the shape of LocalTracker::update's tbb::parallel_invoke,
+ * local_tracker.cpp:184, and of the loop-closure validator's parallel_reduce, keyframe_graph.cpp:576-593).
+ * T_inits: n x 16 doubles or NULL.  Results are identical to n dvo_amd_match() calls. */
+int dvo_amd_match_batch(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *references, dvo_amd_pyramid *const *currents,
+                        const double *T_inits, dvo_amd_result *results);
+
+/* dvo::core::computeResidualsAndValidFlagsSse (dense_tracking_impl.cpp:400-403) for one level and one float transform
+ * (column-major 4x4, reference -> current).  residuals: width*height x 2 floats in pixel order, NaN where the pixel is not
+ * selected or its warp is invalid.  Used by the parity tests and by dvo_amd_error_image. */
+int dvo_amd_residuals(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, int level,
+                      const float *T, float *residuals, int *n_valid);
+/* DenseTracker::computeIntensityErrorImage, dense_tracking.cpp:378-444: |intensity residual| per reference pixel, 0 elsewhere */
+int dvo_amd_error_image(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, const double *T,
+                        int level, float *image);
+
+/* timing helper for bench.py: HIP-event milliseconds the context's stream spent in its residual-pass kernel since the last
+ * reset, and the number of launches */
+int dvo_amd_kernel_timing(dvo_amd_context *ctx, int enable, double *ms_residual_pass, long long *n_launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
