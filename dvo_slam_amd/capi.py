@@ -25,7 +25,8 @@ EXPORTS = [
     "dvo_amd_get_config", "dvo_amd_pyramid_create", "dvo_amd_pyramid_create_from_device", "dvo_amd_pyramid_retain",
     "dvo_amd_pyramid_release", "dvo_amd_pyramid_levels", "dvo_amd_pyramid_timestamp", "dvo_amd_pyramid_level_info",
     "dvo_amd_pyramid_download_plane", "dvo_amd_pyramid_select", "dvo_amd_match", "dvo_amd_match_batch",
-    "dvo_amd_residuals", "dvo_amd_error_image", "dvo_amd_kernel_timing",
+    "dvo_amd_residuals", "dvo_amd_error_image", "dvo_amd_kernel_timing", "dvo_amd_se3_exp", "dvo_amd_se3_log",
+    "dvo_amd_solve6",
 ]
 
 
@@ -72,6 +73,14 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch wheels bundle their own ROCm runtime (libamdhip64 / libhsa-runtime64).  Two HIP runtimes in one process do not
+    # share devices ("No HIP GPUs are available" in whichever initialises second), so when torch is installed let it load
+    # its copy first: this library's DT_NEEDED libamdhip64.so.N then binds to that same copy.
+    if os.environ.get("DVO_AMD_PRELOAD_TORCH", "1") != "0":
+        try:
+            import torch  # noqa: F401
+        except Exception:  # torch absent or broken: the system runtime under /opt/rocm is used
+            pass
     path = _build.LIB_PATH
     if _build.needs_build():
         path = _build.build()
@@ -111,6 +120,12 @@ def lib():
     L.dvo_amd_residuals.argtypes = [vp, vp, vp, C.c_int, fp, fp, C.POINTER(C.c_int)]
     L.dvo_amd_error_image.argtypes = [vp, vp, vp, dp, C.c_int, fp]
     L.dvo_amd_kernel_timing.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_longlong), C.c_int]
+    L.dvo_amd_se3_exp.argtypes = [dp, dp]
+    L.dvo_amd_se3_exp.restype = None
+    L.dvo_amd_se3_log.argtypes = [dp, dp]
+    L.dvo_amd_se3_log.restype = None
+    L.dvo_amd_solve6.argtypes = [dp, dp, dp]
+    L.dvo_amd_solve6.restype = None
     _lib = L
     return L
 
@@ -337,3 +352,26 @@ class DenseTracker:
         n = C.c_longlong()
         _check(lib().dvo_amd_kernel_timing(self._h, int(enable), C.byref(ms), C.byref(n), int(reset)), "kernel_timing")
         return ms.value, n.value
+
+
+def se3_exp(xi) -> np.ndarray:
+    xi = np.ascontiguousarray(xi, dtype=np.float64)
+    T = np.zeros(16)
+    lib().dvo_amd_se3_exp(xi.ctypes.data_as(C.POINTER(C.c_double)), T.ctypes.data_as(C.POINTER(C.c_double)))
+    return T.reshape(4, 4).T.copy()
+
+
+def se3_log(T) -> np.ndarray:
+    Tc = np.ascontiguousarray(np.asarray(T, dtype=np.float64).T)
+    xi = np.zeros(6)
+    lib().dvo_amd_se3_log(Tc.ctypes.data_as(C.POINTER(C.c_double)), xi.ctypes.data_as(C.POINTER(C.c_double)))
+    return xi
+
+
+def solve6(A, b) -> np.ndarray:
+    Ac = np.ascontiguousarray(np.asarray(A, dtype=np.float64).T)
+    bc = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.zeros(6)
+    dp = C.POINTER(C.c_double)
+    lib().dvo_amd_solve6(Ac.ctypes.data_as(dp), bc.ctypes.data_as(dp), x.ctypes.data_as(dp))
+    return x

@@ -112,7 +112,7 @@ struct PixelOut {  // live across the RTZ -> RN switch
 };
 
 // computeResidualsSse for one reference pixel, dense_tracking_impl.cpp:171-294.  Runs in round-toward-zero.
-__device__ __forceinline__ void warp_pixel_rtz(const WorkItem &it, float x, float y, float z, float ri, float rix, float riy,
+__device__ __forceinline__ void warp_pixel_rtz(const TickItem &it, const LevelPairDesc &d, float x, float y, float z, float ri, float rix, float riy,
                                                float &r0, float &r1, float &e2, float &e3, float &e4, float &e5,
                                                bool &valid) {
   const float *kt = it.kt;
@@ -125,15 +125,15 @@ __device__ __forceinline__ void warp_pixel_rtz(const WorkItem &it, float x, floa
   valid = false;
   r0 = r1 = e2 = e3 = e4 = e5 = 0.0f;
   // 0 <= u <= w-2 and 0 <= v <= h-2 (:160-161,203); NaN compares false
-  if ((u >= 0.0f) && (u <= it.ub_x) && (v >= 0.0f) && (v <= it.ub_y)) {
+  if ((u >= 0.0f) && (u <= d.ub_x) && (v >= 0.0f) && (v <= d.ub_y)) {
     const int iu = (int)u, iv = (int)v;  // truncation == _mm_cvtps_epi32 under RTZ (:195)
     const float w1u = u - (float)iu, w1v = v - (float)iv;
     const float w0u = 1.0f - w1u, w0v = 1.0f - w1v;
-    const int base = iv * it.w + iu;
-    const float4 a00 = it.c_a[base], a10 = it.c_a[base + 1];
-    const float4 a01 = it.c_a[base + it.w], a11 = it.c_a[base + it.w + 1];
-    const f4_align8 b0 = *reinterpret_cast<const f4_align8 *>(it.c_b + base);
-    const f4_align8 b1 = *reinterpret_cast<const f4_align8 *>(it.c_b + base + it.w);
+    const int base = iv * d.w + iu;
+    const float4 a00 = d.c_a[base], a10 = d.c_a[base + 1];
+    const float4 a01 = d.c_a[base + d.w], a11 = d.c_a[base + d.w + 1];
+    const f4_align8 b0 = *reinterpret_cast<const f4_align8 *>(d.c_b + base);
+    const f4_align8 b1 = *reinterpret_cast<const f4_align8 *>(d.c_b + base + d.w);
     // bilinear blend, per channel: w0v*(w0u*c00 + w1u*c10) + w1v*(w0u*c01 + w1u*c11)  (:227-258)
 #define DVO_BLEND(c00, c10, c01, c11) ((w0v * (w0u * (c00) + w1u * (c10))) + (w1v * (w0u * (c01) + w1u * (c11))))
     const float ci = DVO_BLEND(a00.x, a10.x, a01.x, a11.x);
@@ -147,18 +147,18 @@ __device__ __forceinline__ void warp_pixel_rtz(const WorkItem &it, float x, floa
     const bool has_nan = (ci != ci) || (cz != cz) || (cix != cix) || (ciy != ciy) || (czx != czx) || (czy != czy);
     if (!has_nan) {
       // e = wcur * cur + wref * ref', ref' = {I, transformed depth, Ix, Iy} (:269-271)
-      const float t0 = it.wc[0] * ci + it.wr[0] * ri;
-      const float t1 = it.wc[1] * cz + it.wr[1] * sz;
+      const float t0 = d.wc[0] * ci + d.wr[0] * ri;
+      const float t1 = d.wc[1] * cz + d.wr[1] * sz;
       // occlusion test (:275) with depthStdDevZ (:122-128) of the reference depth
       float s = z - 0.4f;
       s = 0.0012f + (0.0019f * s) * s;
       if (t1 > -20.0f * s) {
         r0 = t0;
         r1 = t1;
-        e2 = it.wc[2] * cix + it.wr[2] * rix;
-        e3 = it.wc[3] * ciy + it.wr[3] * riy;
-        e4 = it.wc[4] * czx;  // wref is 0 for the depth derivatives (dense_tracking.cpp:217-220)
-        e5 = it.wc[5] * czy;
+        e2 = d.wc[2] * cix + d.wr[2] * rix;
+        e3 = d.wc[3] * ciy + d.wr[3] * riy;
+        e4 = d.wc[4] * czx;  // wref is 0 for the depth derivatives (dense_tracking.cpp:217-220)
+        e5 = d.wc[5] * czy;
         valid = true;
       }
     }
@@ -166,12 +166,12 @@ __device__ __forceinline__ void warp_pixel_rtz(const WorkItem &it, float x, floa
 }
 
 template <int RMODE>
-__device__ void residual_pass(const WorkItem &it, const int lb) {
+__device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const int lb) {
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
   const int seg = lb * kWavesPerBlock + wave;
-  const int w = it.w;
-  int idx = seg * (kSegPxPerRound * it.rounds) + lane * kPxPerLane;
+  const int w = d.w;
+  int idx = seg * (kSegPxPerRound * it.res_rounds) + lane * kPxPerLane;
   int prow = idx / w;
   int pcol = idx - prow * w;
 
@@ -186,16 +186,16 @@ __device__ void residual_pass(const WorkItem &it, const int lb) {
 
   const unsigned long long below = (1ull << lane) - 1ull;
   const bool unit_w = it.unit_weights != 0;
-  const float P0 = it.P[0], P1 = it.P[1], P2 = it.P[2], P3 = it.P[3];
+  const float P0 = it.P_res[0], P1 = it.P_res[1], P2 = it.P_res[2], P3 = it.P_res[3];
 
-  for (int round = 0; round < it.rounds; ++round) {
+  for (int round = 0; round < it.res_rounds; ++round) {
     // ---- round-to-nearest: reference point = pixel ray * depth (RgbdCamera::buildPointCloud, rgbd_image.cpp:245-262)
-    const float4 zs = *reinterpret_cast<const float4 *>(it.r_zsel + idx);
-    const float4 rI = *reinterpret_cast<const float4 *>(it.r_i + idx);
-    const float4 rIx = *reinterpret_cast<const float4 *>(it.r_ix + idx);
-    const float4 rIy = *reinterpret_cast<const float4 *>(it.r_iy + idx);
-    const float4 txv = *reinterpret_cast<const float4 *>(it.tx + pcol);
-    const float tyv = it.ty[prow < it.h ? prow : it.h - 1];
+    const float4 zs = *reinterpret_cast<const float4 *>(d.r_zsel + idx);
+    const float4 rI = *reinterpret_cast<const float4 *>(d.r_i + idx);
+    const float4 rIx = *reinterpret_cast<const float4 *>(d.r_ix + idx);
+    const float4 rIy = *reinterpret_cast<const float4 *>(d.r_iy + idx);
+    const float4 txv = *reinterpret_cast<const float4 *>(d.tx + pcol);
+    const float tyv = d.ty[prow < d.h ? prow : d.h - 1];
     PixelIn pin;
     pin.z[0] = zs.x, pin.z[1] = zs.y, pin.z[2] = zs.z, pin.z[3] = zs.w;
     pin.x[0] = txv.x * zs.x, pin.x[1] = txv.y * zs.y, pin.x[2] = txv.z * zs.z, pin.x[3] = txv.w * zs.w;
@@ -219,7 +219,7 @@ __device__ void residual_pass(const WorkItem &it, const int lb) {
     PixelOut po;
 #pragma unroll
     for (int k = 0; k < kPxPerLane; ++k)
-      warp_pixel_rtz(it, pin.x[k], pin.y[k], pin.z[k], pin.ri[k], pin.rix[k], pin.riy[k], po.r0[k], po.r1[k], po.e2[k],
+      warp_pixel_rtz(it, d, pin.x[k], pin.y[k], pin.z[k], pin.ri[k], pin.rix[k], pin.riy[k], po.r0[k], po.r1[k], po.e2[k],
                      po.e3[k], po.e4[k], po.e5[k], po.valid[k]);
     // ---- back to round-to-nearest
 #pragma unroll
@@ -244,7 +244,7 @@ __device__ void residual_pass(const WorkItem &it, const int lb) {
       s0.z = po.valid[1] ? po.r0[1] : qnan, s0.w = po.valid[1] ? po.r1[1] : qnan;
       s1.x = po.valid[2] ? po.r0[2] : qnan, s1.y = po.valid[2] ? po.r1[2] : qnan;
       s1.z = po.valid[3] ? po.r0[3] : qnan, s1.w = po.valid[3] ? po.r1[3] : qnan;
-      float4 *dst = reinterpret_cast<float4 *>(it.res + idx);
+      float4 *dst = reinterpret_cast<float4 *>(d.res[it.res_buf] + idx);
       dst[0] = s0;
       dst[1] = s1;
     }
@@ -282,8 +282,8 @@ __device__ void residual_pass(const WorkItem &it, const int lb) {
         if (!unit_w) {
           const float t0 = r0 * P0 + r1 * P1;
           const float t1 = r0 * P2 + r1 * P3;
-          const float d = t0 * r0 + t1 * r1;
-          wgt = 7.0f / (5.0f + d);
+          const float dd = t0 * r0 + t1 * r1;
+          wgt = 7.0f * __builtin_amdgcn_rcpf(5.0f + dd);
         }
         // computeScaleSse with Q5: a pair (2j, 2j+1) contributes (w_2j + w_2j+1) r_2j r_2j^T (:603-621).
         // S0 assumes this segment starts on an even global rank, S1 on an odd one.
@@ -301,8 +301,8 @@ __device__ void residual_pass(const WorkItem &it, const int lb) {
 
         // Jacobians at the untransformed reference point (dense_tracking.cpp:333-339,448-476)
         const float x = pin.x[k], y = pin.y[k], z = pin.z[k];
-        const float iz = 1.0f / z;
-        const float iz2 = 1.0f / (z * z);
+        const float iz = __builtin_amdgcn_rcpf(z);
+        const float iz2 = iz * iz;
         const float j02 = -x * iz2, j12 = -y * iz2;
         const float j03 = j02 * y, j13 = -1.0f + j12 * y;
         const float j04 = 1.0f - j02 * x, j14 = -j03;
@@ -381,7 +381,7 @@ __device__ void residual_pass(const WorkItem &it, const int lb) {
   }
   __syncthreads();
 
-  float *rec = it.records + (size_t)lb * kRecStride;
+  float *rec = d.records + (size_t)lb * kRecStride;
   const int tid = threadIdx.x;
   if (tid < kNumAcc) {
     rec[kRecAcc + tid] = (sm[0][kRecAcc + tid] + sm[1][kRecAcc + tid]) + (sm[2][kRecAcc + tid] + sm[3][kRecAcc + tid]);
@@ -427,20 +427,20 @@ __device__ void residual_pass(const WorkItem &it, const int lb) {
 // (computeCompleteDataLogLikelihood, dense_tracking_impl.cpp:406-425, incl. Q6).  Same segment geometry as the residual
 // pass that wrote the residuals; {cut_seg, cut_local} locate global rank 50*floor(V/50).
 // ------------------------------------------------------------------------------------------------------------------
-__device__ void loglik_pass(const WorkItem &it, const int lb) {
+__device__ void loglik_pass(const TickItem &it, const LevelPairDesc &d, const int lb) {
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
   const int seg = lb * kWavesPerBlock + wave;
-  const int cut_seg = it.cut[0], cut_local = it.cut[1];
-  const float P0 = it.P[0], P1 = it.P[1], P2 = it.P[2], P3 = it.P[3];
+  const int cut_seg = d.cut[it.ll_buf][0], cut_local = d.cut[it.ll_buf][1];
+  const float P0 = it.P_ll[0], P1 = it.P_ll[1], P2 = it.P_ll[2], P3 = it.P_ll[3];
   const unsigned long long below = (1ull << lane) - 1ull;
   double total = 0.0;
   if (seg <= cut_seg) {
     const bool partial = seg == cut_seg;
-    int idx = seg * (kSegPxPerRound * it.rounds) + lane * kPxPerLane;
+    int idx = seg * (kSegPxPerRound * it.ll_rounds) + lane * kPxPerLane;
     int run_count = 0;
-    for (int round = 0; round < it.rounds; ++round) {
-      const float4 *src = reinterpret_cast<const float4 *>(it.res + idx);
+    for (int round = 0; round < it.ll_rounds; ++round) {
+      const float4 *src = reinterpret_cast<const float4 *>(d.res[it.ll_buf] + idx);
       const float4 s0 = src[0], s1 = src[1];
       const float r0[kPxPerLane] = {s0.x, s0.z, s1.x, s1.z};
       const float r1[kPxPerLane] = {s0.y, s0.w, s1.y, s1.w};
@@ -476,18 +476,19 @@ __device__ void loglik_pass(const WorkItem &it, const int lb) {
   __shared__ double smd[kWavesPerBlock];
   if (lane == 0) smd[wave] = total;
   __syncthreads();
-  if (threadIdx.x == 0) reinterpret_cast<double *>(it.records)[lb] = (smd[0] + smd[1]) + (smd[2] + smd[3]);
+  if (threadIdx.x == 0) d.ll_partials[lb] = (smd[0] + smd[1]) + (smd[2] + smd[3]);
 }
 
 template <int RMODE>
 __global__ __launch_bounds__(kBlockThreads) void k_tick(const TickArgs args) {
-  const WorkItem &it = args.items[blockIdx.y];
-  if ((int)blockIdx.x >= it.n_blocks) return;
-  const int lb = xcd_contiguous_block((int)blockIdx.x, it.n_blocks);
-  if (it.type == kWorkResidual)
-    residual_pass<RMODE>(it, lb);
+  const TickItem &it = args.items[blockIdx.y];
+  const int bx = (int)blockIdx.x;
+  if (bx >= it.res_blocks + it.ll_blocks) return;
+  const LevelPairDesc &d = *it.desc;
+  if (bx < it.res_blocks)
+    residual_pass<RMODE>(it, d, xcd_contiguous_block(bx, it.res_blocks));
   else
-    loglik_pass(it, lb);
+    loglik_pass(it, d, bx - it.res_blocks);
 }
 
 static int g_reduce_mode = -1;
@@ -641,6 +642,10 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const FinArgs args) {
       out->has_ll = it.n_ll_blocks > 0 ? 1 : 0;
     }
   }
+  // publish: every thread's stores to the (host) record are ordered before the sequence word
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) __hip_atomic_store(&out->seq, it.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 hipError_t launch_finalize(const FinArgs &args, hipStream_t stream) {

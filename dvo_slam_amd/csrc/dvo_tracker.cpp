@@ -301,6 +301,11 @@ struct dvo_amd_context {
   int slot_n_pad = 0;  // capacity every slot was sized for
   FinOut *out_host = nullptr;
   int out_capacity = 0;
+  LevelPairDesc *desc_host = nullptr;  // pinned staging, [slot][level]
+  LevelPairDesc *desc_dev = nullptr;
+  int desc_capacity = 0;               // in slots
+  unsigned tick_seq = 0;
+  bool poll = true;                    // wait for a tick by polling the records' sequence words instead of hipStreamSynchronize
   // optional kernel timing (bench.py roofline section)
   bool timing = false;
   double timing_ms = 0.0;
@@ -467,22 +472,27 @@ void make_kt(const LevelData &C, const SE3 &estimate, float kt[12]) {
       kt[i * 4 + c] = (K[i * 3 + 0] * T[c * 4 + 0] + K[i * 3 + 1] * T[c * 4 + 1]) + K[i * 3 + 2] * T[c * 4 + 2];
 }
 
-void fill_level_fields(WorkItem &w, const dvo_amd_pyramid *ref, int sel, const dvo_amd_pyramid *cur, int level) {
+void fill_desc(LevelPairDesc &d, const dvo_amd_pyramid *ref, int sel, const dvo_amd_pyramid *cur, int level,
+               const JobSlot &slot) {
   const LevelData &R = ref->lv[level];
   const LevelData &C = cur->lv[level];
-  w.w = C.w, w.h = C.h;
-  w.r_zsel = ref->selections[sel].zsel[level];
-  w.r_i = R.r_i, w.r_ix = R.r_ix, w.r_iy = R.r_iy;
-  w.tx = R.tx, w.ty = R.ty;
-  w.c_a = C.c_a, w.c_b = C.c_b;
+  d.w = C.w, d.h = C.h;
+  d.r_zsel = ref->selections[sel].zsel[level];
+  d.r_i = R.r_i, d.r_ix = R.r_ix, d.r_iy = R.r_iy;
+  d.tx = R.tx, d.ty = R.ty;
+  d.c_a = C.c_a, d.c_b = C.c_b;
+  d.res[0] = slot.res[0], d.res[1] = slot.res[1];
+  d.records = slot.records;
+  d.ll_partials = slot.ll_partials;
+  d.cut[0] = slot.cut[0], d.cut[1] = slot.cut[1];
   // wcur / wref, dense_tracking.cpp:215-220
   const float wcur_id = 0.5f, wref_id = 0.5f, wcur_zd = 1.0f;
-  w.wc[0] = 1.0f / 255.0f, w.wc[1] = 1.0f;
-  w.wc[2] = wcur_id * C.fx / 255.0f, w.wc[3] = wcur_id * C.fy / 255.0f;
-  w.wc[4] = wcur_zd * C.fx, w.wc[5] = wcur_zd * C.fy;
-  w.wr[0] = -1.0f / 255.0f, w.wr[1] = -1.0f;
-  w.wr[2] = wref_id * C.fx / 255.0f, w.wr[3] = wref_id * C.fy / 255.0f;
-  w.ub_x = (float)(size_t)(C.w - 2), w.ub_y = (float)(size_t)(C.h - 2);
+  d.wc[0] = 1.0f / 255.0f, d.wc[1] = 1.0f;
+  d.wc[2] = wcur_id * C.fx / 255.0f, d.wc[3] = wcur_id * C.fy / 255.0f;
+  d.wc[4] = wcur_zd * C.fx, d.wc[5] = wcur_zd * C.fy;
+  d.wr[0] = -1.0f / 255.0f, d.wr[1] = -1.0f;
+  d.wr[2] = wref_id * C.fx / 255.0f, d.wr[3] = wref_id * C.fy / 255.0f;
+  d.ub_x = (float)(size_t)(C.w - 2), d.ub_y = (float)(size_t)(C.h - 2);
 }
 
 int blocks_for(int n, int rounds) {
@@ -604,8 +614,17 @@ int ensure_slots(dvo_amd_context *ctx, int n_jobs, int n_pad) {
   if (ctx->out_capacity < n_slots) {
     if (ctx->out_host) (void)hipHostFree(ctx->out_host);
     ctx->out_host = nullptr;
-    HIP_TRY(hipHostMalloc((void **)&ctx->out_host, sizeof(FinOut) * n_slots, hipHostMallocMapped));
+    HIP_TRY(hipHostMalloc((void **)&ctx->out_host, sizeof(FinOut) * n_slots, hipHostMallocMapped | hipHostMallocCoherent));
     ctx->out_capacity = n_slots;
+  }
+  if (ctx->desc_capacity < n_slots) {
+    if (ctx->desc_host) (void)hipHostFree(ctx->desc_host);
+    if (ctx->desc_dev) (void)hipFree(ctx->desc_dev);
+    ctx->desc_host = nullptr, ctx->desc_dev = nullptr;
+    const size_t bytes = sizeof(LevelPairDesc) * DVO_AMD_MAX_LEVELS * n_slots;
+    HIP_TRY(hipHostMalloc((void **)&ctx->desc_host, bytes, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void **)&ctx->desc_dev, bytes));
+    ctx->desc_capacity = n_slots;
   }
   const int max_blocks = new_pad / (kSegPxPerRound * kWavesPerBlock);
   const size_t b_res = align_up(sizeof(float2) * new_pad, 256);
@@ -627,16 +646,19 @@ int ensure_slots(dvo_amd_context *ctx, int n_jobs, int n_pad) {
     FinOut *dev_out = nullptr;
     HIP_TRY(hipHostGetDevicePointer((void **)&dev_out, ctx->out_host + i, 0));
     s.out = dev_out;
+    ctx->out_host[i].seq = 0;
   }
+  ctx->tick_seq = 0;
   ctx->slot_n_pad = new_pad;
   return DVO_AMD_OK;
 }
 
 int pick_rounds(long long total_px) {
-  // keep roughly <= 6144 waves in a launch (256 CUs x 8 waves x 3): more work per wave amortises the 93-value reduction
+  // A wave reduces its 93 partial sums once, whatever its share of pixels: more rounds per wave amortise that, fewer
+  // rounds give more waves to hide the gather latency.  Aim at >= 16 k waves per launch when the work allows.
   const long long waves1 = total_px / kSegPxPerRound;
   int rounds = 1;
-  while (rounds < kMaxRounds && waves1 / rounds > 6144) rounds *= 2;
+  while (rounds < kMaxRounds && waves1 / (rounds * 2) >= 16384) rounds *= 2;
   return rounds;
 }
 
@@ -663,86 +685,94 @@ int timing_collect(dvo_amd_context *ctx) {
   return DVO_AMD_OK;
 }
 
+// wait until the finalize kernel has published this tick's record of every submitted job
+int wait_tick(dvo_amd_context *ctx, const std::vector<Job> &jobs, unsigned seq) {
+  if (!ctx->poll || ctx->timing) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return DVO_AMD_OK;
+  }
+  for (const Job &j : jobs) {
+    if (j.done || !(j.sub_ll || j.sub_res)) continue;
+    const volatile unsigned *p = &ctx->out_host[j.slot - ctx->slots.data()].seq;
+    unsigned long long spins = 0;
+    while (__atomic_load_n(p, __ATOMIC_ACQUIRE) != seq) {
+      if ((++spins & 0xFFFFF) == 0) {  // every ~1M polls make sure the stream is still alive
+        hipError_t e = hipStreamQuery(ctx->stream);
+        if (e != hipSuccess && e != hipErrorNotReady) return fail_hip("stream died while waiting for a tick", e);
+        if (e == hipSuccess && __atomic_load_n(p, __ATOMIC_ACQUIRE) != seq)
+          return fail_hip("tick finished without publishing its record", hipErrorUnknown);
+      }
+    }
+  }
+  return DVO_AMD_OK;
+}
+
 // submit what every unfinished job needs, wait, advance the jobs
 int run_tick(dvo_amd_context *ctx, std::vector<Job> &jobs) {
   long long total_px = 0;
   for (Job &j : jobs)
     if (!j.done && j.have_b) total_px += j.ref->lv[j.level].n;
   const int rounds_now = pick_rounds(total_px);
+  const unsigned seq = ++ctx->tick_seq;
 
-  std::vector<WorkItem> items;
-  FinArgs fin;
-  fin.n_items = 0;
-  auto flush_fin = [&]() -> int {
-    if (fin.n_items > 0) {
-      hipError_t e = launch_finalize(fin, ctx->stream);
-      if (e != hipSuccess) return fail_hip("launch_finalize", e);
-      fin.n_items = 0;
-    }
-    return DVO_AMD_OK;
-  };
+  std::vector<TickItem> items;
   std::vector<FinItem> fin_items;
-
+  items.reserve(jobs.size());
+  fin_items.reserve(jobs.size());
   for (size_t ji = 0; ji < jobs.size(); ++ji) {
     Job &j = jobs[ji];
     if (j.done) continue;
     j.sub_ll = j.sub_res = false;
+    if (!j.have_a && !j.have_b) continue;
+    const size_t slot_index = (size_t)(j.slot - ctx->slots.data());
+    TickItem w;
+    std::memset(&w, 0, sizeof(w));
+    w.desc = ctx->desc_dev + slot_index * DVO_AMD_MAX_LEVELS + j.level;
     FinItem f;
     f.records = nullptr, f.n_blocks = 0, f.n_ll_blocks = 0, f.ll_partials = j.slot->ll_partials;
-    f.cut_out = j.slot->cut[0], f.out = j.slot->out;
+    f.cut_out = j.slot->cut[0], f.out = j.slot->out, f.seq = seq, f.pad = 0;
     if (j.have_a) {
-      WorkItem w;
-      std::memset(&w, 0, sizeof(w));
-      w.type = kWorkLogLik;
-      fill_level_fields(w, j.ref, j.sel, j.cur, j.level);
-      w.rounds = j.a.rounds;
-      w.n_blocks = j.a.n_blocks;
-      w.res = j.slot->res[j.a.buf];
-      w.records = (float *)j.slot->ll_partials;
-      w.cut = j.slot->cut[j.a.buf];
-      std::memcpy(w.P, j.a.P, sizeof(w.P));
-      items.push_back(w);
-      f.n_ll_blocks = w.n_blocks;
+      w.ll_blocks = j.a.n_blocks;
+      w.ll_rounds = j.a.rounds;
+      w.ll_buf = j.a.buf;
+      std::memcpy(w.P_ll, j.a.P, sizeof(w.P_ll));
+      f.n_ll_blocks = w.ll_blocks;
       j.sub_ll = true;
     }
     if (j.have_b) {
-      WorkItem w;
-      std::memset(&w, 0, sizeof(w));
-      w.type = kWorkResidual;
-      fill_level_fields(w, j.ref, j.sel, j.cur, j.level);
       j.b.rounds = rounds_now;
       j.b.n_blocks = blocks_for(j.ref->lv[j.level].n, rounds_now);
-      w.rounds = j.b.rounds;
-      w.n_blocks = j.b.n_blocks;
+      w.res_blocks = j.b.n_blocks;
+      w.res_rounds = j.b.rounds;
+      w.res_buf = j.b.buf;
       w.unit_weights = j.b.k == 0 ? 1 : 0;  // dense_tracking.cpp:286-293
-      w.res = j.slot->res[j.b.buf];
-      w.records = j.slot->records;
       make_kt(j.cur->lv[j.level], j.b.estimate_after, w.kt);
-      // weights of iteration k use the precision of iteration k-1, which is iteration a's (or stale zeros at k = 0)
-      std::memcpy(w.P, j.have_a ? j.a.P : j.precision, sizeof(w.P));
-      items.push_back(w);
+      // weights of iteration k use the precision of iteration k-1, which is iteration a's (unused at k = 0)
+      std::memcpy(w.P_res, j.have_a ? j.a.P : j.precision, sizeof(w.P_res));
       f.records = j.slot->records;
-      f.n_blocks = w.n_blocks;
+      f.n_blocks = w.res_blocks;
       f.cut_out = j.slot->cut[j.b.buf];
       j.sub_res = true;
       j.result->n_residual_passes++;
       j.alg_px += (double)j.ref->selections[j.sel].count[j.level];
     }
-    if (j.sub_ll || j.sub_res) {
-      fin_items.push_back(f);
-      j.result->n_ticks++;
-    }
+    items.push_back(w);
+    fin_items.push_back(f);
+    j.result->n_ticks++;
   }
+  if (items.empty()) return DVO_AMD_OK;
 
-  // residual / likelihood work, kMaxItemsPerLaunch items per launch
-  for (size_t first = 0; first < items.size(); first += kMaxItemsPerLaunch) {
+  // split evenly over as few launches as the argument block allows
+  const size_t n_launch = (items.size() + kMaxItemsPerLaunch - 1) / kMaxItemsPerLaunch;
+  const size_t per = (items.size() + n_launch - 1) / n_launch;
+  for (size_t first = 0; first < items.size(); first += per) {
     TickArgs ta;
-    ta.n_items = (int)std::min<size_t>(kMaxItemsPerLaunch, items.size() - first);
+    ta.n_items = (int)std::min(per, items.size() - first);
     ta.pad = 0;
     int max_blocks = 0;
     for (int i = 0; i < ta.n_items; ++i) {
       ta.items[i] = items[first + i];
-      max_blocks = std::max(max_blocks, ta.items[i].n_blocks);
+      max_blocks = std::max(max_blocks, ta.items[i].res_blocks + ta.items[i].ll_blocks);
     }
     size_t ev = 0;
     if (ctx->timing) {
@@ -753,18 +783,18 @@ int run_tick(dvo_amd_context *ctx, std::vector<Job> &jobs) {
     if (e != hipSuccess) return fail_hip("launch_tick", e);
     if (ctx->timing) HIP_TRY(hipEventRecord(ctx->events[ev].second, ctx->stream));
   }
-  for (size_t i = 0; i < fin_items.size(); ++i) {
-    fin.items[fin.n_items++] = fin_items[i];
-    if (fin.n_items == kMaxFinItems) {
-      int rc = flush_fin();
-      if (rc) return rc;
-    }
+  for (size_t first = 0; first < fin_items.size(); first += kMaxFinItems) {
+    FinArgs fa;
+    fa.n_items = (int)std::min<size_t>(kMaxFinItems, fin_items.size() - first);
+    fa.pad = 0;
+    for (int i = 0; i < fa.n_items; ++i) fa.items[i] = fin_items[first + i];
+    hipError_t e = launch_finalize(fa, ctx->stream);
+    if (e != hipSuccess) return fail_hip("launch_finalize", e);
   }
   {
-    int rc = flush_fin();
+    int rc = wait_tick(ctx, jobs, seq);
     if (rc) return rc;
   }
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
   if (ctx->timing) {
     int rc = timing_collect(ctx);
     if (rc) return rc;
@@ -858,6 +888,8 @@ int dvo_amd_context_create(int device, const dvo_amd_config *cfg, dvo_amd_contex
     delete ctx;
     return fail_hip("hipStreamCreate", e);
   }
+  const char *pe = getenv("DVO_AMD_POLL");
+  ctx->poll = !(pe && pe[0] == '0');
   *out = ctx;
   return DVO_AMD_OK;
 }
@@ -869,6 +901,8 @@ void dvo_amd_context_destroy(dvo_amd_context *ctx) {
   for (JobSlot &s : ctx->slots)
     if (s.dev_block) (void)hipFree(s.dev_block);
   if (ctx->out_host) (void)hipHostFree(ctx->out_host);
+  if (ctx->desc_host) (void)hipHostFree(ctx->desc_host);
+  if (ctx->desc_dev) (void)hipFree(ctx->desc_dev);
   for (auto &ev : ctx->events) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
@@ -1025,8 +1059,12 @@ int dvo_amd_match_batch(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *ref
     j.initial = j.inc;
     j.estimate = SE3::identity();
     j.level = cfg.first_level;
+    for (int l = cfg.last_level; l <= cfg.first_level; ++l)
+      fill_desc(ctx->desc_host[(size_t)i * DVO_AMD_MAX_LEVELS + l], j.ref, j.sel, j.cur, l, *j.slot);
     start_level(j);
   }
+  HIP_TRY(hipMemcpyAsync(ctx->desc_dev, ctx->desc_host, sizeof(LevelPairDesc) * DVO_AMD_MAX_LEVELS * (size_t)n,
+                         hipMemcpyHostToDevice, ctx->stream));
   for (;;) {
     bool any = false;
     for (const Job &j : jobs) any = any || !j.done;
@@ -1058,31 +1096,34 @@ int dvo_amd_residuals(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_
   rc = ensure_slots(ctx, 1, R.n_pad);
   if (rc) return rc;
   JobSlot &s = ctx->slots[0];
+  fill_desc(ctx->desc_host[level], reference, sel, current, level, s);
+  HIP_TRY(hipMemcpyAsync(ctx->desc_dev + level, ctx->desc_host + level, sizeof(LevelPairDesc), hipMemcpyHostToDevice,
+                         ctx->stream));
   TickArgs ta;
   std::memset(&ta, 0, sizeof(ta));
   ta.n_items = 1;
-  WorkItem &w = ta.items[0];
-  w.type = kWorkResidual;
-  fill_level_fields(w, reference, sel, current, level);
-  w.rounds = 1;
-  w.n_blocks = blocks_for(R.n, 1);
+  TickItem &w = ta.items[0];
+  w.desc = ctx->desc_dev + level;
+  w.res_rounds = 1;
+  w.res_blocks = blocks_for(R.n, 1);
   w.unit_weights = 1;
-  w.res = s.res[0];
-  w.records = s.records;
+  w.res_buf = 0;
   const float K[9] = {C.fx, 0.0f, C.ox, 0.0f, C.fy, C.oy, 0.0f, 0.0f, 1.0f};
   for (int i = 0; i < 3; ++i)
     for (int c = 0; c < 4; ++c)
       w.kt[i * 4 + c] = (K[i * 3 + 0] * T[c * 4 + 0] + K[i * 3 + 1] * T[c * 4 + 1]) + K[i * 3 + 2] * T[c * 4 + 2];
-  hipError_t e = launch_tick(ta, w.n_blocks, ctx->stream);
+  hipError_t e = launch_tick(ta, w.res_blocks, ctx->stream);
   if (e != hipSuccess) return fail_hip("launch_tick", e);
   FinArgs fa;
   fa.n_items = 1;
   fa.items[0].records = s.records;
-  fa.items[0].n_blocks = w.n_blocks;
+  fa.items[0].n_blocks = w.res_blocks;
   fa.items[0].n_ll_blocks = 0;
   fa.items[0].ll_partials = s.ll_partials;
   fa.items[0].cut_out = s.cut[0];
   fa.items[0].out = s.out;
+  fa.items[0].seq = ++ctx->tick_seq;
+  fa.items[0].pad = 0;
   e = launch_finalize(fa, ctx->stream);
   if (e != hipSuccess) return fail_hip("launch_finalize", e);
   if (residuals)
@@ -1108,6 +1149,10 @@ int dvo_amd_error_image(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_am
   }
   return DVO_AMD_OK;
 }
+
+void dvo_amd_se3_exp(const double *xi, double *T) { se3_matrix(se3_exp(xi), T); }
+void dvo_amd_se3_log(const double *T, double *xi) { se3_log(se3_from_matrix(T), xi); }
+void dvo_amd_solve6(const double *A, const double *b, double *x) { solve_ldlt6(A, b, x); }
 
 int dvo_amd_kernel_timing(dvo_amd_context *ctx, int enable, double *ms_residual_pass, long long *n_launches, int reset) {
   if (!ctx) return DVO_AMD_ERR_INVALID_ARGUMENT;

@@ -30,37 +30,46 @@ constexpr int kRecStride = 104;
 //   [63..68] sum w Ja_i r0   [69..74] sum w Ja_i r1   [75..80] sum w Jb_i r0   [81..86] sum w Jb_i r1
 constexpr int kAccAA = 0, kAccAB = 21, kAccBB = 42, kAccAR0 = 63, kAccAR1 = 69, kAccBR0 = 75, kAccBR1 = 81;
 
-enum WorkType : int { kWorkResidual = 0, kWorkLogLik = 1 };
-
-// One unit of device work of a tick, passed by value in the kernel arguments (no H2D copy per iteration).
-struct WorkItem {
-  int type;          // WorkType
-  int n_blocks;      // blocks this item uses (grid.x may be larger)
-  int rounds;        // rounds per wave
-  int w, h;          // level size
-  int unit_weights;  // first iteration on a level: weights = 1 (dense_tracking.cpp:286-289)
-  int pad0, pad1;
+// Static description of one (reference level, current level) pair plus the scratch of the job slot that aligns it.
+// Lives in device memory; written once per match call, read by every block through scalar loads.
+struct LevelPairDesc {
   // reference level (planar, padded to kPlanePad, zsel = NaN where the pixel is not selected)
   const float *r_zsel, *r_i, *r_ix, *r_iy;
   const float *tx, *ty;  // ((float)x - ox)/fx, ((float)y - oy)/fy
   // current level, gather layout
   const float4 *c_a;  // {I, Z, Ix, Iy} per pixel
   const float2 *c_b;  // {Zx, Zy} per pixel
-  float2 *res;        // residual buffer of this iteration (written by kWorkResidual, read by kWorkLogLik), NaN = invalid
-  float *records;     // kWorkResidual: n_blocks x kRecStride floats;  kWorkLogLik: n_blocks doubles
-  const int *cut;     // kWorkLogLik: {cut_seg, cut_local} written by the finalize kernel of that iteration
-  float kt[12];       // K * T[0:3,0:4], row-major, float (dense_tracking_impl.cpp:142-152)
-  float P[4];         // precision, column-major: previous iteration's for kWorkResidual, this iteration's for kWorkLogLik
-  float wc[6];        // wcur: {1/255, 1, .5fx/255, .5fy/255, fx, fy}  (dense_tracking.cpp:219)
-  float wr[4];        // wref: {-1/255, -1, .5fx/255, .5fy/255}        (dense_tracking.cpp:220)
-  float ub_x, ub_y;   // (float)(w-2), (float)(h-2)
+  // job-slot scratch
+  float2 *res[2];       // residual buffers (double buffered by iteration parity), NaN = invalid
+  float *records;       // residual pass: n_blocks x kRecStride floats
+  double *ll_partials;  // log-likelihood pass: one double per block
+  int *cut[2];          // {cut_seg, cut_local} of the residual pass that filled res[i]
+  int w, h;
+  float wc[6];          // wcur: {1/255, 1, .5fx/255, .5fy/255, fx, fy}  (dense_tracking.cpp:219)
+  float wr[4];          // wref: {-1/255, -1, .5fx/255, .5fy/255}        (dense_tracking.cpp:220)
+  float ub_x, ub_y;     // (float)(w-2), (float)(h-2)
 };
 
-constexpr int kMaxItemsPerLaunch = 14;
+// One job's device work of a tick, passed by value in the kernel arguments (no H2D copy per iteration):
+// blocks [0, res_blocks) run the residual pass of iteration k+1, blocks [res_blocks, res_blocks + ll_blocks) the
+// log-likelihood pass of iteration k.
+struct TickItem {
+  const LevelPairDesc *desc;
+  int res_blocks, ll_blocks;
+  int res_rounds, ll_rounds;  // rounds per wave
+  int res_buf, ll_buf;        // which residual buffer is written / read
+  int unit_weights;           // first iteration on a level: weights = 1 (dense_tracking.cpp:286-289)
+  int pad;
+  float kt[12];               // K * T[0:3,0:4], row-major, float (dense_tracking_impl.cpp:142-152)
+  float P_res[4];             // precision of the previous iteration (weights), column-major
+  float P_ll[4];              // precision of the iteration whose likelihood is evaluated
+};
+
+constexpr int kMaxItemsPerLaunch = 30;
 struct TickArgs {
   int n_items;
   int pad;
-  WorkItem items[kMaxItemsPerLaunch];
+  TickItem items[kMaxItemsPerLaunch];
 };
 static_assert(sizeof(TickArgs) <= 3800, "kernel argument block too large");
 
@@ -69,7 +78,7 @@ struct FinOut {
   int valid;       // V: number of valid constraints of the residual pass
   int has_res;     // a residual pass was reduced
   int has_ll;
-  int pad;
+  unsigned seq;    // written last (system scope): the tick number this record belongs to
   double S[3];     // sum over pairs (w_2j + w_2j+1) r_2j r_2j^T  (xx, xy, yy), unscaled (Q5 pairing)
   double acc[kNumAcc];
   double ll_sum;   // sum of log(1 + 0.2 r^T P r) over the first 50*floor(V/50) valid residuals (Q6)
@@ -82,8 +91,10 @@ struct FinItem {
   const double *ll_partials;
   int *cut_out;           // {cut_seg, cut_local} for the residual pass just reduced
   FinOut *out;
+  unsigned seq;
+  unsigned pad;
 };
-constexpr int kMaxFinItems = 64;
+constexpr int kMaxFinItems = 64;  // 48 B each
 struct FinArgs {
   int n_items;
   int pad;

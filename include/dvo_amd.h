@@ -169,6 +169,13 @@ int dvo_amd_residuals(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_
 int dvo_amd_error_image(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, const double *T,
                         int level, float *image);
 
+/* Host-side helpers (no GPU needed): the SE(3) exponential / logarithm with Sophus' tangent order (upsilon, omega) and the
+ * pivoted LDL^T 6x6 solve the driver uses in place of Sophus::SE3d::exp/log and Eigen::LDLT (dense_tracking.cpp:238,259,347).
+ * Exported so that bindings do not need Sophus to build a T_init or to compare poses. */
+void dvo_amd_se3_exp(const double *xi, double *T);
+void dvo_amd_se3_log(const double *T, double *xi);
+void dvo_amd_solve6(const double *A, const double *b, double *x);
+
 /* timing helper for bench.py: HIP-event milliseconds the context's stream spent in its residual-pass kernel since the last
  * reset, and the number of launches */
 int dvo_amd_kernel_timing(dvo_amd_context *ctx, int enable, double *ms_residual_pass, long long *n_launches, int reset);
