@@ -26,7 +26,7 @@ EXPORTS = [
     "dvo_amd_pyramid_release", "dvo_amd_pyramid_levels", "dvo_amd_pyramid_timestamp", "dvo_amd_pyramid_level_info",
     "dvo_amd_pyramid_download_plane", "dvo_amd_pyramid_select", "dvo_amd_match", "dvo_amd_match_batch",
     "dvo_amd_residuals", "dvo_amd_error_image", "dvo_amd_kernel_timing", "dvo_amd_se3_exp", "dvo_amd_se3_log",
-    "dvo_amd_solve6",
+    "dvo_amd_solve6", "dvo_amd_bench_residual_pass",
 ]
 
 
@@ -120,6 +120,8 @@ def lib():
     L.dvo_amd_residuals.argtypes = [vp, vp, vp, C.c_int, fp, fp, C.POINTER(C.c_int)]
     L.dvo_amd_error_image.argtypes = [vp, vp, vp, dp, C.c_int, fp]
     L.dvo_amd_kernel_timing.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_longlong), C.c_int]
+    L.dvo_amd_bench_residual_pass.argtypes = [vp, vp, vp, C.c_int, fp, C.c_int, C.c_int, C.c_int, dp, dp,
+                                              C.POINTER(C.c_int)]
     L.dvo_amd_se3_exp.argtypes = [dp, dp]
     L.dvo_amd_se3_exp.restype = None
     L.dvo_amd_se3_log.argtypes = [dp, dp]
@@ -346,6 +348,14 @@ class DenseTracker:
         _check(lib().dvo_amd_error_image(self._h, reference._h, current._h, Td.ctypes.data_as(C.POINTER(C.c_double)),
                                          level, _fp(out)), "dvo_amd_error_image")
         return out
+
+    def bench_residual_pass(self, reference, current, level: int, T, n_items: int, rounds: int = 0, reps: int = 20):
+        """Time the fused residual-pass kernel alone.  Returns (avg ms per repetition, algorithmic bytes, launches)."""
+        Tf = np.ascontiguousarray(np.asarray(T, dtype=np.float64).astype(np.float32).T)
+        ms, ab, nl = C.c_double(), C.c_double(), C.c_int()
+        _check(lib().dvo_amd_bench_residual_pass(self._h, reference._h, current._h, level, _fp(Tf), n_items, rounds, reps,
+                                                 C.byref(ms), C.byref(ab), C.byref(nl)), "dvo_amd_bench_residual_pass")
+        return ms.value, ab.value, nl.value
 
     def kernel_timing(self, enable: bool, reset: bool = False):
         ms = C.c_double()

@@ -93,10 +93,15 @@ __device__ __forceinline__ float rcp_toward_zero(float z) {
   return __builtin_copysignf(u2f(pick), z);
 }
 
-// 16 bytes = two adjacent {Zx,Zy} pairs; only 8-byte aligned
-struct __attribute__((packed, aligned(8))) f4_align8 {
-  float a, b, c, d;
-};
+// Pointers read from a descriptor in memory are generic ("flat") to the compiler; flat loads are slower and cannot be
+// counted separately from LDS traffic.  Everything the kernels touch lives in device global memory: say so.
+#define DVO_GLOBAL __attribute__((address_space(1)))
+typedef float v4f __attribute__((ext_vector_type(4)));               // plain vector types: loadable from any address space
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f_a8 __attribute__((ext_vector_type(4), aligned(8)));  // 16 bytes that are only 8-byte aligned
+typedef const DVO_GLOBAL float *gcf;
+typedef const DVO_GLOBAL v4f *gcf4;
+
 
 // ------------------------------------------------------------------------------------------------------------------
 // residual pass
@@ -111,258 +116,294 @@ struct PixelOut {  // live across the RTZ -> RN switch
   bool valid[kPxPerLane];
 };
 
-// computeResidualsSse for one reference pixel, dense_tracking_impl.cpp:171-294.  Runs in round-toward-zero.
-__device__ __forceinline__ void warp_pixel_rtz(const TickItem &it, const LevelPairDesc &d, float x, float y, float z, float ri, float rix, float riy,
-                                               float &r0, float &r1, float &e2, float &e3, float &e4, float &e5,
-                                               bool &valid) {
+// computeResidualsSse for one reference pixel, dense_tracking_impl.cpp:171-294, split in three so that the 24 gather
+// loads of a round (4 pixels x 6) are issued back to back instead of one pixel's loads waiting behind the previous
+// pixel's arithmetic.  All three parts run in round-toward-zero.
+struct Proj {
+  float u, v, sz;
+  int base;   // top-left gather index, 0 when the point falls outside
+  bool inb;
+};
+struct Gathered {
+  v4f a00, a10, a01, a11;  // {I, Z, Ix, Iy} of the four neighbours
+  v4f_a8 b0, b1;           // {Zx, Zy} pairs of the upper and lower row
+};
+
+__device__ __forceinline__ Proj project_pixel_rtz(const TickItem &it, const LevelPairDesc &d, float x, float y, float z) {
   const float *kt = it.kt;
   // hadd(hadd()) adds lanes (0,1) and (2,3) first (:178-188); the point's w is 1
   const float sx = (kt[0] * x + kt[1] * y) + (kt[2] * z + kt[3]);
   const float sy = (kt[4] * x + kt[5] * y) + (kt[6] * z + kt[7]);
-  const float sz = (kt[8] * x + kt[9] * y) + (kt[10] * z + kt[11]);
-  const float rz = rcp_toward_zero(sz);
-  const float u = sx * rz, v = sy * rz;
-  valid = false;
-  r0 = r1 = e2 = e3 = e4 = e5 = 0.0f;
+  Proj p;
+  p.sz = (kt[8] * x + kt[9] * y) + (kt[10] * z + kt[11]);
+  const float rz = rcp_toward_zero(p.sz);
+  p.u = sx * rz, p.v = sy * rz;
   // 0 <= u <= w-2 and 0 <= v <= h-2 (:160-161,203); NaN compares false
-  if ((u >= 0.0f) && (u <= d.ub_x) && (v >= 0.0f) && (v <= d.ub_y)) {
-    const int iu = (int)u, iv = (int)v;  // truncation == _mm_cvtps_epi32 under RTZ (:195)
-    const float w1u = u - (float)iu, w1v = v - (float)iv;
-    const float w0u = 1.0f - w1u, w0v = 1.0f - w1v;
-    const int base = iv * d.w + iu;
-    const float4 a00 = d.c_a[base], a10 = d.c_a[base + 1];
-    const float4 a01 = d.c_a[base + d.w], a11 = d.c_a[base + d.w + 1];
-    const f4_align8 b0 = *reinterpret_cast<const f4_align8 *>(d.c_b + base);
-    const f4_align8 b1 = *reinterpret_cast<const f4_align8 *>(d.c_b + base + d.w);
-    // bilinear blend, per channel: w0v*(w0u*c00 + w1u*c10) + w1v*(w0u*c01 + w1u*c11)  (:227-258)
-#define DVO_BLEND(c00, c10, c01, c11) ((w0v * (w0u * (c00) + w1u * (c10))) + (w1v * (w0u * (c01) + w1u * (c11))))
-    const float ci = DVO_BLEND(a00.x, a10.x, a01.x, a11.x);
-    const float cz = DVO_BLEND(a00.y, a10.y, a01.y, a11.y);
-    const float cix = DVO_BLEND(a00.z, a10.z, a01.z, a11.z);
-    const float ciy = DVO_BLEND(a00.w, a10.w, a01.w, a11.w);
-    const float czx = DVO_BLEND(b0.a, b0.c, b1.a, b1.c);
-    const float czy = DVO_BLEND(b0.b, b0.d, b1.b, b1.d);
-#undef DVO_BLEND
-    // any NaN among the blended channels rejects the point (:261); channels 6,7 are always 0
-    const bool has_nan = (ci != ci) || (cz != cz) || (cix != cix) || (ciy != ciy) || (czx != czx) || (czy != czy);
-    if (!has_nan) {
-      // e = wcur * cur + wref * ref', ref' = {I, transformed depth, Ix, Iy} (:269-271)
-      const float t0 = d.wc[0] * ci + d.wr[0] * ri;
-      const float t1 = d.wc[1] * cz + d.wr[1] * sz;
-      // occlusion test (:275) with depthStdDevZ (:122-128) of the reference depth
-      float s = z - 0.4f;
-      s = 0.0012f + (0.0019f * s) * s;
-      if (t1 > -20.0f * s) {
-        r0 = t0;
-        r1 = t1;
-        e2 = d.wc[2] * cix + d.wr[2] * rix;
-        e3 = d.wc[3] * ciy + d.wr[3] * riy;
-        e4 = d.wc[4] * czx;  // wref is 0 for the depth derivatives (dense_tracking.cpp:217-220)
-        e5 = d.wc[5] * czy;
-        valid = true;
-      }
-    }
-  }
+  p.inb = (p.u >= 0.0f) && (p.u <= d.ub_x) && (p.v >= 0.0f) && (p.v <= d.ub_y);
+  const int iu = (int)p.u, iv = (int)p.v;  // truncation == _mm_cvtps_epi32 under RTZ (:195)
+  p.base = p.inb ? iv * d.w + iu : 0;
+  return p;
 }
 
-template <int RMODE>
+__device__ __forceinline__ Gathered gather_pixel(const LevelPairDesc &d, int base) {
+  const gcf4 ca = (gcf4)d.c_a;
+  const gcf cb = (gcf)d.c_b;
+  Gathered g;
+  g.a00 = ca[base], g.a10 = ca[base + 1];
+  g.a01 = ca[base + d.w], g.a11 = ca[base + d.w + 1];
+  g.b0 = *reinterpret_cast<const DVO_GLOBAL v4f_a8 *>(cb + 2 * base);
+  g.b1 = *reinterpret_cast<const DVO_GLOBAL v4f_a8 *>(cb + 2 * (base + d.w));
+  return g;
+}
+
+__device__ __forceinline__ void finish_pixel_rtz(const LevelPairDesc &d, const Proj &p, const Gathered &g, float z, float ri,
+                                                 float rix, float riy, float &r0, float &r1, float &e2, float &e3, float &e4,
+                                                 float &e5, bool &valid) {
+  const float fu = (float)(int)p.u, fv = (float)(int)p.v;
+  const float w1u = p.u - fu, w1v = p.v - fv;
+  const float w0u = 1.0f - w1u, w0v = 1.0f - w1v;
+  // bilinear blend, per channel: w0v*(w0u*c00 + w1u*c10) + w1v*(w0u*c01 + w1u*c11)  (:227-258)
+#define DVO_BLEND(c00, c10, c01, c11) ((w0v * (w0u * (c00) + w1u * (c10))) + (w1v * (w0u * (c01) + w1u * (c11))))
+  const float ci = DVO_BLEND(g.a00.x, g.a10.x, g.a01.x, g.a11.x);
+  const float cz = DVO_BLEND(g.a00.y, g.a10.y, g.a01.y, g.a11.y);
+  const float cix = DVO_BLEND(g.a00.z, g.a10.z, g.a01.z, g.a11.z);
+  const float ciy = DVO_BLEND(g.a00.w, g.a10.w, g.a01.w, g.a11.w);
+  const float czx = DVO_BLEND(g.b0.x, g.b0.z, g.b1.x, g.b1.z);
+  const float czy = DVO_BLEND(g.b0.y, g.b0.w, g.b1.y, g.b1.w);
+#undef DVO_BLEND
+  // any NaN among the blended channels rejects the point (:261); channels 6,7 are always 0
+  const bool has_nan = (ci != ci) || (cz != cz) || (cix != cix) || (ciy != ciy) || (czx != czx) || (czy != czy);
+  // e = wcur * cur + wref * ref', ref' = {I, transformed depth, Ix, Iy} (:269-271)
+  const float t0 = d.wc[0] * ci + d.wr[0] * ri;
+  const float t1 = d.wc[1] * cz + d.wr[1] * p.sz;
+  // occlusion test (:275) with depthStdDevZ (:122-128) of the reference depth
+  float s = z - 0.4f;
+  s = 0.0012f + (0.0019f * s) * s;
+  valid = p.inb && !has_nan && (t1 > -20.0f * s);
+  r0 = valid ? t0 : 0.0f;
+  r1 = valid ? t1 : 0.0f;
+  e2 = valid ? d.wc[2] * cix + d.wr[2] * rix : 0.0f;
+  e3 = valid ? d.wc[3] * ciy + d.wr[3] * riy : 0.0f;
+  e4 = valid ? d.wc[4] * czx : 0.0f;  // wref is 0 for the depth derivatives (dense_tracking.cpp:217-220)
+  e5 = valid ? d.wc[5] * czy : 0.0f;
+}
+
+typedef float v4acc __attribute__((ext_vector_type(4)));
+
+// The fused residual pass.  A wave walks its segment in steps of 64 consecutive pixels, one pixel per lane, so that every
+// gather instruction of a step touches ~64 neighbouring pixels of the current image (whole cache lines, reused by the
+// other three neighbour loads of the same step while they are still in L1).
+//
+// ACC 0: the 87 moments live in 87 fp32 registers per lane (fma), reduced across the wave with DPP at the end.
+// ACC 1: the moments are the Gram matrix G = sum_p w_p v_p v_p^T of v = [Ja(6), Jb(6), r0, r1, 0, 0]; sqrt(w) v is staged
+//        through LDS (lane-per-point -> lane-per-component) and accumulated by v_mfma_f32_16x16x4_f32 into 2 x 4
+//        registers.  The MFMA sums over the points itself, so no 87-value wave reduction is needed and the kernel fits
+//        4 waves per SIMD (the 87-register form is capped at 2).
+template <int RMODE, int ACC>
 __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const int lb) {
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
   const int seg = lb * kWavesPerBlock + wave;
   const int w = d.w;
-  int idx = seg * (kSegPxPerRound * it.res_rounds) + lane * kPxPerLane;
+  const int steps = it.res_rounds * kPxPerLane;  // a segment is res_rounds * 256 pixels = steps * 64
+  int idx = seg * (kSegPxPerRound * it.res_rounds) + lane;
   int prow = idx / w;
   int pcol = idx - prow * w;
 
-  float acc[kNumAcc];
+  float acc[ACC == 0 ? kNumAcc : 1];
 #pragma unroll
-  for (int i = 0; i < kNumAcc; ++i) acc[i] = 0.0f;
+  for (int i = 0; i < (ACC == 0 ? kNumAcc : 1); ++i) acc[i] = 0.0f;
+  v4acc gram_a = {0.0f, 0.0f, 0.0f, 0.0f}, gram_b = {0.0f, 0.0f, 0.0f, 0.0f};
+  // staging for the MFMA operands: [wave][point = lane][16 components], 16-byte chunks XOR-swizzled by point
+  __shared__ __attribute__((aligned(16))) float stage[ACC == 1 ? kWavesPerBlock * kWave * 16 : 4];
   float S0[3] = {0.0f, 0.0f, 0.0f}, S1[3] = {0.0f, 0.0f, 0.0f};
   float first_w = 0.0f;
   int run_count = 0;                        // wave uniform
-  float carry_r0 = 0.0f, carry_r1 = 0.0f;   // wave uniform: residual of the last valid pixel of earlier rounds
+  float carry_r0 = 0.0f, carry_r1 = 0.0f;   // wave uniform: residual of the last valid pixel of earlier steps
   bool carry_has = false;
 
   const unsigned long long below = (1ull << lane) - 1ull;
   const bool unit_w = it.unit_weights != 0;
   const float P0 = it.P_res[0], P1 = it.P_res[1], P2 = it.P_res[2], P3 = it.P_res[3];
+  const gcf p_z = (gcf)d.r_zsel, p_i = (gcf)d.r_i, p_ix = (gcf)d.r_ix, p_iy = (gcf)d.r_iy, p_tx = (gcf)d.tx, p_ty = (gcf)d.ty;
+  DVO_GLOBAL v2f *const p_res = (DVO_GLOBAL v2f *)(it.res_buf ? d.res[1] : d.res[0]);  // no dynamic index: keeps d in registers
 
-  for (int round = 0; round < it.res_rounds; ++round) {
+  // reference scalars of the step about to be processed (loaded one step ahead)
+  float n_z = p_z[idx], n_i = p_i[idx], n_ix = p_ix[idx], n_iy = p_iy[idx];
+  float n_tx = p_tx[pcol], n_ty = p_ty[prow < d.h ? prow : d.h - 1];
+
+  for (int step = 0; step < steps; ++step) {
+    const int cur_idx = idx;
     // ---- round-to-nearest: reference point = pixel ray * depth (RgbdCamera::buildPointCloud, rgbd_image.cpp:245-262)
-    const float4 zs = *reinterpret_cast<const float4 *>(d.r_zsel + idx);
-    const float4 rI = *reinterpret_cast<const float4 *>(d.r_i + idx);
-    const float4 rIx = *reinterpret_cast<const float4 *>(d.r_ix + idx);
-    const float4 rIy = *reinterpret_cast<const float4 *>(d.r_iy + idx);
-    const float4 txv = *reinterpret_cast<const float4 *>(d.tx + pcol);
-    const float tyv = d.ty[prow < d.h ? prow : d.h - 1];
-    PixelIn pin;
-    pin.z[0] = zs.x, pin.z[1] = zs.y, pin.z[2] = zs.z, pin.z[3] = zs.w;
-    pin.x[0] = txv.x * zs.x, pin.x[1] = txv.y * zs.y, pin.x[2] = txv.z * zs.z, pin.x[3] = txv.w * zs.w;
-    pin.y[0] = tyv * zs.x, pin.y[1] = tyv * zs.y, pin.y[2] = tyv * zs.z, pin.y[3] = tyv * zs.w;
-    pin.ri[0] = rI.x, pin.ri[1] = rI.y, pin.ri[2] = rI.z, pin.ri[3] = rI.w;
-    pin.rix[0] = rIx.x, pin.rix[1] = rIx.y, pin.rix[2] = rIx.z, pin.rix[3] = rIx.w;
-    pin.riy[0] = rIy.x, pin.riy[1] = rIy.y, pin.riy[2] = rIy.z, pin.riy[3] = rIy.w;
-
-    // ---- switch to round-toward-zero
-#pragma unroll
-    for (int k = 0; k < kPxPerLane; ++k) {
-      DVO_OPAQUE(pin.x[k]); DVO_OPAQUE(pin.y[k]); DVO_OPAQUE(pin.z[k]);
-      DVO_OPAQUE(pin.ri[k]); DVO_OPAQUE(pin.rix[k]); DVO_OPAQUE(pin.riy[k]);
+    float z = n_z, ri = n_i, rix = n_ix, riy = n_iy;
+    float x = n_tx * z, y = n_ty * z;
+    // prefetch the next step's reference scalars; they are consumed a whole step later
+    idx += kWave;
+    pcol += kWave;
+    while (pcol >= w) pcol -= w, ++prow;
+    if (step + 1 < steps) {
+      n_z = p_z[idx], n_i = p_i[idx], n_ix = p_ix[idx], n_iy = p_iy[idx];
+      n_tx = p_tx[pcol], n_ty = p_ty[prow < d.h ? prow : d.h - 1];
     }
+
+    // ---- switch to round-toward-zero: every float that crosses is made opaque on both sides of the s_setreg
+    DVO_OPAQUE(x); DVO_OPAQUE(y); DVO_OPAQUE(z); DVO_OPAQUE(ri); DVO_OPAQUE(rix); DVO_OPAQUE(riy);
     round_toward_zero();
-#pragma unroll
-    for (int k = 0; k < kPxPerLane; ++k) {
-      DVO_OPAQUE(pin.x[k]); DVO_OPAQUE(pin.y[k]); DVO_OPAQUE(pin.z[k]);
-      DVO_OPAQUE(pin.ri[k]); DVO_OPAQUE(pin.rix[k]); DVO_OPAQUE(pin.riy[k]);
+    DVO_OPAQUE(x); DVO_OPAQUE(y); DVO_OPAQUE(z); DVO_OPAQUE(ri); DVO_OPAQUE(rix); DVO_OPAQUE(riy);
+    float r0, r1, e2, e3, e4, e5;
+    bool ok;
+    {
+      const Proj p = project_pixel_rtz(it, d, x, y, z);
+      const Gathered g = gather_pixel(d, p.base);
+      finish_pixel_rtz(d, p, g, z, ri, rix, riy, r0, r1, e2, e3, e4, e5, ok);
     }
-    PixelOut po;
-#pragma unroll
-    for (int k = 0; k < kPxPerLane; ++k)
-      warp_pixel_rtz(it, d, pin.x[k], pin.y[k], pin.z[k], pin.ri[k], pin.rix[k], pin.riy[k], po.r0[k], po.r1[k], po.e2[k],
-                     po.e3[k], po.e4[k], po.e5[k], po.valid[k]);
     // ---- back to round-to-nearest
-#pragma unroll
-    for (int k = 0; k < kPxPerLane; ++k) {
-      DVO_OPAQUE(po.r0[k]); DVO_OPAQUE(po.r1[k]); DVO_OPAQUE(po.e2[k]); DVO_OPAQUE(po.e3[k]);
-      DVO_OPAQUE(po.e4[k]); DVO_OPAQUE(po.e5[k]);
-      DVO_OPAQUE(pin.x[k]); DVO_OPAQUE(pin.y[k]); DVO_OPAQUE(pin.z[k]);
-    }
+    DVO_OPAQUE(r0); DVO_OPAQUE(r1); DVO_OPAQUE(e2); DVO_OPAQUE(e3); DVO_OPAQUE(e4); DVO_OPAQUE(e5);
+    DVO_OPAQUE(x); DVO_OPAQUE(y); DVO_OPAQUE(z);
     round_to_nearest();
-#pragma unroll
-    for (int k = 0; k < kPxPerLane; ++k) {
-      DVO_OPAQUE(po.r0[k]); DVO_OPAQUE(po.r1[k]); DVO_OPAQUE(po.e2[k]); DVO_OPAQUE(po.e3[k]);
-      DVO_OPAQUE(po.e4[k]); DVO_OPAQUE(po.e5[k]);
-      DVO_OPAQUE(pin.x[k]); DVO_OPAQUE(pin.y[k]); DVO_OPAQUE(pin.z[k]);
-    }
+    DVO_OPAQUE(r0); DVO_OPAQUE(r1); DVO_OPAQUE(e2); DVO_OPAQUE(e3); DVO_OPAQUE(e4); DVO_OPAQUE(e5);
+    DVO_OPAQUE(x); DVO_OPAQUE(y); DVO_OPAQUE(z);
 
-    // spill the residuals of this iteration for the log-likelihood pass (NaN marks an invalid pixel)
+    // spill the residual of this iteration for the log-likelihood pass (NaN marks an invalid pixel)
     {
       const float qnan = u2f(0x7fc00000u);
-      float4 s0, s1;
-      s0.x = po.valid[0] ? po.r0[0] : qnan, s0.y = po.valid[0] ? po.r1[0] : qnan;
-      s0.z = po.valid[1] ? po.r0[1] : qnan, s0.w = po.valid[1] ? po.r1[1] : qnan;
-      s1.x = po.valid[2] ? po.r0[2] : qnan, s1.y = po.valid[2] ? po.r1[2] : qnan;
-      s1.z = po.valid[3] ? po.r0[3] : qnan, s1.w = po.valid[3] ? po.r1[3] : qnan;
-      float4 *dst = reinterpret_cast<float4 *>(d.res[it.res_buf] + idx);
-      dst[0] = s0;
-      dst[1] = s1;
+      v2f sv;
+      sv.x = ok ? r0 : qnan, sv.y = ok ? r1 : qnan;
+      p_res[cur_idx] = sv;
     }
 
-    // ---- rank of every valid pixel in scan order within this wave's segment (needed by the pair quirk Q5)
-    unsigned long long B[kPxPerLane];
-    int before = 0, round_total = 0;
-    unsigned long long any_mask = 0;
-#pragma unroll
-    for (int k = 0; k < kPxPerLane; ++k) {
-      B[k] = __ballot(po.valid[k]);
-      before += __popcll(B[k] & below);
-      round_total += __popcll(B[k]);
-      any_mask |= B[k];
+    // Branch free from here: an invalid pixel carries weight 0, zero residuals and a harmless point (exact zeros).
+    // computeWeightsSse / computeWeight: w = (2+5)/(5 + r^T P r), mean 0 (dense_tracking_impl.cpp:640-707)
+    float wgt = 1.0f;
+    if (!unit_w) {
+      const float t0 = r0 * P0 + r1 * P1;
+      const float t1 = r0 * P2 + r1 * P3;
+      const float dd = t0 * r0 + t1 * r1;
+      wgt = 7.0f * __builtin_amdgcn_rcpf(5.0f + dd);
     }
-    float lane_last_r0 = 0.0f, lane_last_r1 = 0.0f;
-#pragma unroll
-    for (int k = 0; k < kPxPerLane; ++k)
-      if (po.valid[k]) lane_last_r0 = po.r0[k], lane_last_r1 = po.r1[k];
-    // residual of the valid pixel that precedes this lane's first one
-    const unsigned long long prev_lanes = any_mask & below;
-    const int src_lane = prev_lanes ? 63 - __clzll((long long)prev_lanes) : 0;
-    const float sh_r0 = __shfl(lane_last_r0, src_lane, 64), sh_r1 = __shfl(lane_last_r1, src_lane, 64);
-    float prev_r0 = prev_lanes ? sh_r0 : carry_r0;
-    float prev_r1 = prev_lanes ? sh_r1 : carry_r1;
-    bool prev_has = prev_lanes ? true : carry_has;
-    int rank = run_count + before;
+    wgt = ok ? wgt : 0.0f;
 
+    // Jacobians at the untransformed reference point (dense_tracking.cpp:333-339,448-476)
+    x = ok ? x : 0.0f, y = ok ? y : 0.0f, z = ok ? z : 1.0f;
+    const float iz = __builtin_amdgcn_rcpf(z);
+    const float iz2 = iz * iz;
+    const float j02 = -x * iz2, j12 = -y * iz2;
+    const float j03 = j02 * y, j13 = -1.0f + j12 * y;
+    const float j04 = 1.0f - j02 * x, j14 = -j03;
+    const float j05 = -y * iz, j15 = x * iz;
+    float Ja[6], Jb[6];
+    Ja[0] = e2 * iz;
+    Ja[1] = e3 * iz;
+    Ja[2] = e2 * j02 + e3 * j12;
+    Ja[3] = e2 * j03 + e3 * j13;
+    Ja[4] = e2 * j04 + e3 * j14;
+    Ja[5] = e2 * j05 + e3 * j15;
+    Jb[0] = e4 * iz;
+    Jb[1] = e5 * iz;
+    Jb[2] = (e4 * j02 + e5 * j12) - 1.0f;
+    Jb[3] = (e4 * j03 + e5 * j13) - y;
+    Jb[4] = (e4 * j04 + e5 * j14) + x;
+    Jb[5] = e4 * j05 + e5 * j15;
+    // A += J^T (w P) J and b -= J^T (w P) r are linear in P: accumulate the P-free moments (87 sums)
+    if (ACC == 0) {
+      float wa[6], wb[6];
 #pragma unroll
-    for (int k = 0; k < kPxPerLane; ++k) {
-      if (po.valid[k]) {
-        const float r0 = po.r0[k], r1 = po.r1[k];
-        // computeWeightsSse / computeWeight: w = (2+5)/(5 + r^T P r), mean 0 (dense_tracking_impl.cpp:640-707)
-        float wgt = 1.0f;
-        if (!unit_w) {
-          const float t0 = r0 * P0 + r1 * P1;
-          const float t1 = r0 * P2 + r1 * P3;
-          const float dd = t0 * r0 + t1 * r1;
-          wgt = 7.0f * __builtin_amdgcn_rcpf(5.0f + dd);
+      for (int i = 0; i < 6; ++i) wa[i] = wgt * Ja[i], wb[i] = wgt * Jb[i];
+      int t = 0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int j = i; j < 6; ++j, ++t) {
+          acc[kAccAA + t] = __builtin_fmaf(wa[i], Ja[j], acc[kAccAA + t]);
+          acc[kAccAB + t] = __builtin_fmaf(wa[i], Jb[j], __builtin_fmaf(wb[i], Ja[j], acc[kAccAB + t]));
+          acc[kAccBB + t] = __builtin_fmaf(wb[i], Jb[j], acc[kAccBB + t]);
         }
-        // computeScaleSse with Q5: a pair (2j, 2j+1) contributes (w_2j + w_2j+1) r_2j r_2j^T (:603-621).
-        // S0 assumes this segment starts on an even global rank, S1 on an odd one.
-        const float sxx = r0 * r0, sxy = r0 * r1, syy = r1 * r1;
-        const float pxx = prev_has ? prev_r0 * prev_r0 : 0.0f, pxy = prev_has ? prev_r0 * prev_r1 : 0.0f,
-                    pyy = prev_has ? prev_r1 * prev_r1 : 0.0f;
-        const bool odd = (rank & 1) != 0;
-        S0[0] = __builtin_fmaf(wgt, odd ? pxx : sxx, S0[0]);
-        S0[1] = __builtin_fmaf(wgt, odd ? pxy : sxy, S0[1]);
-        S0[2] = __builtin_fmaf(wgt, odd ? pyy : syy, S0[2]);
-        S1[0] = __builtin_fmaf(wgt, odd ? sxx : pxx, S1[0]);
-        S1[1] = __builtin_fmaf(wgt, odd ? sxy : pxy, S1[1]);
-        S1[2] = __builtin_fmaf(wgt, odd ? syy : pyy, S1[2]);
-        if (!prev_has) first_w = wgt;  // first valid pixel of the segment: its partner (if any) lives in an earlier segment
-
-        // Jacobians at the untransformed reference point (dense_tracking.cpp:333-339,448-476)
-        const float x = pin.x[k], y = pin.y[k], z = pin.z[k];
-        const float iz = __builtin_amdgcn_rcpf(z);
-        const float iz2 = iz * iz;
-        const float j02 = -x * iz2, j12 = -y * iz2;
-        const float j03 = j02 * y, j13 = -1.0f + j12 * y;
-        const float j04 = 1.0f - j02 * x, j14 = -j03;
-        const float j05 = -y * iz, j15 = x * iz;
-        const float e2 = po.e2[k], e3 = po.e3[k], e4 = po.e4[k], e5 = po.e5[k];
-        float Ja[6], Jb[6];
-        Ja[0] = e2 * iz;
-        Ja[1] = e3 * iz;
-        Ja[2] = e2 * j02 + e3 * j12;
-        Ja[3] = e2 * j03 + e3 * j13;
-        Ja[4] = e2 * j04 + e3 * j14;
-        Ja[5] = e2 * j05 + e3 * j15;
-        Jb[0] = e4 * iz;
-        Jb[1] = e5 * iz;
-        Jb[2] = (e4 * j02 + e5 * j12) - 1.0f;
-        Jb[3] = (e4 * j03 + e5 * j13) - y;
-        Jb[4] = (e4 * j04 + e5 * j14) + x;
-        Jb[5] = e4 * j05 + e5 * j15;
-        // A += J^T (w P) J and b -= J^T (w P) r are linear in P: accumulate the P-free moments (87 sums)
-        float wa[6], wb[6];
+        acc[kAccAR0 + i] = __builtin_fmaf(wa[i], r0, acc[kAccAR0 + i]);
+        acc[kAccAR1 + i] = __builtin_fmaf(wa[i], r1, acc[kAccAR1 + i]);
+        acc[kAccBR0 + i] = __builtin_fmaf(wb[i], r0, acc[kAccBR0 + i]);
+        acc[kAccBR1 + i] = __builtin_fmaf(wb[i], r1, acc[kAccBR1 + i]);
+      }
+    } else {
+      // stage sqrt(w) * v for this lane's pixel; chunk c of point p sits at chunk position c ^ ((p >> 1) & 3)
+      const float sw = __builtin_amdgcn_sqrtf(wgt);
+      float *buf = stage + wave * kWave * 16;
+      v4f *row = reinterpret_cast<v4f *>(buf + lane * 16);
+      const int swz = (lane >> 1) & 3;
+      v4f c0 = {sw * Ja[0], sw * Ja[1], sw * Ja[2], sw * Ja[3]};
+      v4f c1 = {sw * Ja[4], sw * Ja[5], sw * Jb[0], sw * Jb[1]};
+      v4f c2 = {sw * Jb[2], sw * Jb[3], sw * Jb[4], sw * Jb[5]};
+      v4f c3 = {sw * r0, sw * r1, 0.0f, 0.0f};
+      // the LDS queue of a wave is in order: these writes land after the previous step's reads; the fences only stop
+      // the compiler from reordering across them
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      row[0 ^ swz] = c0;
+      row[1 ^ swz] = c1;
+      row[2 ^ swz] = c2;
+      row[3 ^ swz] = c3;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // MFMA m consumes points 4m .. 4m+3: lane l supplies component l&15 of point 4m + (l>>4) as both A and B.
+      // Two accumulators alternate so that no MFMA waits for the one issued just before it.
+      const int comp = lane & 15, sub = lane >> 4;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) wa[i] = wgt * Ja[i], wb[i] = wgt * Jb[i];
-        int t = 0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-#pragma unroll
-          for (int j = i; j < 6; ++j, ++t) {
-            acc[kAccAA + t] = __builtin_fmaf(wa[i], Ja[j], acc[kAccAA + t]);
-            acc[kAccAB + t] = __builtin_fmaf(wa[i], Jb[j], __builtin_fmaf(wb[i], Ja[j], acc[kAccAB + t]));
-            acc[kAccBB + t] = __builtin_fmaf(wb[i], Jb[j], acc[kAccBB + t]);
-          }
-          acc[kAccAR0 + i] = __builtin_fmaf(wa[i], r0, acc[kAccAR0 + i]);
-          acc[kAccAR1 + i] = __builtin_fmaf(wa[i], r1, acc[kAccAR1 + i]);
-          acc[kAccBR0 + i] = __builtin_fmaf(wb[i], r0, acc[kAccBR0 + i]);
-          acc[kAccBR1 + i] = __builtin_fmaf(wb[i], r1, acc[kAccBR1 + i]);
-        }
-        prev_r0 = r0, prev_r1 = r1, prev_has = true;
-        ++rank;
+      for (int m = 0; m < 16; m += 2) {
+        const int pa = 4 * m + sub, pb = pa + 4;
+        const float va = buf[pa * 16 + ((((comp >> 2) ^ ((pa >> 1) & 3)) << 2) | (comp & 3))];
+        const float vb = buf[pb * 16 + ((((comp >> 2) ^ ((pb >> 1) & 3)) << 2) | (comp & 3))];
+        gram_a = __builtin_amdgcn_mfma_f32_16x16x4f32(va, va, gram_a, 0, 0, 0);
+        gram_b = __builtin_amdgcn_mfma_f32_16x16x4f32(vb, vb, gram_b, 0, 0, 0);
       }
     }
 
-    if (any_mask) {
-      const int top = 63 - __clzll((long long)any_mask);
-      carry_r0 = u2f(__builtin_amdgcn_readlane(f2u(lane_last_r0), top));
-      carry_r1 = u2f(__builtin_amdgcn_readlane(f2u(lane_last_r1), top));
+    // ---- rank of every valid pixel in scan order within this wave's segment (needed by the pair quirk Q5)
+    const unsigned long long bk = __ballot(ok);
+    const unsigned long long prev_lanes = bk & below;
+    const int rank = run_count + __popcll(prev_lanes);
+    // residual of the valid pixel that precedes this one: the nearest valid lower lane, else the carry of earlier steps
+    const int src_lane = prev_lanes ? 63 - __clzll((long long)prev_lanes) : 0;
+    const float sh_r0 = __shfl(r0, src_lane, 64), sh_r1 = __shfl(r1, src_lane, 64);
+    const float prev_r0 = prev_lanes ? sh_r0 : carry_r0;
+    const float prev_r1 = prev_lanes ? sh_r1 : carry_r1;
+    const bool prev_has = prev_lanes ? true : carry_has;
+    {
+      // computeScaleSse with Q5: a pair (2j, 2j+1) contributes (w_2j + w_2j+1) r_2j r_2j^T (:603-621).
+      // S0 assumes this segment starts on an even global rank, S1 on an odd one.  Invalid pixels have weight 0.
+      const float sxx = r0 * r0, sxy = r0 * r1, syy = r1 * r1;
+      const float pxx = prev_has ? prev_r0 * prev_r0 : 0.0f, pxy = prev_has ? prev_r0 * prev_r1 : 0.0f,
+                  pyy = prev_has ? prev_r1 * prev_r1 : 0.0f;
+      const bool odd = (rank & 1) != 0;
+      S0[0] = __builtin_fmaf(wgt, odd ? pxx : sxx, S0[0]);
+      S0[1] = __builtin_fmaf(wgt, odd ? pxy : sxy, S0[1]);
+      S0[2] = __builtin_fmaf(wgt, odd ? pyy : syy, S0[2]);
+      S1[0] = __builtin_fmaf(wgt, odd ? sxx : pxx, S1[0]);
+      S1[1] = __builtin_fmaf(wgt, odd ? sxy : pxy, S1[1]);
+      S1[2] = __builtin_fmaf(wgt, odd ? syy : pyy, S1[2]);
+      // first valid pixel of the segment: its partner (if any) lives in an earlier segment
+      first_w = (ok && !prev_has) ? wgt : first_w;
+    }
+    if (bk) {
+      const int top = 63 - __clzll((long long)bk);
+      carry_r0 = u2f(__builtin_amdgcn_readlane(f2u(r0), top));
+      carry_r1 = u2f(__builtin_amdgcn_readlane(f2u(r1), top));
       carry_has = true;
     }
-    run_count += round_total;
-
-    idx += kSegPxPerRound;
-    pcol += kSegPxPerRound;
-    while (pcol >= w) pcol -= w, ++prow;
+    run_count += __popcll(bk);
   }
 
   // ---- wave reduction, then the four waves of the block through LDS
   __shared__ float sm[kWavesPerBlock][kRecStride];
+  __shared__ float gsm[ACC == 1 ? kWavesPerBlock * 256 : 4];
+  if (ACC == 0) {
 #pragma unroll
-  for (int i = 0; i < kNumAcc; ++i) {
-    const float s = wave_sum_to_lane63<RMODE>(acc[i]);
-    if (lane == 63) sm[wave][kRecAcc + i] = s;
+    for (int i = 0; i < kNumAcc; ++i) {
+      const float s = wave_sum_to_lane63<RMODE>(acc[i]);
+      if (lane == 63) sm[wave][kRecAcc + i] = s;
+    }
+  } else {
+    // C/D layout of the 16x16 MFMA: register r of lane l is G[row = (l>>4)*4 + r][col = l&15]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gsm[wave * 256 + ((lane >> 4) * 4 + r) * 16 + (lane & 15)] = gram_a[r] + gram_b[r];
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -381,10 +422,34 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
   }
   __syncthreads();
 
-  float *rec = d.records + (size_t)lb * kRecStride;
+  DVO_GLOBAL float *rec = (DVO_GLOBAL float *)d.records + (size_t)lb * kRecStride;
   const int tid = threadIdx.x;
   if (tid < kNumAcc) {
-    rec[kRecAcc + tid] = (sm[0][kRecAcc + tid] + sm[1][kRecAcc + tid]) + (sm[2][kRecAcc + tid] + sm[3][kRecAcc + tid]);
+    if (ACC == 0) {
+      rec[kRecAcc + tid] = (sm[0][kRecAcc + tid] + sm[1][kRecAcc + tid]) + (sm[2][kRecAcc + tid] + sm[3][kRecAcc + tid]);
+    } else {
+      // map the moment index back to Gram-matrix entries (rows/cols 0-5 = Ja, 6-11 = Jb, 12 = r0, 13 = r1)
+      int e0, e1 = -1;
+      if (tid < kAccAR0) {
+        const int kind = tid / 21;
+        int t = tid - kind * 21, i = 0;
+        while (t >= 6 - i) t -= 6 - i, ++i;
+        const int j = i + t;
+        if (kind == 0) {
+          e0 = i * 16 + j;
+        } else if (kind == 1) {
+          e0 = i * 16 + 6 + j, e1 = j * 16 + 6 + i;
+        } else {
+          e0 = (6 + i) * 16 + 6 + j;
+        }
+      } else {
+        const int q = tid - kAccAR0, grp = q / 6, i = q - grp * 6;  // AR0, AR1, BR0, BR1
+        e0 = ((grp >> 1) * 6 + i) * 16 + 12 + (grp & 1);
+      }
+      float v = (gsm[e0] + gsm[256 + e0]) + (gsm[512 + e0] + gsm[768 + e0]);
+      if (e1 >= 0) v += (gsm[e1] + gsm[256 + e1]) + (gsm[512 + e1] + gsm[768 + e1]);
+      rec[kRecAcc + tid] = v;
+    }
   } else if (tid == 128) {
     // ordered combine of the four wave segments (see combine rule in k_finalize)
     int c = 0;
@@ -431,79 +496,101 @@ __device__ void loglik_pass(const TickItem &it, const LevelPairDesc &d, const in
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
   const int seg = lb * kWavesPerBlock + wave;
-  const int cut_seg = d.cut[it.ll_buf][0], cut_local = d.cut[it.ll_buf][1];
+  const DVO_GLOBAL int *cutp = (const DVO_GLOBAL int *)(it.ll_buf ? d.cut[1] : d.cut[0]);
+  const int cut_seg = cutp[0], cut_local = cutp[1];
   const float P0 = it.P_ll[0], P1 = it.P_ll[1], P2 = it.P_ll[2], P3 = it.P_ll[3];
   const unsigned long long below = (1ull << lane) - 1ull;
   double total = 0.0;
   if (seg <= cut_seg) {
     const bool partial = seg == cut_seg;
-    int idx = seg * (kSegPxPerRound * it.ll_rounds) + lane * kPxPerLane;
+    const int steps = it.ll_rounds * kPxPerLane;
+    const DVO_GLOBAL v2f *src = (const DVO_GLOBAL v2f *)(it.ll_buf ? d.res[1] : d.res[0]) + seg * (kSegPxPerRound * it.ll_rounds) + lane;
     int run_count = 0;
-    for (int round = 0; round < it.ll_rounds; ++round) {
-      const float4 *src = reinterpret_cast<const float4 *>(d.res[it.ll_buf] + idx);
-      const float4 s0 = src[0], s1 = src[1];
-      const float r0[kPxPerLane] = {s0.x, s0.z, s1.x, s1.z};
-      const float r1[kPxPerLane] = {s0.y, s0.w, s1.y, s1.w};
-      bool valid[kPxPerLane];
-      int before = 0, round_total = 0;
+    // four steps (256 pixels) per trip: one log of a product of up to four terms per lane
+    for (int step = 0; step < steps; step += 4) {
+      v2f r[4];
 #pragma unroll
-      for (int k = 0; k < kPxPerLane; ++k) {
-        valid[k] = r0[k] == r0[k];
-        const unsigned long long b = __ballot(valid[k]);
-        before += __popcll(b & below);
-        round_total += __popcll(b);
-      }
-      int rank = run_count + before;
+      for (int k = 0; k < 4; ++k) r[k] = src[(step + k) * kWave];
       double prod = 1.0;
 #pragma unroll
-      for (int k = 0; k < kPxPerLane; ++k) {
-        if (valid[k]) {
-          if (!partial || rank < cut_local) {
-            const float t0 = r0[k] * P0 + r1[k] * P1;
-            const float t1 = r0[k] * P2 + r1[k] * P3;
-            const float q = t0 * r0[k] + t1 * r1[k];
-            prod *= (1.0 + 0.2 * (double)q);
-          }
-          ++rank;
+      for (int k = 0; k < 4; ++k) {
+        const bool valid = r[k].x == r[k].x;
+        const unsigned long long b = __ballot(valid);
+        const int rank = run_count + __popcll(b & below);
+        if (valid && (!partial || rank < cut_local)) {
+          const float t0 = r[k].x * P0 + r[k].y * P1;
+          const float t1 = r[k].x * P2 + r[k].y * P3;
+          const float q = t0 * r[k].x + t1 * r[k].y;
+          prod *= (1.0 + 0.2 * (double)q);
         }
+        run_count += __popcll(b);
       }
       if (prod != 1.0) total += log(prod);
-      run_count += round_total;
-      idx += kSegPxPerRound;
     }
   }
   total = wave_sum_double(total);
   __shared__ double smd[kWavesPerBlock];
   if (lane == 0) smd[wave] = total;
   __syncthreads();
-  if (threadIdx.x == 0) d.ll_partials[lb] = (smd[0] + smd[1]) + (smd[2] + smd[3]);
+  if (threadIdx.x == 0) ((DVO_GLOBAL double *)d.ll_partials)[lb] = (smd[0] + smd[1]) + (smd[2] + smd[3]);
 }
 
-template <int RMODE>
-__global__ __launch_bounds__(kBlockThreads) void k_tick(const TickArgs args) {
+__device__ __forceinline__ LevelPairDesc load_desc(const LevelPairDesc *p) {
+  const __attribute__((address_space(4))) LevelPairDesc *c = (const __attribute__((address_space(4))) LevelPairDesc *)p;
+  LevelPairDesc d;
+  d.r_zsel = c->r_zsel, d.r_i = c->r_i, d.r_ix = c->r_ix, d.r_iy = c->r_iy;
+  d.tx = c->tx, d.ty = c->ty;
+  d.c_a = c->c_a, d.c_b = c->c_b;
+  d.res[0] = c->res[0], d.res[1] = c->res[1];
+  d.records = c->records, d.ll_partials = c->ll_partials;
+  d.cut[0] = c->cut[0], d.cut[1] = c->cut[1];
+  d.w = c->w, d.h = c->h;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) d.wc[i] = c->wc[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) d.wr[i] = c->wr[i];
+  d.ub_x = c->ub_x, d.ub_y = c->ub_y;
+  return d;
+}
+
+template <int RMODE, int ACC>
+__global__ __launch_bounds__(kBlockThreads, ACC == 1 ? 4 : 2) void k_tick(const TickArgs args) {
   const TickItem &it = args.items[blockIdx.y];
   const int bx = (int)blockIdx.x;
   if (bx >= it.res_blocks + it.ll_blocks) return;
-  const LevelPairDesc &d = *it.desc;
+  // Copy the level descriptor into registers once, through the constant address space (scalar loads).  Read through a
+  // plain global reference its fields are re-loaded with vector loads + s_waitcnt vmcnt(0) at every use inside the
+  // pixel loop, because the residual stores might alias them: ten dependent L2 round trips per 64 pixels.
+  const LevelPairDesc d = load_desc(it.desc);
   if (bx < it.res_blocks)
-    residual_pass<RMODE>(it, d, xcd_contiguous_block(bx, it.res_blocks));
+    residual_pass<RMODE, ACC>(it, d, xcd_contiguous_block(bx, it.res_blocks));
   else
     loglik_pass(it, d, bx - it.res_blocks);
 }
 
-static int g_reduce_mode = -1;
+static int g_reduce_mode = -1;  // DVO_AMD_REDUCE=0: ds_bpermute butterfly instead of DPP (debug cross-check)
+static int g_acc_mode = -1;     // DVO_AMD_ACCUM=valu: 87 register accumulators instead of the MFMA Gram matrix
 
 hipError_t launch_tick(const TickArgs &args, int max_blocks, hipStream_t stream) {
   if (g_reduce_mode < 0) {
     const char *e = getenv("DVO_AMD_REDUCE");
     g_reduce_mode = (e && e[0] == '0') ? 0 : 1;
+    const char *a = getenv("DVO_AMD_ACCUM");
+    g_acc_mode = (a && (a[0] == 'v' || a[0] == 'V' || a[0] == '0')) ? 0 : 1;
   }
   if (args.n_items <= 0 || max_blocks <= 0) return hipSuccess;
   dim3 grid((unsigned)((max_blocks + 7) & ~7), (unsigned)args.n_items, 1);
-  if (g_reduce_mode == 0)
-    hipLaunchKernelGGL(k_tick<0>, grid, dim3(kBlockThreads), 0, stream, args);
-  else
-    hipLaunchKernelGGL(k_tick<1>, grid, dim3(kBlockThreads), 0, stream, args);
+  if (g_acc_mode == 0) {
+    if (g_reduce_mode == 0)
+      hipLaunchKernelGGL((k_tick<0, 0>), grid, dim3(kBlockThreads), 0, stream, args);
+    else
+      hipLaunchKernelGGL((k_tick<1, 0>), grid, dim3(kBlockThreads), 0, stream, args);
+  } else {
+    if (g_reduce_mode == 0)
+      hipLaunchKernelGGL((k_tick<0, 1>), grid, dim3(kBlockThreads), 0, stream, args);
+    else
+      hipLaunchKernelGGL((k_tick<1, 1>), grid, dim3(kBlockThreads), 0, stream, args);
+  }
   return hipGetLastError();
 }
 
@@ -513,8 +600,10 @@ hipError_t launch_tick(const TickArgs &args, int max_blocks, hipStream_t stream)
 // cut, sums the log-likelihood partials.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kFinThreads = 1024;
-constexpr int kFinChunks = 10;
-constexpr int kFinCols = 96;
+constexpr int kFinSegThreads = 256;                       // threads [0,256): ordered part of the records
+constexpr int kFinCols = 96;                              // threads [256,1024): 8 row-chunks x 96 columns
+constexpr int kFinChunks = (kFinThreads - kFinSegThreads) / kFinCols;
+constexpr int kFinMaxOwn = 8;                             // blocks one "seg" thread folds (covers 2048 blocks)
 
 struct SegRec {
   int c;
@@ -542,82 +631,103 @@ __device__ __forceinline__ SegRec seg_combine(const SegRec &a, const SegRec &b) 
   return o;
 }
 
+// All global loads are issued in one phase, by role; then 8 tree/scan steps and the output.
 __global__ __launch_bounds__(kFinThreads) void k_finalize(const FinArgs args) {
   const FinItem &it = args.items[blockIdx.x];
   const int t = threadIdx.x;
   FinOut *out = it.out;
   __shared__ double sh_acc[kFinChunks][kFinCols];
-  __shared__ SegRec sh_seg[256];
-  __shared__ int sh_scan[kFinThreads];
-  __shared__ double sh_ll[kFinThreads];
+  __shared__ SegRec sh_seg[kFinSegThreads];
+  __shared__ int sh_cnt[kFinSegThreads];
 
+  const gcf recs = (gcf)it.records;
   const int nb = it.records ? it.n_blocks : 0;
-  if (nb > 0) {
-    // (a) the 87 plain sums
-    {
-      const int col = t % kFinCols, chunk = t / kFinCols;
-      if (chunk < kFinChunks) {
-        double s = 0.0;
-        if (col < kNumAcc)
-          for (int b = chunk; b < nb; b += kFinChunks) s += (double)it.records[(size_t)b * kRecStride + kRecAcc + col];
-        sh_acc[chunk][col] = s;
+  const int per = (nb + kFinSegThreads - 1) / kFinSegThreads;  // <= kFinMaxOwn by construction of the grid
+  int own_cnt[kFinMaxOwn * kWavesPerBlock];
+  int own_total = 0;
+  if (t < kFinSegThreads) {
+    SegRec r;
+    r.c = 0, r.first_w = 0.0f, r.l0 = r.l1 = 0.0f;
+    for (int i = 0; i < 3; ++i) r.s0[i] = r.s1[i] = 0.0;
+#pragma unroll
+    for (int k = 0; k < kFinMaxOwn; ++k) {
+      const int b = t * per + k;
+      const bool live = k < per && b < nb;
+      v4f h0 = {0.0f, 0.0f, 0.0f, 0.0f}, h1 = h0, h2 = h0, h3 = h0;
+      if (live) {
+        const gcf4 hp = reinterpret_cast<gcf4>(recs + (size_t)b * kRecStride);
+        h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3];
       }
+      SegRec q;
+      q.c = (int)f2u(h0.x);
+      q.first_w = h0.y, q.l0 = h0.z, q.l1 = h0.w;
+      q.s0[0] = h1.x, q.s0[1] = h1.y, q.s0[2] = h1.z;
+      q.s1[0] = h1.w, q.s1[1] = h2.x, q.s1[2] = h2.y;
+      own_cnt[4 * k + 0] = (int)f2u(h2.z), own_cnt[4 * k + 1] = (int)f2u(h2.w);
+      own_cnt[4 * k + 2] = (int)f2u(h3.x), own_cnt[4 * k + 3] = (int)f2u(h3.y);
+      if (live) r = seg_combine(r, q);
     }
-    // (b) ordered part: 256 threads each fold a contiguous run of blocks, then a log tree
-    if (t < 256) {
-      const int per = (nb + 255) / 256;
-      SegRec r;
-      r.c = 0, r.first_w = 0.0f, r.l0 = r.l1 = 0.0f;
-      for (int i = 0; i < 3; ++i) r.s0[i] = r.s1[i] = 0.0;
-      for (int b = t * per; b < (t + 1) * per && b < nb; ++b) {
-        const float *rec = it.records + (size_t)b * kRecStride;
-        SegRec q;
-        q.c = (int)f2u(rec[kRecCount]);
-        q.first_w = rec[kRecFirstW];
-        q.l0 = rec[kRecLastR], q.l1 = rec[kRecLastR + 1];
-        for (int i = 0; i < 3; ++i) q.s0[i] = rec[kRecS0 + i], q.s1[i] = rec[kRecS1 + i];
-        r = seg_combine(r, q);
-      }
-      sh_seg[t] = r;
+    sh_seg[t] = r;
+    sh_cnt[t] = r.c;
+    own_total = r.c;
+  } else {
+    const int col = (t - kFinSegThreads) % kFinCols, chunk = (t - kFinSegThreads) / kFinCols;
+    double s = 0.0;
+    if (col < kNumAcc) {
+      for (int b = chunk; b < nb; b += kFinChunks) s += (double)recs[(size_t)b * kRecStride + kRecAcc + col];
+    } else {
+      // the 9 spare columns x 8 chunks sum the log-likelihood partials
+      const int lane72 = chunk * (kFinCols - kNumAcc) + (col - kNumAcc);
+      const DVO_GLOBAL double *llp = (const DVO_GLOBAL double *)it.ll_partials;
+      for (int b = lane72; b < it.n_ll_blocks; b += kFinChunks * (kFinCols - kNumAcc)) s += llp[b];
     }
+    sh_acc[chunk][col] = s;
+  }
+  __syncthreads();
+
+  // ordered combine (tree) and inclusive scan of the per-thread valid counts, 8 steps each
+  for (int stride = 1; stride < kFinSegThreads; stride <<= 1) {
+    SegRec merged;
+    int add = 0;
+    const bool do_merge = t < kFinSegThreads && (t % (2 * stride)) == 0;
+    if (do_merge) merged = seg_combine(sh_seg[t], sh_seg[t + stride]);
+    if (t < kFinSegThreads && t >= stride) add = sh_cnt[t - stride];
     __syncthreads();
-    for (int stride = 1; stride < 256; stride <<= 1) {
-      if (t < 256 && (t % (2 * stride)) == 0) sh_seg[t] = seg_combine(sh_seg[t], sh_seg[t + stride]);
-      __syncthreads();
-    }
-    if (t < kNumAcc) {
-      double s = 0.0;
-      for (int c = 0; c < kFinChunks; ++c) s += sh_acc[c][t];
-      out->acc[t] = s;
-    }
+    if (do_merge) sh_seg[t] = merged;
+    if (t < kFinSegThreads) sh_cnt[t] += add;
+    __syncthreads();
+  }
+
+  if (t < kNumAcc) {
+    double s = 0.0;
+    for (int c = 0; c < kFinChunks; ++c) s += sh_acc[c][t];
+    out->acc[t] = s;
+  }
+  if (t == kNumAcc) {
+    double s = 0.0;
+    for (int c = 0; c < kFinChunks; ++c)
+      for (int k = kNumAcc; k < kFinCols; ++k) s += sh_acc[c][k];
+    out->ll_sum = s;
+    out->has_ll = it.n_ll_blocks > 0 ? 1 : 0;
+  }
+  if (nb > 0) {
     const int V = sh_seg[0].c;
     if (t == 0) {
       out->valid = V;
       out->has_res = 1;
       for (int i = 0; i < 3; ++i) out->S[i] = sh_seg[0].s0[i];
     }
-    // (c) segment that holds global rank 50*floor(V/50)
-    {
-      const int nseg = nb * kWavesPerBlock;
-      const int per = (nseg + kFinThreads - 1) / kFinThreads;
-      const int cutoff = 50 * (V / 50);
-      int local = 0;
-      for (int s = t * per; s < (t + 1) * per && s < nseg; ++s)
-        local += (int)f2u(it.records[(size_t)(s >> 2) * kRecStride + kRecWaveCnt + (s & 3)]);
-      sh_scan[t] = local;
-      __syncthreads();
-      for (int off = 1; off < kFinThreads; off <<= 1) {
-        const int v = t >= off ? sh_scan[t - off] : 0;
-        __syncthreads();
-        sh_scan[t] += v;
-        __syncthreads();
-      }
-      int prefix = sh_scan[t] - local;  // exclusive
-      if (t == 0 && cutoff >= V) it.cut_out[0] = 0x7fffffff, it.cut_out[1] = 0;
-      if (cutoff < V) {
-        for (int s = t * per; s < (t + 1) * per && s < nseg; ++s) {
-          const int c = (int)f2u(it.records[(size_t)(s >> 2) * kRecStride + kRecWaveCnt + (s & 3)]);
-          if (prefix <= cutoff && cutoff < prefix + c) it.cut_out[0] = s, it.cut_out[1] = cutoff - prefix;
+    // wave segment that holds global rank 50*floor(V/50) (Q6 cut of the log-likelihood)
+    const int cutoff = 50 * (V / 50);
+    if (t == 0 && cutoff >= V) it.cut_out[0] = 0x7fffffff, it.cut_out[1] = 0;
+    if (t < kFinSegThreads && cutoff < V) {
+      int prefix = sh_cnt[t] - own_total;  // valid pixels before this thread's blocks
+#pragma unroll
+      for (int k = 0; k < kFinMaxOwn * kWavesPerBlock; ++k) {
+        const int b = t * per + (k >> 2);
+        if ((k >> 2) < per && b < nb) {
+          const int c = own_cnt[k];
+          if (prefix <= cutoff && cutoff < prefix + c) it.cut_out[0] = b * kWavesPerBlock + (k & 3), it.cut_out[1] = cutoff - prefix;
           prefix += c;
         }
       }
@@ -625,22 +735,6 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const FinArgs args) {
   } else if (t == 0) {
     out->has_res = 0;
     out->valid = 0;
-  }
-
-  // (d) log-likelihood partials
-  {
-    double s = 0.0;
-    for (int b = t; b < it.n_ll_blocks; b += kFinThreads) s += it.ll_partials[b];
-    sh_ll[t] = s;
-    __syncthreads();
-    for (int stride = kFinThreads / 2; stride > 0; stride >>= 1) {
-      if (t < stride) sh_ll[t] += sh_ll[t + stride];
-      __syncthreads();
-    }
-    if (t == 0) {
-      out->ll_sum = sh_ll[0];
-      out->has_ll = it.n_ll_blocks > 0 ? 1 : 0;
-    }
   }
   // publish: every thread's stores to the (host) record are ordered before the sequence word
   __threadfence_system();

@@ -296,7 +296,9 @@ struct JobSlot {
 struct dvo_amd_context {
   int device = 0;
   dvo_amd_config cfg;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;             // stream 0
+  std::vector<hipStream_t> extra_streams;   // further streams for the launches of one tick (batches > one launch)
+  hipEvent_t desc_ready = nullptr;
   std::vector<JobSlot> slots;
   int slot_n_pad = 0;  // capacity every slot was sized for
   FinOut *out_host = nullptr;
@@ -606,6 +608,7 @@ void process_loglik(Job &j, const FinOut *outs) {
 int ensure_slots(dvo_amd_context *ctx, int n_jobs, int n_pad) {
   if ((int)ctx->slots.size() >= n_jobs && ctx->slot_n_pad >= n_pad) return DVO_AMD_OK;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (hipStream_t st : ctx->extra_streams) HIP_TRY(hipStreamSynchronize(st));
   const int new_pad = std::max(n_pad, ctx->slot_n_pad);
   for (JobSlot &s : ctx->slots)
     if (s.dev_block) (void)hipFree(s.dev_block);
@@ -654,15 +657,13 @@ int ensure_slots(dvo_amd_context *ctx, int n_jobs, int n_pad) {
 }
 
 int pick_rounds(long long total_px) {
-  // A wave reduces its 93 partial sums once, whatever its share of pixels: more rounds per wave amortise that, fewer
-  // rounds give more waves to hide the gather latency.  Aim at >= 16 k waves per launch when the work allows.
+  // The Gram-matrix (MFMA) form has no per-wave reduction to amortise, so short segments (many waves) are best; two
+  // rounds per wave measured ~4 % better than one once the launch holds tens of thousands of waves.
   const long long waves1 = total_px / kSegPxPerRound;
-  int rounds = 1;
-  while (rounds < kMaxRounds && waves1 / (rounds * 2) >= 16384) rounds *= 2;
-  return rounds;
+  return waves1 >= 32768 ? 2 : 1;
 }
 
-int timing_begin(dvo_amd_context *ctx, size_t *slot) {
+int timing_begin(dvo_amd_context *ctx, hipStream_t stream, size_t *slot) {
   if (ctx->events_used == ctx->events.size()) {
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a));
@@ -670,7 +671,24 @@ int timing_begin(dvo_amd_context *ctx, size_t *slot) {
     ctx->events.emplace_back(a, b);
   }
   *slot = ctx->events_used++;
-  HIP_TRY(hipEventRecord(ctx->events[*slot].first, ctx->stream));
+  HIP_TRY(hipEventRecord(ctx->events[*slot].first, stream));
+  return DVO_AMD_OK;
+}
+
+constexpr int kMaxTickStreams = 4;
+
+int tick_stream(dvo_amd_context *ctx, size_t index, hipStream_t *out) {
+  index %= kMaxTickStreams;
+  if (index == 0) {
+    *out = ctx->stream;
+    return DVO_AMD_OK;
+  }
+  while (ctx->extra_streams.size() < index) {
+    hipStream_t s;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    ctx->extra_streams.push_back(s);
+  }
+  *out = ctx->extra_streams[index - 1];
   return DVO_AMD_OK;
 }
 
@@ -689,6 +707,7 @@ int timing_collect(dvo_amd_context *ctx) {
 int wait_tick(dvo_amd_context *ctx, const std::vector<Job> &jobs, unsigned seq) {
   if (!ctx->poll || ctx->timing) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (hipStream_t s : ctx->extra_streams) HIP_TRY(hipStreamSynchronize(s));
     return DVO_AMD_OK;
   }
   for (const Job &j : jobs) {
@@ -696,10 +715,17 @@ int wait_tick(dvo_amd_context *ctx, const std::vector<Job> &jobs, unsigned seq) 
     const volatile unsigned *p = &ctx->out_host[j.slot - ctx->slots.data()].seq;
     unsigned long long spins = 0;
     while (__atomic_load_n(p, __ATOMIC_ACQUIRE) != seq) {
-      if ((++spins & 0xFFFFF) == 0) {  // every ~1M polls make sure the stream is still alive
-        hipError_t e = hipStreamQuery(ctx->stream);
-        if (e != hipSuccess && e != hipErrorNotReady) return fail_hip("stream died while waiting for a tick", e);
-        if (e == hipSuccess && __atomic_load_n(p, __ATOMIC_ACQUIRE) != seq)
+      if ((++spins & 0xFFFFF) == 0) {  // every ~1M polls make sure the streams are still alive
+        bool all_idle = true;
+        for (size_t si = 0; si <= ctx->extra_streams.size(); ++si) {
+          hipError_t e = hipStreamQuery(si == 0 ? ctx->stream : ctx->extra_streams[si - 1]);
+          if (e == hipErrorNotReady) {
+            all_idle = false;
+          } else if (e != hipSuccess) {
+            return fail_hip("stream died while waiting for a tick", e);
+          }
+        }
+        if (all_idle && __atomic_load_n(p, __ATOMIC_ACQUIRE) != seq)
           return fail_hip("tick finished without publishing its record", hipErrorUnknown);
       }
     }
@@ -741,7 +767,8 @@ int run_tick(dvo_amd_context *ctx, std::vector<Job> &jobs) {
     }
     if (j.have_b) {
       j.b.rounds = rounds_now;
-      j.b.n_blocks = blocks_for(j.ref->lv[j.level].n, rounds_now);
+      while (j.b.rounds < kMaxRounds && blocks_for(j.ref->lv[j.level].n, j.b.rounds) > 2048) j.b.rounds *= 2;
+      j.b.n_blocks = blocks_for(j.ref->lv[j.level].n, j.b.rounds);
       w.res_blocks = j.b.n_blocks;
       w.res_rounds = j.b.rounds;
       w.res_buf = j.b.buf;
@@ -762,33 +789,38 @@ int run_tick(dvo_amd_context *ctx, std::vector<Job> &jobs) {
   }
   if (items.empty()) return DVO_AMD_OK;
 
-  // split evenly over as few launches as the argument block allows
+  // split evenly over as few launches as the argument block allows; launch i (and the finalize of its jobs) goes to stream
+  // i so that the launches of one tick overlap instead of queueing behind each other's latency floor
   const size_t n_launch = (items.size() + kMaxItemsPerLaunch - 1) / kMaxItemsPerLaunch;
   const size_t per = (items.size() + n_launch - 1) / n_launch;
-  for (size_t first = 0; first < items.size(); first += per) {
+  size_t launch_index = 0;
+  for (size_t first = 0; first < items.size(); first += per, ++launch_index) {
+    hipStream_t st;
+    {
+      int rc = tick_stream(ctx, ctx->timing ? 0 : launch_index, &st);  // timed launches run alone, on stream 0
+      if (rc) return rc;
+    }
     TickArgs ta;
+    FinArgs fa;
     ta.n_items = (int)std::min(per, items.size() - first);
     ta.pad = 0;
+    fa.n_items = ta.n_items;
+    fa.pad = 0;
     int max_blocks = 0;
     for (int i = 0; i < ta.n_items; ++i) {
       ta.items[i] = items[first + i];
+      fa.items[i] = fin_items[first + i];
       max_blocks = std::max(max_blocks, ta.items[i].res_blocks + ta.items[i].ll_blocks);
     }
     size_t ev = 0;
     if (ctx->timing) {
-      int rc = timing_begin(ctx, &ev);
+      int rc = timing_begin(ctx, st, &ev);
       if (rc) return rc;
     }
-    hipError_t e = launch_tick(ta, max_blocks, ctx->stream);
+    hipError_t e = launch_tick(ta, max_blocks, st);
     if (e != hipSuccess) return fail_hip("launch_tick", e);
-    if (ctx->timing) HIP_TRY(hipEventRecord(ctx->events[ev].second, ctx->stream));
-  }
-  for (size_t first = 0; first < fin_items.size(); first += kMaxFinItems) {
-    FinArgs fa;
-    fa.n_items = (int)std::min<size_t>(kMaxFinItems, fin_items.size() - first);
-    fa.pad = 0;
-    for (int i = 0; i < fa.n_items; ++i) fa.items[i] = fin_items[first + i];
-    hipError_t e = launch_finalize(fa, ctx->stream);
+    if (ctx->timing) HIP_TRY(hipEventRecord(ctx->events[ev].second, st));
+    e = launch_finalize(fa, st);
     if (e != hipSuccess) return fail_hip("launch_finalize", e);
   }
   {
@@ -898,6 +930,11 @@ void dvo_amd_context_destroy(dvo_amd_context *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (hipStream_t st : ctx->extra_streams) {
+    (void)hipStreamSynchronize(st);
+    (void)hipStreamDestroy(st);
+  }
+  if (ctx->desc_ready) (void)hipEventDestroy(ctx->desc_ready);
   for (JobSlot &s : ctx->slots)
     if (s.dev_block) (void)hipFree(s.dev_block);
   if (ctx->out_host) (void)hipHostFree(ctx->out_host);
@@ -1065,6 +1102,17 @@ int dvo_amd_match_batch(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *ref
   }
   HIP_TRY(hipMemcpyAsync(ctx->desc_dev, ctx->desc_host, sizeof(LevelPairDesc) * DVO_AMD_MAX_LEVELS * (size_t)n,
                          hipMemcpyHostToDevice, ctx->stream));
+  if (n > kMaxItemsPerLaunch) {
+    if (!ctx->desc_ready) HIP_TRY(hipEventCreateWithFlags(&ctx->desc_ready, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ctx->desc_ready, ctx->stream));
+    const size_t n_launch = ((size_t)n + kMaxItemsPerLaunch - 1) / kMaxItemsPerLaunch;
+    for (size_t i = 1; i < n_launch && i < (size_t)kMaxTickStreams; ++i) {
+      hipStream_t st;
+      rc = tick_stream(ctx, i, &st);
+      if (rc) return rc;
+      HIP_TRY(hipStreamWaitEvent(st, ctx->desc_ready, 0));
+    }
+  }
   for (;;) {
     bool any = false;
     for (const Job &j : jobs) any = any || !j.done;
@@ -1105,7 +1153,8 @@ int dvo_amd_residuals(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_
   TickItem &w = ta.items[0];
   w.desc = ctx->desc_dev + level;
   w.res_rounds = 1;
-  w.res_blocks = blocks_for(R.n, 1);
+  while (w.res_rounds < kMaxRounds && blocks_for(R.n, w.res_rounds) > 2048) w.res_rounds *= 2;
+  w.res_blocks = blocks_for(R.n, w.res_rounds);
   w.unit_weights = 1;
   w.res_buf = 0;
   const float K[9] = {C.fx, 0.0f, C.ox, 0.0f, C.fy, C.oy, 0.0f, 0.0f, 1.0f};
@@ -1147,6 +1196,71 @@ int dvo_amd_error_image(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_am
     const float r0 = res[(size_t)2 * i];
     image[i] = (r0 == r0) ? std::fabs(r0) : 0.0f;  // :426-438
   }
+  return DVO_AMD_OK;
+}
+
+int dvo_amd_bench_residual_pass(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, int level,
+                                const float *T, int n_items, int rounds, int reps, double *avg_ms, double *alg_bytes,
+                                int *n_launches) {
+  if (!ctx || !reference || !current || !T || level < 0 || n_items < 1 || n_items > 1024 || reps < 1)
+    return DVO_AMD_ERR_INVALID_ARGUMENT;
+  if (level >= reference->n_levels || level >= current->n_levels) return DVO_AMD_ERR_TOO_FEW_LEVELS;
+  if (reference->device != ctx->device || current->device != ctx->device) return DVO_AMD_ERR_DEVICE_MISMATCH;
+  const LevelData &R = reference->lv[level];
+  const LevelData &C = current->lv[level];
+  if (R.w != C.w || R.h != C.h) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(ctx->device));
+  int sel = 0;
+  int rc = pyramid_selection(reference, ctx->cfg.intensity_derivative_threshold, ctx->cfg.depth_derivative_threshold, &sel);
+  if (rc) return rc;
+  rc = ensure_slots(ctx, n_items, R.n_pad);
+  if (rc) return rc;
+  if (rounds <= 0) rounds = pick_rounds((long long)R.n * n_items);
+  if (rounds != 1 && rounds != 2 && rounds != 4 && rounds != 8 && rounds != 16) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  while (rounds < kMaxRounds && blocks_for(R.n, rounds) > 2048) rounds *= 2;
+  for (int i = 0; i < n_items; ++i) fill_desc(ctx->desc_host[(size_t)i * DVO_AMD_MAX_LEVELS + level], reference, sel, current, level, ctx->slots[(size_t)i]);
+  HIP_TRY(hipMemcpyAsync(ctx->desc_dev, ctx->desc_host, sizeof(LevelPairDesc) * DVO_AMD_MAX_LEVELS * (size_t)n_items,
+                         hipMemcpyHostToDevice, ctx->stream));
+  TickItem proto;
+  std::memset(&proto, 0, sizeof(proto));
+  proto.res_rounds = rounds;
+  proto.res_blocks = blocks_for(R.n, rounds);
+  proto.unit_weights = 0;
+  proto.P_res[0] = 1500.0f, proto.P_res[3] = 7000.0f;  // a typical precision: the weights take the non-trivial branch
+  const float K[9] = {C.fx, 0.0f, C.ox, 0.0f, C.fy, C.oy, 0.0f, 0.0f, 1.0f};
+  for (int i = 0; i < 3; ++i)
+    for (int cc = 0; cc < 4; ++cc)
+      proto.kt[i * 4 + cc] = (K[i * 3 + 0] * T[cc * 4 + 0] + K[i * 3 + 1] * T[cc * 4 + 1]) + K[i * 3 + 2] * T[cc * 4 + 2];
+  const int launches = (n_items + kMaxItemsPerLaunch - 1) / kMaxItemsPerLaunch;
+  const int per = (n_items + launches - 1) / launches;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  double total_ms = 0.0;
+  for (int rep = -1; rep < reps; ++rep) {  // rep -1 warms up
+    HIP_TRY(hipEventRecord(e0, ctx->stream));
+    for (int first = 0; first < n_items; first += per) {
+      TickArgs ta;
+      ta.n_items = std::min(per, n_items - first);
+      ta.pad = 0;
+      for (int i = 0; i < ta.n_items; ++i) {
+        ta.items[i] = proto;
+        ta.items[i].desc = ctx->desc_dev + (size_t)(first + i) * DVO_AMD_MAX_LEVELS + level;
+      }
+      hipError_t e = launch_tick(ta, proto.res_blocks, ctx->stream);
+      if (e != hipSuccess) return fail_hip("launch_tick", e);
+    }
+    HIP_TRY(hipEventRecord(e1, ctx->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (rep >= 0) total_ms += ms;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (avg_ms) *avg_ms = total_ms / reps;
+  if (alg_bytes) *alg_bytes = 56.0 * (double)reference->selections[sel].count[level] * n_items;
+  if (n_launches) *n_launches = launches;
   return DVO_AMD_OK;
 }
 

@@ -169,6 +169,15 @@ int dvo_amd_residuals(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_
 int dvo_amd_error_image(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, const double *T,
                         int level, float *image);
 
+/* Micro-benchmark of the dominant kernel alone (used by bench.py for the roofline figure and by the tuning scripts):
+ * `reps` timed repetitions of the fused residual pass over `n_items` copies of one (reference level, current level) pair
+ * at the float transform T (column-major 4x4), `rounds` rounds per wave (1, 2, 4, 8 or 16; 0 = the driver's choice).
+ * avg_ms: HIP-event time per repetition on the context's stream; alg_bytes: 56 B x selected points x n_items;
+ * n_launches: kernel launches one repetition needs (the argument block holds 30 items). */
+int dvo_amd_bench_residual_pass(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, int level,
+                                const float *T, int n_items, int rounds, int reps, double *avg_ms, double *alg_bytes,
+                                int *n_launches);
+
 /* Host-side helpers (no GPU needed): the SE(3) exponential / logarithm with Sophus' tangent order (upsilon, omega) and the
  * pivoted LDL^T 6x6 solve the driver uses in place of Sophus::SE3d::exp/log and Eigen::LDLT (dense_tracking.cpp:238,259,347).
  * Exported so that bindings do not need Sophus to build a T_init or to compare poses. */
