@@ -30,13 +30,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="frame pairs aligned per step per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="frame pairs aligned per step per GPU")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--distinct", type=int, default=8, help="distinct current frames cycled through the batch")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--threads", type=int, default=1,
+    ap.add_argument("--in-flight", type=int, default=27,
+                    help="pairs resident per tracker at a time (0 = the whole share in lock step)")
+    ap.add_argument("--threads", type=int, default=4,
                     help="host threads per GPU, each with its own tracker (HIP stream) and an equal share of the batch")
     return ap.parse_args()
 
@@ -93,7 +95,7 @@ def main():
             idx = shares[t]
             r, c = [refs[i] for i in idx], [curb[i] for i in idx]
             for _ in range(n_steps):
-                out = trackers[t].match_batch(r, c, stats=False)
+                out = trackers[t].match_batch(r, c, stats=False, in_flight=args.in_flight)
                 collect.append((sum(o.alg_bytes for o in out), sum(o.n_residual_passes for o in out)))
         if T == 1:
             worker(0)
@@ -168,10 +170,13 @@ def main():
             "config": {
                 "workload": f"synthetic {W}x{H} RGB-D pairs (analytic room corner, seed 20131103), {levels}-level "
                             f"coarse-to-fine Gauss-Newton (FirstLevel {first_level} -> LastLevel 0, MaxIter 100, "
-                            f"Precision 5e-7, Mu 0), {B} independent pairs per step per GPU advanced in lock step, "
-                            f"pyramids pre-built and resident in HBM",
+                            f"Precision 5e-7, Mu 0), {B} independent pairs per step per GPU ({args.distinct} distinct current "
+                            f"frames against one keyframe), worked through by {T} host threads (one tracker / HIP stream "
+                            f"each) with at most {args.in_flight or 'all'} pairs resident per tracker, pyramids pre-built "
+                            f"and resident in HBM",
                 "pairs_per_step_per_gpu": B,
                 "host_threads_per_gpu": T,
+                "pairs_in_flight_per_tracker": args.in_flight,
                 "sharding": "independent pairs per rank, no collective on the data path",
             },
             "single_pair_latency_ms": single_ms,
@@ -192,6 +197,14 @@ def main():
                 "residual_passes": int(passes),
             },
         }
+        try:
+            ms_i, ab_i, nl_i = trk.bench_residual_pass(ref, curs[0], 0, synth.se3_exp(synth.XI_GT_PAIR * 0.6), 27, 0, reps=20)
+            line["roofline_isolated_kernel"] = {
+                "what": "the residual pass alone: level 0, 27 pairs in one launch (one launch's worth of resident pairs)",
+                "achieved": ab_i / ms_i / 1e6, "unit": "GB/s", "frac": ab_i / ms_i / 1e6 / HBM_PEAK_GBS,
+                "launch_us": ms_i * 1e3 / nl_i, "alg_bytes_per_launch": ab_i / nl_i}
+        except Exception as exc:  # pragma: no cover
+            line["roofline_isolated_kernel"] = {"error": str(exc)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, ref_frame, cur_frames, K, levels, first_level)
         print(json.dumps(line), flush=True)

@@ -26,7 +26,8 @@ EXPORTS = [
     "dvo_amd_pyramid_release", "dvo_amd_pyramid_levels", "dvo_amd_pyramid_timestamp", "dvo_amd_pyramid_level_info",
     "dvo_amd_pyramid_download_plane", "dvo_amd_pyramid_select", "dvo_amd_match", "dvo_amd_match_batch",
     "dvo_amd_residuals", "dvo_amd_error_image", "dvo_amd_kernel_timing", "dvo_amd_se3_exp", "dvo_amd_se3_log",
-    "dvo_amd_solve6", "dvo_amd_bench_residual_pass",
+    "dvo_amd_solve6", "dvo_amd_bench_residual_pass", "dvo_amd_match_many",
+    "dvo_amd_debug_finalize_stamps",
 ]
 
 
@@ -117,11 +118,13 @@ def lib():
     L.dvo_amd_pyramid_select.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_ubyte)]
     L.dvo_amd_match.argtypes = [vp, vp, vp, dp, C.POINTER(CResult)]
     L.dvo_amd_match_batch.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), dp, C.POINTER(CResult)]
+    L.dvo_amd_match_many.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), dp, C.POINTER(CResult), C.c_int]
     L.dvo_amd_residuals.argtypes = [vp, vp, vp, C.c_int, fp, fp, C.POINTER(C.c_int)]
     L.dvo_amd_error_image.argtypes = [vp, vp, vp, dp, C.c_int, fp]
     L.dvo_amd_kernel_timing.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_longlong), C.c_int]
     L.dvo_amd_bench_residual_pass.argtypes = [vp, vp, vp, C.c_int, fp, C.c_int, C.c_int, C.c_int, dp, dp,
                                               C.POINTER(C.c_int)]
+    L.dvo_amd_debug_finalize_stamps.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     L.dvo_amd_se3_exp.argtypes = [dp, dp]
     L.dvo_amd_se3_exp.restype = None
     L.dvo_amd_se3_log.argtypes = [dp, dp]
@@ -312,8 +315,9 @@ class DenseTracker:
         _check(lib().dvo_amd_match(self._h, reference._h, current._h, T0, C.byref(res[0])), "dvo_amd_match")
         return Result(res[0], its[0])
 
-    def match_batch(self, references, currents, T_inits=None, stats: bool = True):
-        """n independent match() calls advanced in lock step on this tracker's GPU."""
+    def match_batch(self, references, currents, T_inits=None, stats: bool = True, in_flight: int = 0):
+        """n independent match() calls on this tracker's GPU.  in_flight = 0: all advanced in lock step; otherwise at most
+        in_flight pairs are resident and a finished pair hands its slot to the next one."""
         n = len(references)
         assert len(currents) == n
         if stats:
@@ -326,7 +330,7 @@ class DenseTracker:
         if T_inits is not None:
             T0a = np.ascontiguousarray(np.stack([np.asarray(T, dtype=np.float64).T for T in T_inits]))
             T0 = T0a.ctypes.data_as(C.POINTER(C.c_double))
-        _check(lib().dvo_amd_match_batch(self._h, n, refs, curs, T0, res), "dvo_amd_match_batch")
+        _check(lib().dvo_amd_match_many(self._h, n, refs, curs, T0, res, in_flight), "dvo_amd_match_many")
         if not stats:
             return [Result(res[i], None) for i in range(n)]
         return [Result(res[i], its[i]) for i in range(n)]

@@ -103,6 +103,19 @@ typedef const DVO_GLOBAL float *gcf;
 typedef const DVO_GLOBAL v4f *gcf4;
 
 
+// what a block needs of the three descriptors, in registers
+struct LevelPairDesc {
+  const float *r_zsel, *r_i, *r_ix, *r_iy, *tx, *ty;
+  const float4 *c_a;
+  const float2 *c_b;
+  float2 *res[2];
+  float *records;
+  double *ll_partials;
+  int *cut[2];
+  int w, h;
+  float wc[6], wr[4], ub_x, ub_y;
+};
+
 // ------------------------------------------------------------------------------------------------------------------
 // residual pass
 // ------------------------------------------------------------------------------------------------------------------
@@ -535,21 +548,27 @@ __device__ void loglik_pass(const TickItem &it, const LevelPairDesc &d, const in
   if (threadIdx.x == 0) ((DVO_GLOBAL double *)d.ll_partials)[lb] = (smd[0] + smd[1]) + (smd[2] + smd[3]);
 }
 
-__device__ __forceinline__ LevelPairDesc load_desc(const LevelPairDesc *p) {
-  const __attribute__((address_space(4))) LevelPairDesc *c = (const __attribute__((address_space(4))) LevelPairDesc *)p;
+// Copy the descriptors into registers once, through the constant address space (scalar loads).  Read through plain global
+// references their fields would be re-loaded with vector loads + s_waitcnt vmcnt(0) at every use inside the pixel loop,
+// because the residual stores might alias them: ten dependent L2 round trips per 64 pixels.
+#define DVO_CONST __attribute__((address_space(4)))
+__device__ __forceinline__ LevelPairDesc load_desc(const TickItem &it) {
+  const DVO_CONST RefLevelDesc *r = (const DVO_CONST RefLevelDesc *)it.ref;
+  const DVO_CONST CurLevelDesc *c = (const DVO_CONST CurLevelDesc *)it.cur;
+  const DVO_CONST SlotDesc *s = (const DVO_CONST SlotDesc *)it.slot;
   LevelPairDesc d;
-  d.r_zsel = c->r_zsel, d.r_i = c->r_i, d.r_ix = c->r_ix, d.r_iy = c->r_iy;
-  d.tx = c->tx, d.ty = c->ty;
+  d.r_zsel = r->r_zsel, d.r_i = r->r_i, d.r_ix = r->r_ix, d.r_iy = r->r_iy;
+  d.tx = r->tx, d.ty = r->ty;
   d.c_a = c->c_a, d.c_b = c->c_b;
-  d.res[0] = c->res[0], d.res[1] = c->res[1];
-  d.records = c->records, d.ll_partials = c->ll_partials;
-  d.cut[0] = c->cut[0], d.cut[1] = c->cut[1];
   d.w = c->w, d.h = c->h;
 #pragma unroll
   for (int i = 0; i < 6; ++i) d.wc[i] = c->wc[i];
 #pragma unroll
   for (int i = 0; i < 4; ++i) d.wr[i] = c->wr[i];
   d.ub_x = c->ub_x, d.ub_y = c->ub_y;
+  d.res[0] = s->res[0], d.res[1] = s->res[1];
+  d.records = s->records, d.ll_partials = s->ll_partials;
+  d.cut[0] = s->cut[0], d.cut[1] = s->cut[1];
   return d;
 }
 
@@ -558,10 +577,7 @@ __global__ __launch_bounds__(kBlockThreads, ACC == 1 ? 4 : 2) void k_tick(const 
   const TickItem &it = args.items[blockIdx.y];
   const int bx = (int)blockIdx.x;
   if (bx >= it.res_blocks + it.ll_blocks) return;
-  // Copy the level descriptor into registers once, through the constant address space (scalar loads).  Read through a
-  // plain global reference its fields are re-loaded with vector loads + s_waitcnt vmcnt(0) at every use inside the
-  // pixel loop, because the residual stores might alias them: ten dependent L2 round trips per 64 pixels.
-  const LevelPairDesc d = load_desc(it.desc);
+  const LevelPairDesc d = load_desc(it);
   if (bx < it.res_blocks)
     residual_pass<RMODE, ACC>(it, d, xcd_contiguous_block(bx, it.res_blocks));
   else
@@ -600,10 +616,11 @@ hipError_t launch_tick(const TickArgs &args, int max_blocks, hipStream_t stream)
 // cut, sums the log-likelihood partials.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kFinThreads = 1024;
-constexpr int kFinSegThreads = 256;                       // threads [0,256): ordered part of the records
-constexpr int kFinCols = 96;                              // threads [256,1024): 8 row-chunks x 96 columns
-constexpr int kFinChunks = (kFinThreads - kFinSegThreads) / kFinCols;
-constexpr int kFinMaxOwn = 8;                             // blocks one "seg" thread folds (covers 2048 blocks)
+constexpr int kFinSegThreads = 64;    // wave 0: the ordered part of the records (no block barriers inside)
+constexpr int kFinAccFirst = 256;     // threads [256,1024): 32 row-chunks x 24 groups of 4 columns
+constexpr int kFinCols = 96;
+constexpr int kFinCol4 = kFinCols / 4;
+constexpr int kFinChunks = (kFinThreads - kFinAccFirst) / kFinCol4;
 
 struct SegRec {
   int c;
@@ -631,115 +648,160 @@ __device__ __forceinline__ SegRec seg_combine(const SegRec &a, const SegRec &b) 
   return o;
 }
 
-// All global loads are issued in one phase, by role; then 8 tree/scan steps and the output.
+// Diagnostic only (DVO_AMD_FIN_STAMPS=1): shader-clock stamps of the phases of block 0, read back by
+// dvo_amd_debug_finalize_stamps().  Never read by any kernel; no output depends on them.
+__device__ unsigned long long g_fin_stamps[8];
+#define DVO_FIN_STAMP(i)                                                                  \
+  do {                                                                                    \
+    if (args.pad == 0x57A3 && blockIdx.x == 0 && threadIdx.x == 0) g_fin_stamps[i] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+
+// wave-local LDS hand-off: the LDS queue of a wave is in order, the fences only pin the compiler
+#define DVO_WAVE_LDS_SYNC()                                 \
+  do {                                                      \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  \
+    __builtin_amdgcn_wave_barrier();                        \
+  } while (0)
+
+// One block per job.  Wave 0 folds the ordered part of the block records (count, S under both start parities, boundary
+// residual / weight) left to right and locates the log-likelihood cut; threads 256.. sum the 87 moments and the
+// log-likelihood partials in fp64 with 16-byte loads, four in flight per thread.  Two block barriers in all; the record is
+// assembled in LDS and pushed to the pinned host buffer by wave 0 with one system-scope fence in front of the sequence word.
 __global__ __launch_bounds__(kFinThreads) void k_finalize(const FinArgs args) {
   const FinItem &it = args.items[blockIdx.x];
   const int t = threadIdx.x;
-  FinOut *out = it.out;
   __shared__ double sh_acc[kFinChunks][kFinCols];
   __shared__ SegRec sh_seg[kFinSegThreads];
   __shared__ int sh_cnt[kFinSegThreads];
+  __shared__ __attribute__((aligned(16))) FinOut sh_out;
 
+  DVO_FIN_STAMP(0);
   const gcf recs = (gcf)it.records;
   const int nb = it.records ? it.n_blocks : 0;
-  const int per = (nb + kFinSegThreads - 1) / kFinSegThreads;  // <= kFinMaxOwn by construction of the grid
-  int own_cnt[kFinMaxOwn * kWavesPerBlock];
-  int own_total = 0;
+  const int per = (nb + kFinSegThreads - 1) / kFinSegThreads;
   if (t < kFinSegThreads) {
     SegRec r;
     r.c = 0, r.first_w = 0.0f, r.l0 = r.l1 = 0.0f;
     for (int i = 0; i < 3; ++i) r.s0[i] = r.s1[i] = 0.0;
-#pragma unroll
-    for (int k = 0; k < kFinMaxOwn; ++k) {
-      const int b = t * per + k;
-      const bool live = k < per && b < nb;
-      v4f h0 = {0.0f, 0.0f, 0.0f, 0.0f}, h1 = h0, h2 = h0, h3 = h0;
-      if (live) {
-        const gcf4 hp = reinterpret_cast<gcf4>(recs + (size_t)b * kRecStride);
-        h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3];
-      }
+    for (int b = t * per; b < (t + 1) * per && b < nb; ++b) {
+      const gcf4 hp = reinterpret_cast<gcf4>(recs + (size_t)b * kRecStride);
+      const v4f h0 = hp[0], h1 = hp[1], h2 = hp[2];
       SegRec q;
       q.c = (int)f2u(h0.x);
       q.first_w = h0.y, q.l0 = h0.z, q.l1 = h0.w;
       q.s0[0] = h1.x, q.s0[1] = h1.y, q.s0[2] = h1.z;
       q.s1[0] = h1.w, q.s1[1] = h2.x, q.s1[2] = h2.y;
-      own_cnt[4 * k + 0] = (int)f2u(h2.z), own_cnt[4 * k + 1] = (int)f2u(h2.w);
-      own_cnt[4 * k + 2] = (int)f2u(h3.x), own_cnt[4 * k + 3] = (int)f2u(h3.y);
-      if (live) r = seg_combine(r, q);
+      r = seg_combine(r, q);
     }
+    const int own_total = r.c;
     sh_seg[t] = r;
     sh_cnt[t] = r.c;
-    own_total = r.c;
-  } else {
-    const int col = (t - kFinSegThreads) % kFinCols, chunk = (t - kFinSegThreads) / kFinCols;
-    double s = 0.0;
-    if (col < kNumAcc) {
-      for (int b = chunk; b < nb; b += kFinChunks) s += (double)recs[(size_t)b * kRecStride + kRecAcc + col];
-    } else {
-      // the 9 spare columns x 8 chunks sum the log-likelihood partials
-      const int lane72 = chunk * (kFinCols - kNumAcc) + (col - kNumAcc);
-      const DVO_GLOBAL double *llp = (const DVO_GLOBAL double *)it.ll_partials;
-      for (int b = lane72; b < it.n_ll_blocks; b += kFinChunks * (kFinCols - kNumAcc)) s += llp[b];
+    DVO_WAVE_LDS_SYNC();
+    // ordered combine (tree) and inclusive scan of the per-lane valid counts, 6 wave-local steps
+    for (int stride = 1; stride < kFinSegThreads; stride <<= 1) {
+      SegRec merged;
+      int add = 0;
+      const bool do_merge = (t % (2 * stride)) == 0;
+      if (do_merge) merged = seg_combine(sh_seg[t], sh_seg[t + stride]);
+      if (t >= stride) add = sh_cnt[t - stride];
+      DVO_WAVE_LDS_SYNC();
+      if (do_merge) sh_seg[t] = merged;
+      sh_cnt[t] += add;
+      DVO_WAVE_LDS_SYNC();
     }
-    sh_acc[chunk][col] = s;
-  }
-  __syncthreads();
-
-  // ordered combine (tree) and inclusive scan of the per-thread valid counts, 8 steps each
-  for (int stride = 1; stride < kFinSegThreads; stride <<= 1) {
-    SegRec merged;
-    int add = 0;
-    const bool do_merge = t < kFinSegThreads && (t % (2 * stride)) == 0;
-    if (do_merge) merged = seg_combine(sh_seg[t], sh_seg[t + stride]);
-    if (t < kFinSegThreads && t >= stride) add = sh_cnt[t - stride];
-    __syncthreads();
-    if (do_merge) sh_seg[t] = merged;
-    if (t < kFinSegThreads) sh_cnt[t] += add;
-    __syncthreads();
-  }
-
-  if (t < kNumAcc) {
-    double s = 0.0;
-    for (int c = 0; c < kFinChunks; ++c) s += sh_acc[c][t];
-    out->acc[t] = s;
-  }
-  if (t == kNumAcc) {
-    double s = 0.0;
-    for (int c = 0; c < kFinChunks; ++c)
-      for (int k = kNumAcc; k < kFinCols; ++k) s += sh_acc[c][k];
-    out->ll_sum = s;
-    out->has_ll = it.n_ll_blocks > 0 ? 1 : 0;
-  }
-  if (nb > 0) {
-    const int V = sh_seg[0].c;
-    if (t == 0) {
-      out->valid = V;
-      out->has_res = 1;
-      for (int i = 0; i < 3; ++i) out->S[i] = sh_seg[0].s0[i];
-    }
-    // wave segment that holds global rank 50*floor(V/50) (Q6 cut of the log-likelihood)
-    const int cutoff = 50 * (V / 50);
-    if (t == 0 && cutoff >= V) it.cut_out[0] = 0x7fffffff, it.cut_out[1] = 0;
-    if (t < kFinSegThreads && cutoff < V) {
-      int prefix = sh_cnt[t] - own_total;  // valid pixels before this thread's blocks
-#pragma unroll
-      for (int k = 0; k < kFinMaxOwn * kWavesPerBlock; ++k) {
-        const int b = t * per + (k >> 2);
-        if ((k >> 2) < per && b < nb) {
-          const int c = own_cnt[k];
-          if (prefix <= cutoff && cutoff < prefix + c) it.cut_out[0] = b * kWavesPerBlock + (k & 3), it.cut_out[1] = cutoff - prefix;
-          prefix += c;
+    if (nb > 0) {
+      const int V = sh_seg[0].c;
+      if (t == 0) {
+        sh_out.valid = V;
+        sh_out.has_res = 1;
+        for (int i = 0; i < 3; ++i) sh_out.S[i] = sh_seg[0].s0[i];
+      }
+      // wave segment that holds global rank 50*floor(V/50) (Q6 cut of the log-likelihood)
+      const int cutoff = 50 * (V / 50);
+      if (t == 0 && cutoff >= V) it.cut_out[0] = 0x7fffffff, it.cut_out[1] = 0;
+      int prefix = sh_cnt[t] - own_total;  // valid pixels before this lane's blocks
+      if (cutoff < V && prefix <= cutoff && cutoff < prefix + own_total) {
+        for (int b = t * per; b < (t + 1) * per && b < nb; ++b) {
+          const v4f h2 = reinterpret_cast<gcf4>(recs + (size_t)b * kRecStride)[2];
+          const v4f h3 = reinterpret_cast<gcf4>(recs + (size_t)b * kRecStride)[3];
+          const int cw[4] = {(int)f2u(h2.z), (int)f2u(h2.w), (int)f2u(h3.x), (int)f2u(h3.y)};
+          for (int k = 0; k < 4; ++k) {
+            if (prefix <= cutoff && cutoff < prefix + cw[k]) it.cut_out[0] = b * kWavesPerBlock + k, it.cut_out[1] = cutoff - prefix;
+            prefix += cw[k];
+          }
         }
       }
+    } else if (t == 0) {
+      sh_out.valid = 0;
+      sh_out.has_res = 0;
+      for (int i = 0; i < 3; ++i) sh_out.S[i] = 0.0;
     }
-  } else if (t == 0) {
-    out->has_res = 0;
-    out->valid = 0;
+  } else if (t >= kFinAccFirst) {
+    // moments: 16-byte loads (4 columns), rows strided by the 32 chunks, four independent loads in flight per thread
+    const int c4 = (t - kFinAccFirst) % kFinCol4, chunk = (t - kFinAccFirst) / kFinCol4;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (c4 * 4 < kNumAcc) {
+      const gcf base = recs + kRecAcc + c4 * 4;
+      int b = chunk;
+      for (; b + 3 * kFinChunks < nb; b += 4 * kFinChunks) {
+        const v4f r0 = *reinterpret_cast<gcf4>(base + (size_t)b * kRecStride);
+        const v4f r1 = *reinterpret_cast<gcf4>(base + (size_t)(b + kFinChunks) * kRecStride);
+        const v4f r2 = *reinterpret_cast<gcf4>(base + (size_t)(b + 2 * kFinChunks) * kRecStride);
+        const v4f r3 = *reinterpret_cast<gcf4>(base + (size_t)(b + 3 * kFinChunks) * kRecStride);
+        s0 += ((double)r0.x + (double)r1.x) + ((double)r2.x + (double)r3.x);
+        s1 += ((double)r0.y + (double)r1.y) + ((double)r2.y + (double)r3.y);
+        s2 += ((double)r0.z + (double)r1.z) + ((double)r2.z + (double)r3.z);
+        s3 += ((double)r0.w + (double)r1.w) + ((double)r2.w + (double)r3.w);
+      }
+      for (; b < nb; b += kFinChunks) {
+        const v4f r0 = *reinterpret_cast<gcf4>(base + (size_t)b * kRecStride);
+        s0 += (double)r0.x, s1 += (double)r0.y, s2 += (double)r0.z, s3 += (double)r0.w;
+      }
+    } else {
+      // the two spare column groups x 32 chunks sum the log-likelihood partials
+      const int lane64 = chunk * 2 + (c4 - (kNumAcc + 3) / 4);
+      const DVO_GLOBAL double *llp = (const DVO_GLOBAL double *)it.ll_partials;
+      for (int b = lane64; b < it.n_ll_blocks; b += kFinChunks * 2) s0 += llp[b];
+    }
+    sh_acc[chunk][c4 * 4 + 0] = s0, sh_acc[chunk][c4 * 4 + 1] = s1;
+    sh_acc[chunk][c4 * 4 + 2] = s2, sh_acc[chunk][c4 * 4 + 3] = s3;
   }
-  // publish: every thread's stores to the (host) record are ordered before the sequence word
-  __threadfence_system();
   __syncthreads();
-  if (t == 0) __hip_atomic_store(&out->seq, it.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  DVO_FIN_STAMP(1);
+
+  if (t >= kFinAccFirst && t < kFinAccFirst + kNumAcc) {
+    const int col = t - kFinAccFirst;
+    double s = 0.0;
+    for (int c = 0; c < kFinChunks; ++c) s += sh_acc[c][col];
+    sh_out.acc[col] = s;
+  }
+  if (t == kFinAccFirst + kNumAcc) {
+    double s = 0.0;
+    for (int c = 0; c < kFinChunks; ++c) s += sh_acc[c][88] + sh_acc[c][92];  // first lanes of the two spare groups
+    sh_out.ll_sum = s;
+    sh_out.has_ll = it.n_ll_blocks > 0 ? 1 : 0;
+  }
+  __syncthreads();
+  DVO_FIN_STAMP(2);
+
+  // ---- publish: wave 0 copies the record to the pinned host buffer, one system-scope fence, then the sequence word
+  if (t < 64) {
+    constexpr int kPieces = (int)(sizeof(FinOut) / 16);
+    static_assert(kPieces <= 64, "one wave copies the record");
+    const v4f *src = reinterpret_cast<const v4f *>(&sh_out);
+    v4f *dst = reinterpret_cast<v4f *>(it.out);
+    if (t >= 1 && t < kPieces) dst[t] = src[t];
+    if (t == 0) it.out->valid = sh_out.valid, it.out->has_res = sh_out.has_res, it.out->has_ll = sh_out.has_ll;
+    DVO_FIN_STAMP(3);
+    __threadfence_system();
+    DVO_FIN_STAMP(4);
+    if (t == 0) __hip_atomic_store(&it.out->seq, it.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    DVO_FIN_STAMP(5);
+  }
+}
+
+hipError_t read_finalize_stamps(unsigned long long out[8]) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fin_stamps), sizeof(unsigned long long) * 8);
 }
 
 hipError_t launch_finalize(const FinArgs &args, hipStream_t stream) {

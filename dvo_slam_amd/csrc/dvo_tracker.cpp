@@ -97,6 +97,7 @@ struct Selection {
   float *zsel[DVO_AMD_MAX_LEVELS];
   int count[DVO_AMD_MAX_LEVELS];  // PointSelection size (includes an odd trailing point)
   int last[DVO_AMD_MAX_LEVELS];   // index of the last selected pixel
+  RefLevelDesc *ref_desc;         // device, [levels]
   void *extra_slab;               // owned allocation (null for the selection carved from the pyramid slab)
   size_t extra_bytes;
 };
@@ -121,6 +122,8 @@ struct dvo_amd_pyramid {
   void *slab = nullptr;
   size_t slab_bytes = 0;
   int *counters = nullptr;  // device, [levels][2], inside the slab
+  CurLevelDesc *cur_desc = nullptr;   // device, [levels], inside the slab
+  RefLevelDesc *ref_desc0 = nullptr;  // device, [levels], inside the slab: room for the first selection's descriptors
   std::mutex mu;
   std::vector<Selection> selections;
 };
@@ -148,6 +151,8 @@ size_t pyramid_layout(dvo_amd_pyramid *p, char *base) {
     L.ty = (float *)carve(sizeof(float) * L.h);
   }
   p->counters = (int *)carve(sizeof(int) * 2 * DVO_AMD_MAX_LEVELS);
+  p->cur_desc = (CurLevelDesc *)carve(sizeof(CurLevelDesc) * DVO_AMD_MAX_LEVELS);
+  p->ref_desc0 = (RefLevelDesc *)carve(sizeof(RefLevelDesc) * DVO_AMD_MAX_LEVELS);
   return off;
 }
 
@@ -230,6 +235,23 @@ int pyramid_build(int device, const float *src_i, const float *src_z, bool src_o
                             L.r_iy, L.tx, L.ty, L.h, st);
     if (e != hipSuccess) return bail(fail_hip("level_planes", e));
   }
+  CurLevelDesc cur_host[DVO_AMD_MAX_LEVELS];
+  std::memset(cur_host, 0, sizeof(cur_host));
+  for (int l = 0; l < levels; ++l) {
+    const LevelData &C = p->lv[l];
+    CurLevelDesc &d = cur_host[l];
+    d.c_a = C.c_a, d.c_b = C.c_b, d.w = C.w, d.h = C.h;
+    // wcur / wref, dense_tracking.cpp:215-220
+    const float wcur_id = 0.5f, wref_id = 0.5f, wcur_zd = 1.0f;
+    d.wc[0] = 1.0f / 255.0f, d.wc[1] = 1.0f;
+    d.wc[2] = wcur_id * C.fx / 255.0f, d.wc[3] = wcur_id * C.fy / 255.0f;
+    d.wc[4] = wcur_zd * C.fx, d.wc[5] = wcur_zd * C.fy;
+    d.wr[0] = -1.0f / 255.0f, d.wr[1] = -1.0f;
+    d.wr[2] = wref_id * C.fx / 255.0f, d.wr[3] = wref_id * C.fy / 255.0f;
+    d.ub_x = (float)(size_t)(C.w - 2), d.ub_y = (float)(size_t)(C.h - 2);
+  }
+  e = hipMemcpyAsync(p->cur_desc, cur_host, sizeof(CurLevelDesc) * levels, hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return bail(fail_hip("pyramid descriptors", e));
   e = hipStreamSynchronize(st);
   if (e != hipSuccess) return bail(fail_hip("pyramid build", e));
   *out = p;
@@ -253,17 +275,28 @@ int pyramid_selection(dvo_amd_pyramid *p, float ti, float td, int *index) {
   s.ti = ti, s.td = td, s.extra_slab = nullptr, s.extra_bytes = 0;
   if (p->selections.empty()) {
     for (int l = 0; l < p->n_levels; ++l) s.zsel[l] = p->lv[l].zsel0;
+    s.ref_desc = p->ref_desc0;
   } else {
-    size_t bytes = 0;
+    size_t bytes = align_up(sizeof(RefLevelDesc) * DVO_AMD_MAX_LEVELS, 256);
     for (int l = 0; l < p->n_levels; ++l) bytes += align_up(sizeof(float) * p->lv[l].n_pad, 256);
     HIP_TRY(hipMalloc(&s.extra_slab, bytes));
     s.extra_bytes = bytes;
-    size_t off = 0;
+    s.ref_desc = (RefLevelDesc *)s.extra_slab;
+    size_t off = align_up(sizeof(RefLevelDesc) * DVO_AMD_MAX_LEVELS, 256);
     for (int l = 0; l < p->n_levels; ++l) {
       s.zsel[l] = (float *)((char *)s.extra_slab + off);
       off += align_up(sizeof(float) * p->lv[l].n_pad, 256);
     }
   }
+  RefLevelDesc ref_host[DVO_AMD_MAX_LEVELS];
+  std::memset(ref_host, 0, sizeof(ref_host));
+  for (int l = 0; l < p->n_levels; ++l) {
+    const LevelData &R = p->lv[l];
+    ref_host[l].r_zsel = s.zsel[l];
+    ref_host[l].r_i = R.r_i, ref_host[l].r_ix = R.r_ix, ref_host[l].r_iy = R.r_iy;
+    ref_host[l].tx = R.tx, ref_host[l].ty = R.ty;
+  }
+  HIP_TRY(hipMemcpyAsync(s.ref_desc, ref_host, sizeof(RefLevelDesc) * p->n_levels, hipMemcpyHostToDevice, st));
   for (int l = 0; l < p->n_levels; ++l) {
     const LevelData &L = p->lv[l];
     hipError_t e = launch_select(L.z_plane, L.c_a, L.c_b, L.n, L.n_pad, ti, td, s.zsel[l], p->counters + 2 * l, st);
@@ -289,7 +322,8 @@ struct JobSlot {
   float *records = nullptr;
   double *ll_partials = nullptr;
   int *cut[2] = {nullptr, nullptr};
-  FinOut *out = nullptr;  // pinned host memory, device-visible
+  FinOut *out = nullptr;      // pinned host memory, device-visible
+  FinOut *out_dev = nullptr;  // device staging of the record
   void *dev_block = nullptr;
 };
 
@@ -303,10 +337,10 @@ struct dvo_amd_context {
   int slot_n_pad = 0;  // capacity every slot was sized for
   FinOut *out_host = nullptr;
   int out_capacity = 0;
-  LevelPairDesc *desc_host = nullptr;  // pinned staging, [slot][level]
-  LevelPairDesc *desc_dev = nullptr;
-  int desc_capacity = 0;               // in slots
+  SlotDesc *slot_desc = nullptr;       // device, [slot]
+  unsigned *tickets = nullptr;         // device, one arrival counter per tick stream
   unsigned tick_seq = 0;
+  bool fin_stamps = false;             // DVO_AMD_FIN_STAMPS=1: k_finalize records phase stamps (diagnostic)
   bool poll = true;                    // wait for a tick by polling the records' sequence words instead of hipStreamSynchronize
   // optional kernel timing (bench.py roofline section)
   bool timing = false;
@@ -474,29 +508,6 @@ void make_kt(const LevelData &C, const SE3 &estimate, float kt[12]) {
       kt[i * 4 + c] = (K[i * 3 + 0] * T[c * 4 + 0] + K[i * 3 + 1] * T[c * 4 + 1]) + K[i * 3 + 2] * T[c * 4 + 2];
 }
 
-void fill_desc(LevelPairDesc &d, const dvo_amd_pyramid *ref, int sel, const dvo_amd_pyramid *cur, int level,
-               const JobSlot &slot) {
-  const LevelData &R = ref->lv[level];
-  const LevelData &C = cur->lv[level];
-  d.w = C.w, d.h = C.h;
-  d.r_zsel = ref->selections[sel].zsel[level];
-  d.r_i = R.r_i, d.r_ix = R.r_ix, d.r_iy = R.r_iy;
-  d.tx = R.tx, d.ty = R.ty;
-  d.c_a = C.c_a, d.c_b = C.c_b;
-  d.res[0] = slot.res[0], d.res[1] = slot.res[1];
-  d.records = slot.records;
-  d.ll_partials = slot.ll_partials;
-  d.cut[0] = slot.cut[0], d.cut[1] = slot.cut[1];
-  // wcur / wref, dense_tracking.cpp:215-220
-  const float wcur_id = 0.5f, wref_id = 0.5f, wcur_zd = 1.0f;
-  d.wc[0] = 1.0f / 255.0f, d.wc[1] = 1.0f;
-  d.wc[2] = wcur_id * C.fx / 255.0f, d.wc[3] = wcur_id * C.fy / 255.0f;
-  d.wc[4] = wcur_zd * C.fx, d.wc[5] = wcur_zd * C.fy;
-  d.wr[0] = -1.0f / 255.0f, d.wr[1] = -1.0f;
-  d.wr[2] = wref_id * C.fx / 255.0f, d.wr[3] = wref_id * C.fy / 255.0f;
-  d.ub_x = (float)(size_t)(C.w - 2), d.ub_y = (float)(size_t)(C.h - 2);
-}
-
 int blocks_for(int n, int rounds) {
   const int px_per_block = kSegPxPerRound * kWavesPerBlock * rounds;
   return (n + px_per_block - 1) / px_per_block;
@@ -620,21 +631,21 @@ int ensure_slots(dvo_amd_context *ctx, int n_jobs, int n_pad) {
     HIP_TRY(hipHostMalloc((void **)&ctx->out_host, sizeof(FinOut) * n_slots, hipHostMallocMapped | hipHostMallocCoherent));
     ctx->out_capacity = n_slots;
   }
-  if (ctx->desc_capacity < n_slots) {
-    if (ctx->desc_host) (void)hipHostFree(ctx->desc_host);
-    if (ctx->desc_dev) (void)hipFree(ctx->desc_dev);
-    ctx->desc_host = nullptr, ctx->desc_dev = nullptr;
-    const size_t bytes = sizeof(LevelPairDesc) * DVO_AMD_MAX_LEVELS * n_slots;
-    HIP_TRY(hipHostMalloc((void **)&ctx->desc_host, bytes, hipHostMallocDefault));
-    HIP_TRY(hipMalloc((void **)&ctx->desc_dev, bytes));
-    ctx->desc_capacity = n_slots;
+  if (ctx->slot_desc) (void)hipFree(ctx->slot_desc);
+  ctx->slot_desc = nullptr;
+  HIP_TRY(hipMalloc((void **)&ctx->slot_desc, sizeof(SlotDesc) * n_slots));
+  if (!ctx->tickets) {
+    HIP_TRY(hipMalloc((void **)&ctx->tickets, sizeof(unsigned) * 64));
+    HIP_TRY(hipMemset(ctx->tickets, 0, sizeof(unsigned) * 64));
   }
+  std::vector<SlotDesc> slot_host((size_t)n_slots);
   const int max_blocks = new_pad / (kSegPxPerRound * kWavesPerBlock);
   const size_t b_res = align_up(sizeof(float2) * new_pad, 256);
   const size_t b_rec = align_up(sizeof(float) * kRecStride * max_blocks, 256);
   const size_t b_ll = align_up(sizeof(double) * max_blocks, 256);
   const size_t b_cut = 256;
-  const size_t total = 2 * b_res + b_rec + b_ll + 2 * b_cut;
+  const size_t b_out = align_up(sizeof(FinOut), 256);
+  const size_t total = 2 * b_res + b_rec + b_ll + 2 * b_cut + b_out;
   ctx->slots.resize(n_slots);
   for (int i = 0; i < n_slots; ++i) {
     JobSlot &s = ctx->slots[i];
@@ -646,21 +657,28 @@ int ensure_slots(dvo_amd_context *ctx, int n_jobs, int n_pad) {
     s.ll_partials = (double *)p, p += b_ll;
     s.cut[0] = (int *)p, p += b_cut;
     s.cut[1] = (int *)p, p += b_cut;
+    s.out_dev = (FinOut *)p, p += b_out;
     FinOut *dev_out = nullptr;
     HIP_TRY(hipHostGetDevicePointer((void **)&dev_out, ctx->out_host + i, 0));
     s.out = dev_out;
     ctx->out_host[i].seq = 0;
+    SlotDesc &sd = slot_host[(size_t)i];
+    sd.res[0] = s.res[0], sd.res[1] = s.res[1];
+    sd.records = s.records, sd.ll_partials = s.ll_partials;
+    sd.cut[0] = s.cut[0], sd.cut[1] = s.cut[1];
   }
+  HIP_TRY(hipMemcpy(ctx->slot_desc, slot_host.data(), sizeof(SlotDesc) * n_slots, hipMemcpyHostToDevice));
   ctx->tick_seq = 0;
   ctx->slot_n_pad = new_pad;
   return DVO_AMD_OK;
 }
 
 int pick_rounds(long long total_px) {
-  // The Gram-matrix (MFMA) form has no per-wave reduction to amortise, so short segments (many waves) are best; two
-  // rounds per wave measured ~4 % better than one once the launch holds tens of thousands of waves.
+  // The Gram-matrix (MFMA) form has no per-wave reduction to amortise, so short segments (many waves) are best for the
+  // residual pass itself (1 vs 2 rounds: within 4 %).  Longer segments mean fewer per-block records for k_finalize to
+  // read, which matters once many pairs are resident.
   const long long waves1 = total_px / kSegPxPerRound;
-  return waves1 >= 32768 ? 2 : 1;
+  return waves1 >= 65536 ? 4 : waves1 >= 8192 ? 2 : 1;
 }
 
 int timing_begin(dvo_amd_context *ctx, hipStream_t stream, size_t *slot) {
@@ -753,10 +771,12 @@ int run_tick(dvo_amd_context *ctx, std::vector<Job> &jobs) {
     const size_t slot_index = (size_t)(j.slot - ctx->slots.data());
     TickItem w;
     std::memset(&w, 0, sizeof(w));
-    w.desc = ctx->desc_dev + slot_index * DVO_AMD_MAX_LEVELS + j.level;
+    w.ref = j.ref->selections[j.sel].ref_desc + j.level;
+    w.cur = j.cur->cur_desc + j.level;
+    w.slot = ctx->slot_desc + slot_index;
     FinItem f;
     f.records = nullptr, f.n_blocks = 0, f.n_ll_blocks = 0, f.ll_partials = j.slot->ll_partials;
-    f.cut_out = j.slot->cut[0], f.out = j.slot->out, f.seq = seq, f.pad = 0;
+    f.cut_out = j.slot->cut[0], f.out = j.slot->out, f.out_dev = j.slot->out_dev, f.seq = seq, f.pad = 0;
     if (j.have_a) {
       w.ll_blocks = j.a.n_blocks;
       w.ll_rounds = j.a.rounds;
@@ -805,7 +825,8 @@ int run_tick(dvo_amd_context *ctx, std::vector<Job> &jobs) {
     ta.n_items = (int)std::min(per, items.size() - first);
     ta.pad = 0;
     fa.n_items = ta.n_items;
-    fa.pad = 0;
+    fa.pad = ctx->fin_stamps ? 0x57A3 : 0;
+    fa.ticket = ctx->tickets + 16 * ((ctx->timing ? 0 : launch_index) % kMaxTickStreams);  // one counter per stream
     int max_blocks = 0;
     for (int i = 0; i < ta.n_items; ++i) {
       ta.items[i] = items[first + i];
@@ -922,6 +943,8 @@ int dvo_amd_context_create(int device, const dvo_amd_config *cfg, dvo_amd_contex
   }
   const char *pe = getenv("DVO_AMD_POLL");
   ctx->poll = !(pe && pe[0] == '0');
+  const char *fs = getenv("DVO_AMD_FIN_STAMPS");
+  ctx->fin_stamps = fs && fs[0] == '1';
   *out = ctx;
   return DVO_AMD_OK;
 }
@@ -938,8 +961,8 @@ void dvo_amd_context_destroy(dvo_amd_context *ctx) {
   for (JobSlot &s : ctx->slots)
     if (s.dev_block) (void)hipFree(s.dev_block);
   if (ctx->out_host) (void)hipHostFree(ctx->out_host);
-  if (ctx->desc_host) (void)hipHostFree(ctx->desc_host);
-  if (ctx->desc_dev) (void)hipFree(ctx->desc_dev);
+  if (ctx->slot_desc) (void)hipFree(ctx->slot_desc);
+  if (ctx->tickets) (void)hipFree(ctx->tickets);
   for (auto &ev : ctx->events) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
@@ -1045,8 +1068,8 @@ int dvo_amd_pyramid_select(dvo_amd_pyramid *p, int level, float ti, float td, in
   return DVO_AMD_OK;
 }
 
-int dvo_amd_match_batch(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *references, dvo_amd_pyramid *const *currents,
-                        const double *T_inits, dvo_amd_result *results) {
+int dvo_amd_match_many(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *references, dvo_amd_pyramid *const *currents,
+                       const double *T_inits, dvo_amd_result *results, int max_in_flight) {
   if (!ctx || n < 0 || (n > 0 && (!references || !currents || !results))) return DVO_AMD_ERR_INVALID_ARGUMENT;
   if (n == 0) return DVO_AMD_OK;
   const dvo_amd_config &cfg = ctx->cfg;
@@ -1055,6 +1078,7 @@ int dvo_amd_match_batch(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *ref
   HIP_TRY(hipSetDevice(ctx->device));
   const int need_levels = cfg.first_level + 1;  // Config::getNumLevels
   int n_pad = 0;
+  if (cfg.use_initial_estimate && !T_inits) return DVO_AMD_ERR_INVALID_ARGUMENT;
   for (int i = 0; i < n; ++i) {
     if (!references[i] || !currents[i]) return DVO_AMD_ERR_INVALID_ARGUMENT;
     if (references[i]->device != ctx->device || currents[i]->device != ctx->device) return DVO_AMD_ERR_DEVICE_MISMATCH;
@@ -1066,61 +1090,61 @@ int dvo_amd_match_batch(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *ref
     const int its_needed = (cfg.first_level - cfg.last_level + 1) * (cfg.max_iterations_per_level + 1);
     if (results[i].iterations && results[i].iterations_capacity > 0 && results[i].iterations_capacity < its_needed)
       return DVO_AMD_ERR_CAPACITY;
+    if (cfg.use_initial_estimate) {  // dense_tracking.cpp:139
+      double s = 0.0;
+      for (int k = 0; k < 16; ++k) s += T_inits[16 * (size_t)i + k];
+      if (!std::isfinite(s)) return DVO_AMD_ERR_NAN_INIT;
+    }
   }
-  rc = ensure_slots(ctx, n, n_pad);
+  const int in_flight = (max_in_flight <= 0 || max_in_flight > n) ? n : max_in_flight;
+  rc = ensure_slots(ctx, in_flight, n_pad);
   if (rc) return rc;
 
-  std::vector<Job> jobs((size_t)n);
-  for (int i = 0; i < n; ++i) {
-    Job &j = jobs[(size_t)i];
-    j.ref = references[i], j.cur = currents[i];
-    j.result = &results[i];
-    j.slot = &ctx->slots[(size_t)i];
-    j.cfg = &ctx->cfg;
-    rc = pyramid_selection(j.ref, cfg.intensity_derivative_threshold, cfg.depth_derivative_threshold, &j.sel);
-    if (rc) return rc;
-    dvo_amd_result *r = j.result;
-    r->n_levels = 0, r->n_iterations = 0, r->n_ticks = 0, r->n_residual_passes = 0, r->alg_bytes = 0.0, r->is_nan = 0;
-    if (!r->iterations) r->iterations_capacity = 0;
-    // dense_tracking.cpp:137-150
-    if (cfg.use_initial_estimate) {
-      if (!T_inits) return DVO_AMD_ERR_INVALID_ARGUMENT;
-      const double *T0 = T_inits + 16 * (size_t)i;
-      double s = 0.0;
-      for (int k = 0; k < 16; ++k) s += T0[k];
-      if (!std::isfinite(s)) return DVO_AMD_ERR_NAN_INIT;
-      j.inc = se3_from_matrix(T0);
-    } else {
-      j.inc = SE3::identity();
-    }
-    j.initial = j.inc;
-    j.estimate = SE3::identity();
-    j.level = cfg.first_level;
-    for (int l = cfg.last_level; l <= cfg.first_level; ++l)
-      fill_desc(ctx->desc_host[(size_t)i * DVO_AMD_MAX_LEVELS + l], j.ref, j.sel, j.cur, l, *j.slot);
-    start_level(j);
-  }
-  HIP_TRY(hipMemcpyAsync(ctx->desc_dev, ctx->desc_host, sizeof(LevelPairDesc) * DVO_AMD_MAX_LEVELS * (size_t)n,
-                         hipMemcpyHostToDevice, ctx->stream));
-  if (n > kMaxItemsPerLaunch) {
-    if (!ctx->desc_ready) HIP_TRY(hipEventCreateWithFlags(&ctx->desc_ready, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(ctx->desc_ready, ctx->stream));
-    const size_t n_launch = ((size_t)n + kMaxItemsPerLaunch - 1) / kMaxItemsPerLaunch;
-    for (size_t i = 1; i < n_launch && i < (size_t)kMaxTickStreams; ++i) {
-      hipStream_t st;
-      rc = tick_stream(ctx, i, &st);
+  // Pairs enter a free slot as soon as one opens up: the launch of every tick stays full although pairs need different
+  // numbers of iterations.  A pair's state machine never looks at another pair, so results do not depend on the schedule
+  // (except through the rounds-per-wave choice, which only changes the order partial sums are taken in).
+  std::vector<Job> jobs((size_t)in_flight);
+  std::vector<int> job_of_slot((size_t)in_flight, -1);
+  for (Job &j : jobs) j.done = true;
+  int next = 0, finished = 0;
+  while (finished < n) {
+    for (int sidx = 0; sidx < in_flight && next < n; ++sidx) {
+      Job &j = jobs[(size_t)sidx];
+      if (!j.done) continue;
+      const int i = next++;
+      j = Job();
+      j.ref = references[i], j.cur = currents[i];
+      j.result = &results[i];
+      j.slot = &ctx->slots[(size_t)sidx];
+      j.cfg = &ctx->cfg;
+      rc = pyramid_selection(j.ref, cfg.intensity_derivative_threshold, cfg.depth_derivative_threshold, &j.sel);
       if (rc) return rc;
-      HIP_TRY(hipStreamWaitEvent(st, ctx->desc_ready, 0));
+      dvo_amd_result *r = j.result;
+      r->n_levels = 0, r->n_iterations = 0, r->n_ticks = 0, r->n_residual_passes = 0, r->alg_bytes = 0.0, r->is_nan = 0;
+      if (!r->iterations) r->iterations_capacity = 0;
+      // dense_tracking.cpp:137-150
+      j.inc = cfg.use_initial_estimate ? se3_from_matrix(T_inits + 16 * (size_t)i) : SE3::identity();
+      j.initial = j.inc;
+      j.estimate = SE3::identity();
+      j.level = cfg.first_level;
+      j.done = false;
+      job_of_slot[(size_t)sidx] = i;
+      start_level(j);
     }
-  }
-  for (;;) {
-    bool any = false;
-    for (const Job &j : jobs) any = any || !j.done;
-    if (!any) break;
     rc = run_tick(ctx, jobs);
     if (rc) return rc;
+    for (int sidx = 0; sidx < in_flight; ++sidx)
+      if (jobs[(size_t)sidx].done && job_of_slot[(size_t)sidx] >= 0) {
+        job_of_slot[(size_t)sidx] = -1;
+        ++finished;
+      }
   }
   return DVO_AMD_OK;
+}
+
+int dvo_amd_match_batch(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *references, dvo_amd_pyramid *const *currents,
+                        const double *T_inits, dvo_amd_result *results) {
+  return dvo_amd_match_many(ctx, n, references, currents, T_inits, results, 0);
 }
 
 int dvo_amd_match(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, const double *T_init,
@@ -1144,14 +1168,13 @@ int dvo_amd_residuals(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_
   rc = ensure_slots(ctx, 1, R.n_pad);
   if (rc) return rc;
   JobSlot &s = ctx->slots[0];
-  fill_desc(ctx->desc_host[level], reference, sel, current, level, s);
-  HIP_TRY(hipMemcpyAsync(ctx->desc_dev + level, ctx->desc_host + level, sizeof(LevelPairDesc), hipMemcpyHostToDevice,
-                         ctx->stream));
   TickArgs ta;
   std::memset(&ta, 0, sizeof(ta));
   ta.n_items = 1;
   TickItem &w = ta.items[0];
-  w.desc = ctx->desc_dev + level;
+  w.ref = reference->selections[sel].ref_desc + level;
+  w.cur = current->cur_desc + level;
+  w.slot = ctx->slot_desc;
   w.res_rounds = 1;
   while (w.res_rounds < kMaxRounds && blocks_for(R.n, w.res_rounds) > 2048) w.res_rounds *= 2;
   w.res_blocks = blocks_for(R.n, w.res_rounds);
@@ -1171,6 +1194,8 @@ int dvo_amd_residuals(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_
   fa.items[0].ll_partials = s.ll_partials;
   fa.items[0].cut_out = s.cut[0];
   fa.items[0].out = s.out;
+  fa.items[0].out_dev = s.out_dev;
+  fa.ticket = ctx->tickets;
   fa.items[0].seq = ++ctx->tick_seq;
   fa.items[0].pad = 0;
   e = launch_finalize(fa, ctx->stream);
@@ -1218,11 +1243,10 @@ int dvo_amd_bench_residual_pass(dvo_amd_context *ctx, dvo_amd_pyramid *reference
   if (rounds <= 0) rounds = pick_rounds((long long)R.n * n_items);
   if (rounds != 1 && rounds != 2 && rounds != 4 && rounds != 8 && rounds != 16) return DVO_AMD_ERR_INVALID_ARGUMENT;
   while (rounds < kMaxRounds && blocks_for(R.n, rounds) > 2048) rounds *= 2;
-  for (int i = 0; i < n_items; ++i) fill_desc(ctx->desc_host[(size_t)i * DVO_AMD_MAX_LEVELS + level], reference, sel, current, level, ctx->slots[(size_t)i]);
-  HIP_TRY(hipMemcpyAsync(ctx->desc_dev, ctx->desc_host, sizeof(LevelPairDesc) * DVO_AMD_MAX_LEVELS * (size_t)n_items,
-                         hipMemcpyHostToDevice, ctx->stream));
   TickItem proto;
   std::memset(&proto, 0, sizeof(proto));
+  proto.ref = reference->selections[sel].ref_desc + level;
+  proto.cur = current->cur_desc + level;
   proto.res_rounds = rounds;
   proto.res_blocks = blocks_for(R.n, rounds);
   proto.unit_weights = 0;
@@ -1245,7 +1269,7 @@ int dvo_amd_bench_residual_pass(dvo_amd_context *ctx, dvo_amd_pyramid *reference
       ta.pad = 0;
       for (int i = 0; i < ta.n_items; ++i) {
         ta.items[i] = proto;
-        ta.items[i].desc = ctx->desc_dev + (size_t)(first + i) * DVO_AMD_MAX_LEVELS + level;
+        ta.items[i].slot = ctx->slot_desc + (first + i);
       }
       hipError_t e = launch_tick(ta, proto.res_blocks, ctx->stream);
       if (e != hipSuccess) return fail_hip("launch_tick", e);
@@ -1261,6 +1285,14 @@ int dvo_amd_bench_residual_pass(dvo_amd_context *ctx, dvo_amd_pyramid *reference
   if (avg_ms) *avg_ms = total_ms / reps;
   if (alg_bytes) *alg_bytes = 56.0 * (double)reference->selections[sel].count[level] * n_items;
   if (n_launches) *n_launches = launches;
+  return DVO_AMD_OK;
+}
+
+int dvo_amd_debug_finalize_stamps(dvo_amd_context *ctx, unsigned long long *stamps8) {
+  if (!ctx || !stamps8) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(read_finalize_stamps(stamps8));
   return DVO_AMD_OK;
 }
 

@@ -30,31 +30,35 @@ constexpr int kRecStride = 104;
 //   [63..68] sum w Ja_i r0   [69..74] sum w Ja_i r1   [75..80] sum w Jb_i r0   [81..86] sum w Jb_i r1
 constexpr int kAccAA = 0, kAccAB = 21, kAccBB = 42, kAccAR0 = 63, kAccAR1 = 69, kAccBR0 = 75, kAccBR1 = 81;
 
-// Static description of one (reference level, current level) pair plus the scratch of the job slot that aligns it.
-// Lives in device memory; written once per match call, read by every block through scalar loads.
-struct LevelPairDesc {
-  // reference level (planar, padded to kPlanePad, zsel = NaN where the pixel is not selected)
-  const float *r_zsel, *r_i, *r_ix, *r_iy;
+// Static descriptors, resident in device memory next to what they describe and read by every block through scalar loads.
+// They are written once (pyramid build / point selection / scratch allocation); nothing is uploaded per match or per tick.
+struct RefLevelDesc {  // one per (pyramid, selection thresholds, level): the reference side of a pair
+  const float *r_zsel;  // depth where the pixel is selected, NaN elsewhere and in the padding (planes padded to kPlanePad)
+  const float *r_i, *r_ix, *r_iy;
   const float *tx, *ty;  // ((float)x - ox)/fx, ((float)y - oy)/fy
-  // current level, gather layout
-  const float4 *c_a;  // {I, Z, Ix, Iy} per pixel
+};
+struct CurLevelDesc {  // one per (pyramid, level): the current side of a pair
+  const float4 *c_a;  // {I, Z, Ix, Iy} per pixel (gather layout)
   const float2 *c_b;  // {Zx, Zy} per pixel
-  // job-slot scratch
+  int w, h;
+  float wc[6];       // wcur: {1/255, 1, .5fx/255, .5fy/255, fx, fy}  (dense_tracking.cpp:219)
+  float wr[4];       // wref: {-1/255, -1, .5fx/255, .5fy/255}        (dense_tracking.cpp:220)
+  float ub_x, ub_y;  // (float)(w-2), (float)(h-2)
+};
+struct SlotDesc {  // one per job slot of a context: scratch of the pair being aligned in that slot
   float2 *res[2];       // residual buffers (double buffered by iteration parity), NaN = invalid
   float *records;       // residual pass: n_blocks x kRecStride floats
   double *ll_partials;  // log-likelihood pass: one double per block
   int *cut[2];          // {cut_seg, cut_local} of the residual pass that filled res[i]
-  int w, h;
-  float wc[6];          // wcur: {1/255, 1, .5fx/255, .5fy/255, fx, fy}  (dense_tracking.cpp:219)
-  float wr[4];          // wref: {-1/255, -1, .5fx/255, .5fy/255}        (dense_tracking.cpp:220)
-  float ub_x, ub_y;     // (float)(w-2), (float)(h-2)
 };
 
 // One job's device work of a tick, passed by value in the kernel arguments (no H2D copy per iteration):
 // blocks [0, res_blocks) run the residual pass of iteration k+1, blocks [res_blocks, res_blocks + ll_blocks) the
 // log-likelihood pass of iteration k.
 struct TickItem {
-  const LevelPairDesc *desc;
+  const RefLevelDesc *ref;
+  const CurLevelDesc *cur;
+  const SlotDesc *slot;
   int res_blocks, ll_blocks;
   int res_rounds, ll_rounds;  // rounds per wave
   int res_buf, ll_buf;        // which residual buffer is written / read
@@ -65,7 +69,7 @@ struct TickItem {
   float P_ll[4];              // precision of the iteration whose likelihood is evaluated
 };
 
-constexpr int kMaxItemsPerLaunch = 30;
+constexpr int kMaxItemsPerLaunch = 27;
 struct TickArgs {
   int n_items;
   int pad;
@@ -82,7 +86,9 @@ struct FinOut {
   double S[3];     // sum over pairs (w_2j + w_2j+1) r_2j r_2j^T  (xx, xy, yy), unscaled (Q5 pairing)
   double acc[kNumAcc];
   double ll_sum;   // sum of log(1 + 0.2 r^T P r) over the first 50*floor(V/50) valid residuals (Q6)
+  double pad_to_16;
 };
+static_assert(sizeof(FinOut) % 16 == 0, "FinOut is copied to the host in 16-byte pieces");
 
 struct FinItem {
   const float *records;   // residual-pass block records (or null)
@@ -90,14 +96,16 @@ struct FinItem {
   int n_ll_blocks;
   const double *ll_partials;
   int *cut_out;           // {cut_seg, cut_local} for the residual pass just reduced
-  FinOut *out;
+  FinOut *out;            // host (pinned, device-visible): where the record is published
+  FinOut *out_dev;        // device staging of the same record
   unsigned seq;
   unsigned pad;
 };
-constexpr int kMaxFinItems = 64;  // 48 B each
+constexpr int kMaxFinItems = 56;  // 56 B each
 struct FinArgs {
   int n_items;
   int pad;
+  unsigned *ticket;       // device word, zero between launches: arrival counter of this launch's blocks
   FinItem items[kMaxFinItems];
 };
 static_assert(sizeof(FinArgs) <= 3800, "kernel argument block too large");
@@ -105,6 +113,7 @@ static_assert(sizeof(FinArgs) <= 3800, "kernel argument block too large");
 // ---- launch wrappers (dvo_kernels.hip) ----------------------------------------------------------------------------
 hipError_t launch_tick(const TickArgs &args, int max_blocks, hipStream_t stream);
 hipError_t launch_finalize(const FinArgs &args, hipStream_t stream);
+hipError_t read_finalize_stamps(unsigned long long out[8]);
 
 // prep (pyramid construction) kernels
 hipError_t launch_pyr_down(const float *i_prev, const float *z_prev, int w_prev, float *i_out, float *z_out, int w, int h,

@@ -160,6 +160,12 @@ int dvo_amd_match(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyra
 int dvo_amd_match_batch(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *references, dvo_amd_pyramid *const *currents,
                         const double *T_inits, dvo_amd_result *results);
 
+/* The same n alignments with at most max_in_flight of them resident at a time: a pair that finishes hands its slot to the
+ * next pending pair, so every launch stays full although pairs need different numbers of iterations (the shape of the
+ * loop-closure validator working through a proposal list, keyframe_graph.cpp:576-593).  max_in_flight <= 0: all n at once. */
+int dvo_amd_match_many(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *references, dvo_amd_pyramid *const *currents,
+                       const double *T_inits, dvo_amd_result *results, int max_in_flight);
+
 /* dvo::core::computeResidualsAndValidFlagsSse (dense_tracking_impl.cpp:400-403) for one level and one float transform
  * (column-major 4x4, reference -> current).  residuals: width*height x 2 floats in pixel order, NaN where the pixel is not
  * selected or its warp is invalid.  Used by the parity tests and by dvo_amd_error_image. */
@@ -177,6 +183,10 @@ int dvo_amd_error_image(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_am
 int dvo_amd_bench_residual_pass(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, int level,
                                 const float *T, int n_items, int rounds, int reps, double *avg_ms, double *alg_bytes,
                                 int *n_launches);
+
+/* Diagnostic: with DVO_AMD_FIN_STAMPS=1 in the environment the finalize kernel records 8 shader-clock stamps of its phases
+ * (block 0 of the most recent launch); this reads them back. */
+int dvo_amd_debug_finalize_stamps(dvo_amd_context *ctx, unsigned long long *stamps8);
 
 /* Host-side helpers (no GPU needed): the SE(3) exponential / logarithm with Sophus' tangent order (upsilon, omega) and the
  * pivoted LDL^T 6x6 solve the driver uses in place of Sophus::SE3d::exp/log and Eigen::LDLT (dense_tracking.cpp:238,259,347).

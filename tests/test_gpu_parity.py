@@ -302,6 +302,11 @@ def test_deterministic_and_batch_equals_single(capi, synth, pair640):
     for o, s in zip(out, singles):
         assert synth.pose_error(s.Transformation, o.Transformation) <= POSE_TOL
         assert [L["ValidPixels"] for L in o.Levels] == [L["ValidPixels"] for L in s.Levels]
+    # continuous batching: at most 2 pairs resident, the others take over the slots as they free up
+    rolling = trk.match_batch(refs, curs, in_flight=2)
+    for o, s in zip(rolling, singles):
+        assert synth.pose_error(s.Transformation, o.Transformation) <= POSE_TOL
+        assert [len(L["Iterations"]) for L in o.Levels] == [len(L["Iterations"]) for L in s.Levels]
     big = trk.match_batch([pair640["gr"]] * 40, [pair640["gc"]] * 40, stats=False)  # > one launch worth of items
     assert all(np.array_equal(big[0].Transformation, o.Transformation) for o in big)
     assert synth.pose_error(a.Transformation, big[0].Transformation) <= POSE_TOL
