@@ -45,9 +45,9 @@ def parse():
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from dvo_slam_amd import sharding
+
+    rank, local_rank, world = sharding.rank_info()
     dist = None
     if world > 1:
         import torch
@@ -87,7 +87,7 @@ def main():
     B = args.batch
     refs = [ref] * B
     curb = [curs[i % len(curs)] for i in range(B)]
-    shares = [list(range(t, B, T)) for t in range(T)]
+    shares = sharding.split_for_threads(list(range(B)), T)
 
     def run_steps(n_steps, collect):
         """n_steps lock-step batches of B pairs on this GPU; with T > 1 every thread drives its own stream"""
@@ -141,13 +141,8 @@ def main():
         out = trk.match_batch(refs, curb, stats=False)
         k_ms, k_launches = trk.kernel_timing(False)
         alg_bytes_k = sum(o.alg_bytes for o in out)
-    if dist is not None:
-        import torch
-
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    pairs = world * B * args.steps
+    # MAX over ranks of the elapsed time, SUM over ranks of the pairs aligned
+    elapsed, pairs = sharding.aggregate(elapsed, B * args.steps, dist, "cuda" if dist is not None else None)
     value = pairs / elapsed
 
     if rank == 0:

@@ -1,0 +1,51 @@
+"""Pair-level sharding for multi-GPU runs: one process per GPU, independent frame pairs per rank, no data-path collective.
+
+A DenseTracker::match() call is an independent unit (the reference runs them as TBB tasks: local_tracker.cpp:184,
+keyframe_graph.cpp:576-593), so N GPUs simply take N disjoint subsets of the pairs.  torch.distributed (backend "nccl" =
+RCCL on ROCm, "gloo" in the CPU tests) is used only for the barrier around the timed region, the MAX over ranks of the
+elapsed time and the SUM of the pairs processed.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Sequence, Tuple
+
+
+def rank_info() -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torchrun environment; (0, 0, 1) when launched directly."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
+    """Round-robin share of `n_items` global items for `rank`: every item belongs to exactly one rank and the shares
+    differ by at most one item (a loop-closure proposal list is dealt over the GPUs like this)."""
+    if world < 1 or not (0 <= rank < world) or n_items < 0:
+        raise ValueError("bad shard request")
+    return list(range(rank, n_items, world))
+
+
+def shard_weak(per_rank: int, rank: int, world: int) -> List[int]:
+    """Weak scaling: every rank gets `per_rank` items of its own; global ids are contiguous per rank."""
+    if world < 1 or not (0 <= rank < world) or per_rank < 0:
+        raise ValueError("bad shard request")
+    return list(range(rank * per_rank, (rank + 1) * per_rank))
+
+
+def aggregate(elapsed_s: float, n_pairs_local: int, dist=None, device=None) -> Tuple[float, int]:
+    """(max over ranks of elapsed, total pairs over ranks).  `dist` is torch.distributed (initialised) or None."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(elapsed_s), int(n_pairs_local)
+    import torch
+
+    t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
+    n = torch.tensor([n_pairs_local], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(n, op=dist.ReduceOp.SUM)
+    return float(t.item()), int(n.item())
+
+
+def split_for_threads(items: Sequence, n_threads: int) -> List[list]:
+    """Deal a rank's items over its host threads (one tracker / HIP stream each)."""
+    n_threads = max(1, min(n_threads, max(1, len(items))))
+    return [list(items[t::n_threads]) for t in range(n_threads)]
