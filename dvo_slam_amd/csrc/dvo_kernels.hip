@@ -203,6 +203,13 @@ __device__ __forceinline__ void finish_pixel_rtz(const LevelPairDesc &d, const P
 
 typedef float v4acc __attribute__((ext_vector_type(4)));
 
+// Timing-only ablation builds (scripts/ablate.sh: -DDVO_ABLATE=<mask>); never defined in the shipped library.
+// 1: no LDS staging / MFMA   2: no gather loads   4: no rank / pair-sum logic   8: no residual spill store
+#ifndef DVO_ABLATE
+#define DVO_ABLATE 0
+#endif
+#define DVO_KEEP(x) asm volatile("" ::"v"(x))
+
 // The fused residual pass.  A wave walks its segment in steps of 64 consecutive pixels, one pixel per lane, so that every
 // gather instruction of a step touches ~64 neighbouring pixels of the current image (whole cache lines, reused by the
 // other three neighbour loads of the same step while they are still in L1).
@@ -228,7 +235,7 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
   for (int i = 0; i < (ACC == 0 ? kNumAcc : 1); ++i) acc[i] = 0.0f;
   v4acc gram_a = {0.0f, 0.0f, 0.0f, 0.0f}, gram_b = {0.0f, 0.0f, 0.0f, 0.0f};
   // staging for the MFMA operands: [wave][point = lane][16 components], 16-byte chunks XOR-swizzled by point
-  __shared__ __attribute__((aligned(16))) float stage[ACC == 1 ? kWavesPerBlock * kWave * 16 : 4];
+  __shared__ __attribute__((aligned(16))) float stage[ACC == 1 ? kWavesPerBlock * 2 * kWave * 16 : 4];
   float S0[3] = {0.0f, 0.0f, 0.0f}, S1[3] = {0.0f, 0.0f, 0.0f};
   float first_w = 0.0f;
   int run_count = 0;                        // wave uniform
@@ -267,7 +274,31 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
     bool ok;
     {
       const Proj p = project_pixel_rtz(it, d, x, y, z);
-      const Gathered g = gather_pixel(d, p.base);
+      Gathered g;
+      if (DVO_ABLATE & 2) {
+        const v4f c = {p.u, 1.5f, p.v, 0.25f};
+        g.a00 = c, g.a10 = c, g.a01 = c, g.a11 = c, g.b0 = c, g.b1 = c;
+        DVO_KEEP(p.base);
+      } else {
+        g = gather_pixel(d, p.base);
+      }
+      // While this step's gathers are in flight, feed the matrix pipe with the vectors the PREVIOUS step staged
+      // (v_mfma_f32 ignores MODE.FP_ROUND -- probed on gfx950, scripts/probes/mfma_round.hip -- so it may sit in
+      // the toward-zero window).  This overlaps ~512 matrix-pipe cycles with the gather latency and with the next
+      // wave's arithmetic instead of serialising them behind this wave's own VALU work.
+      if (ACC == 1 && !(DVO_ABLATE & 1) && step > 0) {
+        const float *buf = stage + ((wave * 2 + ((step - 1) & 1)) * kWave) * 16;
+        const int comp = lane & 15, sub = lane >> 4;
+#pragma unroll
+        for (int m = 0; m < 16; m += 2) {
+          const int pa = 4 * m + sub, pb = pa + 4;
+          const float va = buf[pa * 16 + ((((comp >> 2) ^ ((pa >> 1) & 3)) << 2) | (comp & 3))];
+          const float vb = buf[pb * 16 + ((((comp >> 2) ^ ((pb >> 1) & 3)) << 2) | (comp & 3))];
+          gram_a = __builtin_amdgcn_mfma_f32_16x16x4f32(va, va, gram_a, 0, 0, 0);
+          gram_b = __builtin_amdgcn_mfma_f32_16x16x4f32(vb, vb, gram_b, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       finish_pixel_rtz(d, p, g, z, ri, rix, riy, r0, r1, e2, e3, e4, e5, ok);
     }
     // ---- back to round-to-nearest
@@ -282,7 +313,12 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
       const float qnan = u2f(0x7fc00000u);
       v2f sv;
       sv.x = ok ? r0 : qnan, sv.y = ok ? r1 : qnan;
-      p_res[cur_idx] = sv;
+      if (DVO_ABLATE & 8) {
+        DVO_KEEP(sv.x);
+        DVO_KEEP(sv.y);
+      } else {
+        p_res[cur_idx] = sv;
+      }
     }
 
     // Branch free from here: an invalid pixel carries weight 0, zero residuals and a harmless point (exact zeros).
@@ -336,18 +372,26 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
         acc[kAccBR0 + i] = __builtin_fmaf(wb[i], r0, acc[kAccBR0 + i]);
         acc[kAccBR1 + i] = __builtin_fmaf(wb[i], r1, acc[kAccBR1 + i]);
       }
+    } else if (DVO_ABLATE & 1) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        DVO_KEEP(Ja[i]);
+        DVO_KEEP(Jb[i]);
+      }
+      DVO_KEEP(wgt);
     } else {
-      // stage sqrt(w) * v for this lane's pixel; chunk c of point p sits at chunk position c ^ ((p >> 1) & 3)
+      // stage sqrt(w) * v for this lane's pixel; chunk c of point p sits at chunk position c ^ ((p >> 1) & 3).
+      // Two buffers alternate: the matrix pipe consumes this one during the NEXT step (see above).
       const float sw = __builtin_amdgcn_sqrtf(wgt);
-      float *buf = stage + wave * kWave * 16;
+      float *buf = stage + ((wave * 2 + (step & 1)) * kWave) * 16;
       v4f *row = reinterpret_cast<v4f *>(buf + lane * 16);
       const int swz = (lane >> 1) & 3;
       v4f c0 = {sw * Ja[0], sw * Ja[1], sw * Ja[2], sw * Ja[3]};
       v4f c1 = {sw * Ja[4], sw * Ja[5], sw * Jb[0], sw * Jb[1]};
       v4f c2 = {sw * Jb[2], sw * Jb[3], sw * Jb[4], sw * Jb[5]};
       v4f c3 = {sw * r0, sw * r1, 0.0f, 0.0f};
-      // the LDS queue of a wave is in order: these writes land after the previous step's reads; the fences only stop
-      // the compiler from reordering across them
+      // the LDS queue of a wave is in order: these writes land after the reads of two steps ago and before the reads of
+      // the next step; the fences only stop the compiler from reordering across them
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
       row[0 ^ swz] = c0;
@@ -356,19 +400,13 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
       row[3 ^ swz] = c3;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      // MFMA m consumes points 4m .. 4m+3: lane l supplies component l&15 of point 4m + (l>>4) as both A and B.
-      // Two accumulators alternate so that no MFMA waits for the one issued just before it.
-      const int comp = lane & 15, sub = lane >> 4;
-#pragma unroll
-      for (int m = 0; m < 16; m += 2) {
-        const int pa = 4 * m + sub, pb = pa + 4;
-        const float va = buf[pa * 16 + ((((comp >> 2) ^ ((pa >> 1) & 3)) << 2) | (comp & 3))];
-        const float vb = buf[pb * 16 + ((((comp >> 2) ^ ((pb >> 1) & 3)) << 2) | (comp & 3))];
-        gram_a = __builtin_amdgcn_mfma_f32_16x16x4f32(va, va, gram_a, 0, 0, 0);
-        gram_b = __builtin_amdgcn_mfma_f32_16x16x4f32(vb, vb, gram_b, 0, 0, 0);
-      }
     }
 
+    if (DVO_ABLATE & 4) {
+      S0[0] += wgt * r0;
+      run_count += ok ? 1 : 0;
+      continue;
+    }
     // ---- rank of every valid pixel in scan order within this wave's segment (needed by the pair quirk Q5)
     const unsigned long long bk = __ballot(ok);
     const unsigned long long prev_lanes = bk & below;
@@ -402,6 +440,19 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
       carry_has = true;
     }
     run_count += __popcll(bk);
+  }
+
+  if (ACC == 1 && !(DVO_ABLATE & 1) && steps > 0) {
+    const float *buf = stage + ((wave * 2 + ((steps - 1) & 1)) * kWave) * 16;
+    const int comp = lane & 15, sub = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < 16; m += 2) {
+      const int pa = 4 * m + sub, pb = pa + 4;
+      const float va = buf[pa * 16 + ((((comp >> 2) ^ ((pa >> 1) & 3)) << 2) | (comp & 3))];
+      const float vb = buf[pb * 16 + ((((comp >> 2) ^ ((pb >> 1) & 3)) << 2) | (comp & 3))];
+      gram_a = __builtin_amdgcn_mfma_f32_16x16x4f32(va, va, gram_a, 0, 0, 0);
+      gram_b = __builtin_amdgcn_mfma_f32_16x16x4f32(vb, vb, gram_b, 0, 0, 0);
+    }
   }
 
   // ---- wave reduction, then the four waves of the block through LDS
@@ -572,8 +623,8 @@ __device__ __forceinline__ LevelPairDesc load_desc(const TickItem &it) {
   return d;
 }
 
-template <int RMODE, int ACC>
-__global__ __launch_bounds__(kBlockThreads, ACC == 1 ? 4 : 2) void k_tick(const TickArgs args) {
+template <int RMODE, int ACC, int OCC>
+__global__ __launch_bounds__(kBlockThreads, OCC) void k_tick(const TickArgs args) {
   const TickItem &it = args.items[blockIdx.y];
   const int bx = (int)blockIdx.x;
   if (bx >= it.res_blocks + it.ll_blocks) return;
@@ -586,6 +637,7 @@ __global__ __launch_bounds__(kBlockThreads, ACC == 1 ? 4 : 2) void k_tick(const 
 
 static int g_reduce_mode = -1;  // DVO_AMD_REDUCE=0: ds_bpermute butterfly instead of DPP (debug cross-check)
 static int g_acc_mode = -1;     // DVO_AMD_ACCUM=valu: 87 register accumulators instead of the MFMA Gram matrix
+static int g_occ = 4;           // DVO_AMD_OCC=5: compile-time register budget for 5 waves/SIMD (MFMA form only)
 
 hipError_t launch_tick(const TickArgs &args, int max_blocks, hipStream_t stream) {
   if (g_reduce_mode < 0) {
@@ -593,19 +645,23 @@ hipError_t launch_tick(const TickArgs &args, int max_blocks, hipStream_t stream)
     g_reduce_mode = (e && e[0] == '0') ? 0 : 1;
     const char *a = getenv("DVO_AMD_ACCUM");
     g_acc_mode = (a && (a[0] == 'v' || a[0] == 'V' || a[0] == '0')) ? 0 : 1;
+    const char *o = getenv("DVO_AMD_OCC");
+    g_occ = (o && o[0] == '5') ? 5 : 4;
   }
   if (args.n_items <= 0 || max_blocks <= 0) return hipSuccess;
   dim3 grid((unsigned)((max_blocks + 7) & ~7), (unsigned)args.n_items, 1);
   if (g_acc_mode == 0) {
     if (g_reduce_mode == 0)
-      hipLaunchKernelGGL((k_tick<0, 0>), grid, dim3(kBlockThreads), 0, stream, args);
+      hipLaunchKernelGGL((k_tick<0, 0, 2>), grid, dim3(kBlockThreads), 0, stream, args);
     else
-      hipLaunchKernelGGL((k_tick<1, 0>), grid, dim3(kBlockThreads), 0, stream, args);
+      hipLaunchKernelGGL((k_tick<1, 0, 2>), grid, dim3(kBlockThreads), 0, stream, args);
+  } else if (g_occ == 5) {
+    hipLaunchKernelGGL((k_tick<1, 1, 5>), grid, dim3(kBlockThreads), 0, stream, args);
   } else {
     if (g_reduce_mode == 0)
-      hipLaunchKernelGGL((k_tick<0, 1>), grid, dim3(kBlockThreads), 0, stream, args);
+      hipLaunchKernelGGL((k_tick<0, 1, 4>), grid, dim3(kBlockThreads), 0, stream, args);
     else
-      hipLaunchKernelGGL((k_tick<1, 1>), grid, dim3(kBlockThreads), 0, stream, args);
+      hipLaunchKernelGGL((k_tick<1, 1, 4>), grid, dim3(kBlockThreads), 0, stream, args);
   }
   return hipGetLastError();
 }

@@ -1,0 +1,7 @@
+#!/bin/bash
+# Builds timing-only ablation variants of the library (results are wrong by construction) next to the real one.
+cd "$(dirname "$0")/.."
+for m in "$@"; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -DDVO_ABLATE=$m -x hip \
+    dvo_slam_amd/csrc/dvo_kernels.hip dvo_slam_amd/csrc/dvo_tracker.cpp -o dvo_slam_amd/libdvo_amd_abl$m.so || exit 1
+done
