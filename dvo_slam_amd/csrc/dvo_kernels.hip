@@ -111,7 +111,7 @@ struct LevelPairDesc {
   float2 *res[2];
   float *records;
   double *ll_partials;
-  int *cut[2];
+  int *seg_prefix[2];
   int w, h;
   float wc[6], wr[4], ub_x, ub_y;
 };
@@ -560,16 +560,16 @@ __device__ void loglik_pass(const TickItem &it, const LevelPairDesc &d, const in
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
   const int seg = lb * kWavesPerBlock + wave;
-  const DVO_GLOBAL int *cutp = (const DVO_GLOBAL int *)(it.ll_buf ? d.cut[1] : d.cut[0]);
-  const int cut_seg = cutp[0], cut_local = cutp[1];
+  // valid pixels of this band that precede the segment (written by k_finalize of the residual pass that filled the buffer)
+  const int seg_before = ((const DVO_GLOBAL int *)(it.ll_buf ? d.seg_prefix[1] : d.seg_prefix[0]))[seg];
+  const int cut_rank = it.ll_cut_rank;
   const float P0 = it.P_ll[0], P1 = it.P_ll[1], P2 = it.P_ll[2], P3 = it.P_ll[3];
   const unsigned long long below = (1ull << lane) - 1ull;
   double total = 0.0;
-  if (seg <= cut_seg) {
-    const bool partial = seg == cut_seg;
+  if (seg_before < cut_rank) {
     const int steps = it.ll_rounds * kPxPerLane;
     const DVO_GLOBAL v2f *src = (const DVO_GLOBAL v2f *)(it.ll_buf ? d.res[1] : d.res[0]) + seg * (kSegPxPerRound * it.ll_rounds) + lane;
-    int run_count = 0;
+    int run_count = seg_before;
     // four steps (256 pixels) per trip: one log of a product of up to four terms per lane
     for (int step = 0; step < steps; step += 4) {
       v2f r[4];
@@ -581,7 +581,7 @@ __device__ void loglik_pass(const TickItem &it, const LevelPairDesc &d, const in
         const bool valid = r[k].x == r[k].x;
         const unsigned long long b = __ballot(valid);
         const int rank = run_count + __popcll(b & below);
-        if (valid && (!partial || rank < cut_local)) {
+        if (valid && rank < cut_rank) {
           const float t0 = r[k].x * P0 + r[k].y * P1;
           const float t1 = r[k].x * P2 + r[k].y * P3;
           const float q = t0 * r[k].x + t1 * r[k].y;
@@ -619,7 +619,7 @@ __device__ __forceinline__ LevelPairDesc load_desc(const TickItem &it) {
   d.ub_x = c->ub_x, d.ub_y = c->ub_y;
   d.res[0] = s->res[0], d.res[1] = s->res[1];
   d.records = s->records, d.ll_partials = s->ll_partials;
-  d.cut[0] = s->cut[0], d.cut[1] = s->cut[1];
+  d.seg_prefix[0] = s->seg_prefix[0], d.seg_prefix[1] = s->seg_prefix[1];
   return d;
 }
 
@@ -630,9 +630,9 @@ __global__ __launch_bounds__(kBlockThreads, OCC) void k_tick(const TickArgs args
   if (bx >= it.res_blocks + it.ll_blocks) return;
   const LevelPairDesc d = load_desc(it);
   if (bx < it.res_blocks)
-    residual_pass<RMODE, ACC>(it, d, xcd_contiguous_block(bx, it.res_blocks));
+    residual_pass<RMODE, ACC>(it, d, it.res_first + xcd_contiguous_block(bx, it.res_blocks));
   else
-    loglik_pass(it, d, bx - it.res_blocks);
+    loglik_pass(it, d, it.ll_first + (bx - it.res_blocks));
 }
 
 static int g_reduce_mode = -1;  // DVO_AMD_REDUCE=0: ds_bpermute butterfly instead of DPP (debug cross-check)
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const FinArgs args) {
   __shared__ __attribute__((aligned(16))) FinOut sh_out;
 
   DVO_FIN_STAMP(0);
-  const gcf recs = (gcf)it.records;
+  const gcf recs = (gcf)it.records + (size_t)it.block_first * kRecStride;  // the band's first block record
   const int nb = it.records ? it.n_blocks : 0;
   const int per = (nb + kFinSegThreads - 1) / kFinSegThreads;
   if (t < kFinSegThreads) {
@@ -766,31 +766,31 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const FinArgs args) {
       DVO_WAVE_LDS_SYNC();
     }
     if (nb > 0) {
-      const int V = sh_seg[0].c;
       if (t == 0) {
-        sh_out.valid = V;
+        const SegRec &a = sh_seg[0];
+        sh_out.valid = a.c;
         sh_out.has_res = 1;
-        for (int i = 0; i < 3; ++i) sh_out.S[i] = sh_seg[0].s0[i];
+        for (int i = 0; i < 3; ++i) sh_out.S[i] = a.s0[i], sh_out.S_odd[i] = a.s1[i];
+        sh_out.first_w = a.first_w, sh_out.last_r0 = a.l0, sh_out.last_r1 = a.l1, sh_out.pad_f = 0.0f;
       }
-      // wave segment that holds global rank 50*floor(V/50) (Q6 cut of the log-likelihood)
-      const int cutoff = 50 * (V / 50);
-      if (t == 0 && cutoff >= V) it.cut_out[0] = 0x7fffffff, it.cut_out[1] = 0;
+      // exclusive scan of the valid counts over the band's wave segments: the log-likelihood pass needs each pixel's
+      // rank to honour the V % 50 cut (Q6)
       int prefix = sh_cnt[t] - own_total;  // valid pixels before this lane's blocks
-      if (cutoff < V && prefix <= cutoff && cutoff < prefix + own_total) {
-        for (int b = t * per; b < (t + 1) * per && b < nb; ++b) {
-          const v4f h2 = reinterpret_cast<gcf4>(recs + (size_t)b * kRecStride)[2];
-          const v4f h3 = reinterpret_cast<gcf4>(recs + (size_t)b * kRecStride)[3];
-          const int cw[4] = {(int)f2u(h2.z), (int)f2u(h2.w), (int)f2u(h3.x), (int)f2u(h3.y)};
-          for (int k = 0; k < 4; ++k) {
-            if (prefix <= cutoff && cutoff < prefix + cw[k]) it.cut_out[0] = b * kWavesPerBlock + k, it.cut_out[1] = cutoff - prefix;
-            prefix += cw[k];
-          }
+      DVO_GLOBAL int *sp = (DVO_GLOBAL int *)it.seg_prefix_out + (size_t)it.block_first * kWavesPerBlock;
+      for (int b = t * per; b < (t + 1) * per && b < nb; ++b) {
+        const v4f h2 = reinterpret_cast<gcf4>(recs + (size_t)b * kRecStride)[2];
+        const v4f h3 = reinterpret_cast<gcf4>(recs + (size_t)b * kRecStride)[3];
+        const int cw[4] = {(int)f2u(h2.z), (int)f2u(h2.w), (int)f2u(h3.x), (int)f2u(h3.y)};
+        for (int k = 0; k < 4; ++k) {
+          sp[b * kWavesPerBlock + k] = prefix;
+          prefix += cw[k];
         }
       }
     } else if (t == 0) {
       sh_out.valid = 0;
       sh_out.has_res = 0;
-      for (int i = 0; i < 3; ++i) sh_out.S[i] = 0.0;
+      for (int i = 0; i < 3; ++i) sh_out.S[i] = 0.0, sh_out.S_odd[i] = 0.0;
+      sh_out.first_w = sh_out.last_r0 = sh_out.last_r1 = sh_out.pad_f = 0.0f;
     }
   } else if (t >= kFinAccFirst) {
     // moments: 16-byte loads (4 columns), rows strided by the 32 chunks, four independent loads in flight per thread
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const FinArgs args) {
     } else {
       // the two spare column groups x 32 chunks sum the log-likelihood partials
       const int lane64 = chunk * 2 + (c4 - (kNumAcc + 3) / 4);
-      const DVO_GLOBAL double *llp = (const DVO_GLOBAL double *)it.ll_partials;
+      const DVO_GLOBAL double *llp = (const DVO_GLOBAL double *)it.ll_partials + it.ll_first;
       for (int b = lane64; b < it.n_ll_blocks; b += kFinChunks * 2) s0 += llp[b];
     }
     sh_acc[chunk][c4 * 4 + 0] = s0, sh_acc[chunk][c4 * 4 + 1] = s1;
@@ -848,6 +848,7 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const FinArgs args) {
     v4f *dst = reinterpret_cast<v4f *>(it.out);
     if (t >= 1 && t < kPieces) dst[t] = src[t];
     if (t == 0) it.out->valid = sh_out.valid, it.out->has_res = sh_out.has_res, it.out->has_ll = sh_out.has_ll;
+    if (it.out_dev && t < kPieces) ((DVO_GLOBAL v4f *)it.out_dev)[t] = src[t];  // multi-GPU exchange buffer
     DVO_FIN_STAMP(3);
     __threadfence_system();
     DVO_FIN_STAMP(4);

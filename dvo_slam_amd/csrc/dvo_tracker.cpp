@@ -321,7 +321,7 @@ struct JobSlot {
   float2 *res[2] = {nullptr, nullptr};
   float *records = nullptr;
   double *ll_partials = nullptr;
-  int *cut[2] = {nullptr, nullptr};
+  int *seg_prefix[2] = {nullptr, nullptr};
   FinOut *out = nullptr;      // pinned host memory, device-visible
   FinOut *out_dev = nullptr;  // device staging of the record
   void *dev_block = nullptr;
@@ -366,6 +366,7 @@ struct IterCtx {
   int n = 0;
   float cov[4], P[4];
   double A[36], b[6], x_new[6], prior = 0.0;
+  int cut_rank = 0;  // 50 * floor(n / 50): the likelihood keeps the valid residuals ranked below it (Q6)
   bool cont = false;
   int stats_index = -1;
 };
@@ -518,6 +519,7 @@ void process_residual(Job &j, IterCtx &it, const FinOut &o) {
   dvo_amd_iteration_stats *e = stats_push(j);
   e->id = it.k;
   it.n = o.valid;
+  it.cut_rank = 50 * (it.n / 50);
   e->valid_constraints = it.n;
   it.stats_index = j.result->n_iterations - 1;
   if (it.n < 6) {  // :276-284
@@ -643,9 +645,9 @@ int ensure_slots(dvo_amd_context *ctx, int n_jobs, int n_pad) {
   const size_t b_res = align_up(sizeof(float2) * new_pad, 256);
   const size_t b_rec = align_up(sizeof(float) * kRecStride * max_blocks, 256);
   const size_t b_ll = align_up(sizeof(double) * max_blocks, 256);
-  const size_t b_cut = 256;
+  const size_t b_sp = align_up(sizeof(int) * kWavesPerBlock * max_blocks, 256);
   const size_t b_out = align_up(sizeof(FinOut), 256);
-  const size_t total = 2 * b_res + b_rec + b_ll + 2 * b_cut + b_out;
+  const size_t total = 2 * b_res + b_rec + b_ll + 2 * b_sp + b_out;
   ctx->slots.resize(n_slots);
   for (int i = 0; i < n_slots; ++i) {
     JobSlot &s = ctx->slots[i];
@@ -655,8 +657,8 @@ int ensure_slots(dvo_amd_context *ctx, int n_jobs, int n_pad) {
     s.res[1] = (float2 *)p, p += b_res;
     s.records = (float *)p, p += b_rec;
     s.ll_partials = (double *)p, p += b_ll;
-    s.cut[0] = (int *)p, p += b_cut;
-    s.cut[1] = (int *)p, p += b_cut;
+    s.seg_prefix[0] = (int *)p, p += b_sp;
+    s.seg_prefix[1] = (int *)p, p += b_sp;
     s.out_dev = (FinOut *)p, p += b_out;
     FinOut *dev_out = nullptr;
     HIP_TRY(hipHostGetDevicePointer((void **)&dev_out, ctx->out_host + i, 0));
@@ -665,7 +667,7 @@ int ensure_slots(dvo_amd_context *ctx, int n_jobs, int n_pad) {
     SlotDesc &sd = slot_host[(size_t)i];
     sd.res[0] = s.res[0], sd.res[1] = s.res[1];
     sd.records = s.records, sd.ll_partials = s.ll_partials;
-    sd.cut[0] = s.cut[0], sd.cut[1] = s.cut[1];
+    sd.seg_prefix[0] = s.seg_prefix[0], sd.seg_prefix[1] = s.seg_prefix[1];
   }
   HIP_TRY(hipMemcpy(ctx->slot_desc, slot_host.data(), sizeof(SlotDesc) * n_slots, hipMemcpyHostToDevice));
   ctx->tick_seq = 0;
@@ -775,12 +777,14 @@ int run_tick(dvo_amd_context *ctx, std::vector<Job> &jobs) {
     w.cur = j.cur->cur_desc + j.level;
     w.slot = ctx->slot_desc + slot_index;
     FinItem f;
-    f.records = nullptr, f.n_blocks = 0, f.n_ll_blocks = 0, f.ll_partials = j.slot->ll_partials;
-    f.cut_out = j.slot->cut[0], f.out = j.slot->out, f.out_dev = j.slot->out_dev, f.seq = seq, f.pad = 0;
+    f.records = nullptr, f.n_blocks = 0, f.block_first = 0, f.n_ll_blocks = 0, f.ll_first = 0;
+    f.ll_partials = j.slot->ll_partials;
+    f.seg_prefix_out = j.slot->seg_prefix[0], f.out = j.slot->out, f.out_dev = nullptr, f.seq = seq, f.pad = 0;
     if (j.have_a) {
       w.ll_blocks = j.a.n_blocks;
       w.ll_rounds = j.a.rounds;
       w.ll_buf = j.a.buf;
+      w.ll_cut_rank = j.a.cut_rank;
       std::memcpy(w.P_ll, j.a.P, sizeof(w.P_ll));
       f.n_ll_blocks = w.ll_blocks;
       j.sub_ll = true;
@@ -798,7 +802,7 @@ int run_tick(dvo_amd_context *ctx, std::vector<Job> &jobs) {
       std::memcpy(w.P_res, j.have_a ? j.a.P : j.precision, sizeof(w.P_res));
       f.records = j.slot->records;
       f.n_blocks = w.res_blocks;
-      f.cut_out = j.slot->cut[j.b.buf];
+      f.seg_prefix_out = j.slot->seg_prefix[j.b.buf];
       j.sub_res = true;
       j.result->n_residual_passes++;
       j.alg_px += (double)j.ref->selections[j.sel].count[j.level];
@@ -1192,9 +1196,10 @@ int dvo_amd_residuals(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_
   fa.items[0].n_blocks = w.res_blocks;
   fa.items[0].n_ll_blocks = 0;
   fa.items[0].ll_partials = s.ll_partials;
-  fa.items[0].cut_out = s.cut[0];
+  fa.items[0].seg_prefix_out = s.seg_prefix[0];
+  fa.items[0].block_first = 0, fa.items[0].ll_first = 0;
   fa.items[0].out = s.out;
-  fa.items[0].out_dev = s.out_dev;
+  fa.items[0].out_dev = nullptr;
   fa.ticket = ctx->tickets;
   fa.items[0].seq = ++ctx->tick_seq;
   fa.items[0].pad = 0;

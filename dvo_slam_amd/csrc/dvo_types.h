@@ -49,7 +49,7 @@ struct SlotDesc {  // one per job slot of a context: scratch of the pair being a
   float2 *res[2];       // residual buffers (double buffered by iteration parity), NaN = invalid
   float *records;       // residual pass: n_blocks x kRecStride floats
   double *ll_partials;  // log-likelihood pass: one double per block
-  int *cut[2];          // {cut_seg, cut_local} of the residual pass that filled res[i]
+  int *seg_prefix[2];   // per wave segment: valid pixels before it within its band, for the pass that filled res[i]
 };
 
 // One job's device work of a tick, passed by value in the kernel arguments (no H2D copy per iteration):
@@ -59,17 +59,18 @@ struct TickItem {
   const RefLevelDesc *ref;
   const CurLevelDesc *cur;
   const SlotDesc *slot;
-  int res_blocks, ll_blocks;
+  int res_blocks, ll_blocks;  // blocks this item runs (a band of the level when the pair is sharded)
+  int res_first, ll_first;    // first logical block of the band (0 for the whole level)
   int res_rounds, ll_rounds;  // rounds per wave
   int res_buf, ll_buf;        // which residual buffer is written / read
   int unit_weights;           // first iteration on a level: weights = 1 (dense_tracking.cpp:286-289)
-  int pad;
+  int ll_cut_rank;            // log-likelihood pass: keep valid pixels whose rank within the band is below this (Q6)
   float kt[12];               // K * T[0:3,0:4], row-major, float (dense_tracking_impl.cpp:142-152)
   float P_res[4];             // precision of the previous iteration (weights), column-major
   float P_ll[4];              // precision of the iteration whose likelihood is evaluated
 };
 
-constexpr int kMaxItemsPerLaunch = 27;
+constexpr int kMaxItemsPerLaunch = 26;
 struct TickArgs {
   int n_items;
   int pad;
@@ -83,25 +84,26 @@ struct FinOut {
   int has_res;     // a residual pass was reduced
   int has_ll;
   unsigned seq;    // written last (system scope): the tick number this record belongs to
-  double S[3];     // sum over pairs (w_2j + w_2j+1) r_2j r_2j^T  (xx, xy, yy), unscaled (Q5 pairing)
+  double S[3];     // sum over pairs (w_2j + w_2j+1) r_2j r_2j^T  (xx, xy, yy), unscaled (Q5 pairing), band starts even
+  double S_odd[3]; // the same if the band's first valid pixel had an odd global rank (used when bands are combined)
+  float first_w, last_r0, last_r1, pad_f;  // boundary data of the band for the ordered combine
   double acc[kNumAcc];
   double ll_sum;   // sum of log(1 + 0.2 r^T P r) over the first 50*floor(V/50) valid residuals (Q6)
-  double pad_to_16;
 };
 static_assert(sizeof(FinOut) % 16 == 0, "FinOut is copied to the host in 16-byte pieces");
 
 struct FinItem {
-  const float *records;   // residual-pass block records (or null)
-  int n_blocks;
-  int n_ll_blocks;
+  const float *records;   // residual-pass block records (or null), indexed by logical block of the level
+  int n_blocks, block_first;      // the band this item reduces
+  int n_ll_blocks, ll_first;
   const double *ll_partials;
-  int *cut_out;           // {cut_seg, cut_local} for the residual pass just reduced
+  int *seg_prefix_out;    // per wave segment of the band: valid pixels before it (exclusive scan from the band start)
   FinOut *out;            // host (pinned, device-visible): where the record is published
-  FinOut *out_dev;        // device staging of the same record
+  FinOut *out_dev;        // optional device copy of the record (multi-GPU exchange), or null
   unsigned seq;
   unsigned pad;
 };
-constexpr int kMaxFinItems = 56;  // 56 B each
+constexpr int kMaxFinItems = 48;  // 64 B each
 struct FinArgs {
   int n_items;
   int pad;
