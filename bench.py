@@ -36,6 +36,10 @@ def parse():
     ap.add_argument("--distinct", type=int, default=8, help="distinct current frames cycled through the batch")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tile-shard", action="store_true",
+                    help="BASELINE config 4 instead of the default: ONE pair at a time, every level tile-sharded over the "
+                         "N GPUs with a per-iteration RCCL all-gather of the band records (strong scaling, expected to be "
+                         "slower than 1 GPU at 640x480: a tick is ~26 us, so is a small-message all-gather)")
     ap.add_argument("--prime", type=int, default=2,
                     help="untimed priming steps run as part of set-up before the W warm-up steps: the first calls grow "
                          "scratch buffers, streams and the HIP runtime's internal pools (a one-off ~40 ms stall)")
@@ -82,6 +86,10 @@ def main():
     ref = capi.RgbdImagePyramid(ref_frame[0], ref_frame[1], K, levels, device=device)
     curs = [capi.RgbdImagePyramid(f[0], f[1], K, levels, device=device) for f in cur_frames]
     prep_ms = (time.perf_counter() - t0) * 1e3 / (1 + len(curs))
+    if args.tile_shard:
+        return tile_shard_bench(args, capi, synth, sharding, dist, rank, world, device, ref_frame, cur_frames, K, levels,
+                                first_level)
+
     import threading
 
     T = max(1, min(args.threads, args.batch))
@@ -210,6 +218,59 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, ref_frame, cur_frames, K, levels, first_level)
         print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def tile_shard_bench(args, capi, synth, sharding, dist, rank, world, device, ref_frame, cur_frames, K, levels, first_level):
+    """Strong scaling of one pair: every rank holds the same two pyramids and aligns band `rank` of every level."""
+    import numpy as np
+
+    # every rank must hold the SAME frames: regenerate them rank-independently
+    ref_frame = synth.render(args.width, args.height, None, frame_id=0)
+    cur_frames = [synth.render(args.width, args.height, synth.se3_exp(synth.XI_GT_PAIR * (0.6 + 0.1 * i)), frame_id=1 + 2 * i)
+                  for i in range(4)]
+    ref = capi.RgbdImagePyramid(ref_frame[0], ref_frame[1], K, levels, device=device)
+    curs = [capi.RgbdImagePyramid(f[0], f[1], K, levels, device=device) for f in cur_frames]
+    trk = capi.DenseTracker(capi.Config(FirstLevel=first_level, LastLevel=0), device=device)
+    ids = [capi.comm_unique_id() if rank == 0 else None]
+    if dist is not None:
+        dist.broadcast_object_list(ids, src=0)
+    trk.comm_create(ids[0], world, rank)
+    pairs_per_step = 8
+    for _ in range(args.warmup + 1):
+        for i in range(pairs_per_step):
+            trk.match_sharded(ref, curs[i % len(curs)])
+    if dist is not None:
+        import torch
+
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ticks = 0
+    for _ in range(args.steps):
+        for i in range(pairs_per_step):
+            r = trk.match_sharded(ref, curs[i % len(curs)])
+            ticks += r.n_ticks
+    if dist is not None:
+        import torch
+
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    elapsed, _ = sharding.aggregate(elapsed, 0, dist, "cuda" if dist is not None else None)
+    n_pairs = pairs_per_step * args.steps  # the SAME pairs on every rank: total work is fixed
+    if rank == 0:
+        print(json.dumps({
+            "metric": "frame-pairs/s (640x480, 4-level GN align)", "value": n_pairs / elapsed, "unit": "frame-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ONE synthetic {args.width}x{args.height} pair at a time, every pyramid level tile-sharded "
+                                   f"over {world} GPU(s) (bands of scan-order blocks), per-tick RCCL all-gather of the "
+                                   f"784-byte band records, {pairs_per_step} pairs per step",
+                       "sharding": "tile-shard with per-iteration all-gather (BASELINE config 4)"},
+            "us_per_tick": elapsed * 1e6 / max(ticks, 1),
+        }), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

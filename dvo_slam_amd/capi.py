@@ -27,7 +27,8 @@ EXPORTS = [
     "dvo_amd_pyramid_download_plane", "dvo_amd_pyramid_select", "dvo_amd_match", "dvo_amd_match_batch",
     "dvo_amd_residuals", "dvo_amd_error_image", "dvo_amd_kernel_timing", "dvo_amd_se3_exp", "dvo_amd_se3_log",
     "dvo_amd_solve6", "dvo_amd_bench_residual_pass", "dvo_amd_match_many",
-    "dvo_amd_debug_finalize_stamps",
+    "dvo_amd_debug_finalize_stamps", "dvo_amd_comm_unique_id", "dvo_amd_comm_create", "dvo_amd_comm_destroy",
+    "dvo_amd_match_sharded", "dvo_amd_match_banded", "dvo_amd_debug_combine_bands",
 ]
 
 
@@ -125,6 +126,13 @@ def lib():
     L.dvo_amd_bench_residual_pass.argtypes = [vp, vp, vp, C.c_int, fp, C.c_int, C.c_int, C.c_int, dp, dp,
                                               C.POINTER(C.c_int)]
     L.dvo_amd_debug_finalize_stamps.argtypes = [vp, C.POINTER(C.c_ulonglong)]
+    L.dvo_amd_comm_unique_id.argtypes = [C.POINTER(C.c_ubyte)]
+    L.dvo_amd_comm_create.argtypes = [vp, C.POINTER(C.c_ubyte), C.c_int, C.c_int]
+    L.dvo_amd_comm_destroy.argtypes = [vp]
+    L.dvo_amd_comm_destroy.restype = None
+    L.dvo_amd_match_sharded.argtypes = [vp, vp, vp, dp, C.POINTER(CResult)]
+    L.dvo_amd_match_banded.argtypes = [vp, vp, vp, dp, C.POINTER(CResult), C.c_int]
+    L.dvo_amd_debug_combine_bands.argtypes = [C.c_int, dp, dp]
     L.dvo_amd_se3_exp.argtypes = [dp, dp]
     L.dvo_amd_se3_exp.restype = None
     L.dvo_amd_se3_log.argtypes = [dp, dp]
@@ -335,6 +343,31 @@ class DenseTracker:
             return [Result(res[i], None) for i in range(n)]
         return [Result(res[i], its[i]) for i in range(n)]
 
+    def match_banded(self, reference: RgbdImagePyramid, current: RgbdImagePyramid, n_bands: int, T_init=None) -> Result:
+        """The tile-shard pipeline with all n_bands bands on this one GPU (verification of the multi-GPU path)."""
+        res, its = self._alloc_results(1)
+        T0 = None
+        if T_init is not None:
+            T0a = np.ascontiguousarray(np.asarray(T_init, dtype=np.float64).T)
+            T0 = T0a.ctypes.data_as(C.POINTER(C.c_double))
+        _check(lib().dvo_amd_match_banded(self._h, reference._h, current._h, T0, C.byref(res[0]), n_bands), "dvo_amd_match_banded")
+        return Result(res[0], its[0])
+
+    def comm_create(self, unique_id: bytes, nranks: int, rank: int):
+        """Attach an RCCL communicator (one rank per GPU) for match_sharded."""
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        _check(lib().dvo_amd_comm_create(self._h, buf, nranks, rank), "dvo_amd_comm_create")
+
+    def match_sharded(self, reference: RgbdImagePyramid, current: RgbdImagePyramid, T_init=None) -> Result:
+        """One pair tile-sharded over the communicator's ranks; every rank calls this with the same arguments."""
+        res, its = self._alloc_results(1)
+        T0 = None
+        if T_init is not None:
+            T0a = np.ascontiguousarray(np.asarray(T_init, dtype=np.float64).T)
+            T0 = T0a.ctypes.data_as(C.POINTER(C.c_double))
+        _check(lib().dvo_amd_match_sharded(self._h, reference._h, current._h, T0, C.byref(res[0])), "dvo_amd_match_sharded")
+        return Result(res[0], its[0])
+
     def residuals(self, reference: RgbdImagePyramid, current: RgbdImagePyramid, level: int, T):
         """computeResidualsAndValidFlagsSse: (residuals[h, w, 2] with NaN = invalid, n_valid)."""
         w, h, _ = reference.level_info(level)
@@ -389,3 +422,18 @@ def solve6(A, b) -> np.ndarray:
     dp = C.POINTER(C.c_double)
     lib().dvo_amd_solve6(Ac.ctypes.data_as(dp), bc.ctypes.data_as(dp), x.ctypes.data_as(dp))
     return x
+
+
+def comm_unique_id() -> bytes:
+    buf = (C.c_ubyte * 128)()
+    _check(lib().dvo_amd_comm_unique_id(buf), "dvo_amd_comm_unique_id")
+    return bytes(buf)
+
+
+def combine_bands(bands) -> np.ndarray:
+    """bands: [n, 10] = {valid, first_w, last_r0, last_r1, S[3], S_odd[3]} -> {valid, S[3], S_odd[3]} (host only)."""
+    b = np.ascontiguousarray(bands, dtype=np.float64)
+    out = np.zeros(7)
+    dp = C.POINTER(C.c_double)
+    _check(lib().dvo_amd_debug_combine_bands(b.shape[0], b.ctypes.data_as(dp), out.ctypes.data_as(dp)), "combine_bands")
+    return out

@@ -9,6 +9,8 @@
 //
 // The 6x6 solve, SE(3) exp/log and the 2x2 inverse stay on the host (se3.h), as in the reference.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <atomic>
@@ -339,6 +341,13 @@ struct dvo_amd_context {
   int out_capacity = 0;
   SlotDesc *slot_desc = nullptr;       // device, [slot]
   unsigned *tickets = nullptr;         // device, one arrival counter per tick stream
+  // tile-shard exchange (RCCL, loaded with dlopen so that single-GPU users do not depend on it)
+  void *rccl_lib = nullptr;
+  ncclComm_t comm = nullptr;
+  int comm_ranks = 0, comm_rank = 0;
+  FinOut *gather_dev = nullptr, *gather_host = nullptr;
+  ncclResult_t (*p_allgather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*p_comm_destroy)(ncclComm_t) = nullptr;
   unsigned tick_seq = 0;
   bool fin_stamps = false;             // DVO_AMD_FIN_STAMPS=1: k_finalize records phase stamps (diagnostic)
   bool poll = true;                    // wait for a tick by polling the records' sequence words instead of hipStreamSynchronize
@@ -351,6 +360,8 @@ struct dvo_amd_context {
 };
 
 namespace {
+
+constexpr int kMaxBands = 16;
 
 // one Gauss-Newton iteration whose residual pass has been submitted
 struct IterCtx {
@@ -367,6 +378,7 @@ struct IterCtx {
   float cov[4], P[4];
   double A[36], b[6], x_new[6], prior = 0.0;
   int cut_rank = 0;  // 50 * floor(n / 50): the likelihood keeps the valid residuals ranked below it (Q6)
+  int band_valid[kMaxBands];  // valid constraints per band of this iteration's residual pass (sharded pairs only)
   bool cont = false;
   int stats_index = -1;
 };
@@ -879,6 +891,177 @@ int check_config(const dvo_amd_config *c) {
   return DVO_AMD_OK;
 }
 
+
+// ---- one pair tile-sharded into bands of scan-order blocks (BASELINE config 4) ---------------------------------------
+// Band i of n covers blocks [nb*i/n, nb*(i+1)/n) of the level.  Per-pixel work is independent given the pose; what
+// couples the bands is exactly what couples blocks inside one GPU: the ordered fold of (count, pair-quirk scale sums under
+// both start parities, boundary weight / residual) and the plain sums of the 87 moments and of the likelihood.  So the
+// exchange per tick is one record (FinOut, 784 B) per band, combined left to right in band order on every rank.
+void band_range(int nb, int n_bands, int b, int *first, int *count) {
+  const int lo = (int)((long long)nb * b / n_bands), hi = (int)((long long)nb * (b + 1) / n_bands);
+  *first = lo, *count = hi - lo;
+}
+
+void combine_bands(const FinOut *const *recs, int n, FinOut &out) {
+  std::memset(&out, 0, sizeof(out));
+  int c = 0;
+  double s0[3] = {0, 0, 0}, s1[3] = {0, 0, 0};
+  float fw = 0.0f, l0 = 0.0f, l1 = 0.0f;
+  for (int b = 0; b < n; ++b) {
+    const FinOut &r = *recs[b];
+    out.has_res |= r.has_res, out.has_ll |= r.has_ll;
+    for (int i = 0; i < kNumAcc; ++i) out.acc[i] += r.acc[i];
+    out.ll_sum += r.ll_sum;
+    if (!r.has_res || r.valid == 0) continue;
+    if (c == 0) {
+      for (int i = 0; i < 3; ++i) s0[i] = r.S[i], s1[i] = r.S_odd[i];
+      fw = r.first_w;
+    } else {
+      const bool flip = (c & 1) != 0;  // the band starts on the opposite parity of everything before it
+      const double R[3] = {(double)l0 * l0, (double)l0 * l1, (double)l1 * l1};
+      for (int i = 0; i < 3; ++i) {
+        double n0 = s0[i] + (flip ? r.S_odd[i] : r.S[i]);
+        double n1 = s1[i] + (flip ? r.S[i] : r.S_odd[i]);
+        // the band's first pixel is a pair-second under exactly one hypothesis: there it weights the previous last residual
+        (flip ? n0 : n1) += (double)r.first_w * R[i];
+        s0[i] = n0, s1[i] = n1;
+      }
+    }
+    l0 = r.last_r0, l1 = r.last_r1;
+    c += r.valid;
+  }
+  out.valid = c;
+  for (int i = 0; i < 3; ++i) out.S[i] = s0[i], out.S_odd[i] = s1[i];
+  out.first_w = fw, out.last_r0 = l0, out.last_r1 = l1;
+}
+
+int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, int n_local, bool exchange) {
+  const unsigned seq = ++ctx->tick_seq;
+  if (!j.have_a && !j.have_b) return DVO_AMD_OK;
+  const int nb_level = blocks_for(j.ref->lv[j.level].n, 1);  // one round per wave: identical segments for every band count
+  TickArgs ta;
+  FinArgs fa;
+  std::memset(&ta, 0, sizeof(ta));
+  std::memset(&fa, 0, sizeof(fa));
+  fa.ticket = ctx->tickets;
+  j.sub_ll = j.have_a, j.sub_res = j.have_b;
+  if (j.have_b) {
+    j.b.rounds = 1, j.b.n_blocks = nb_level;
+    j.result->n_residual_passes++;
+    j.alg_px += (double)j.ref->selections[j.sel].count[j.level];
+  }
+  j.result->n_ticks++;
+  int max_blocks = 0;
+  for (int li = 0; li < n_local; ++li) {
+    const int band = band_first + li;
+    TickItem &w = ta.items[li];
+    w.ref = j.ref->selections[j.sel].ref_desc + j.level;
+    w.cur = j.cur->cur_desc + j.level;
+    w.slot = ctx->slot_desc;  // every band works in slot 0's buffers (logical block indexing), disjoint ranges
+    FinItem &f = fa.items[li];
+    f.ll_partials = ctx->slots[0].ll_partials;
+    f.seg_prefix_out = ctx->slots[0].seg_prefix[0];
+    f.out = ctx->slots[(size_t)li].out;
+    f.out_dev = exchange ? ctx->slots[(size_t)li].out_dev : nullptr;
+    f.seq = seq;
+    if (j.have_a) {
+      band_range(j.a.n_blocks, n_bands, band, &w.ll_first, &w.ll_blocks);
+      w.ll_rounds = 1, w.ll_buf = j.a.buf;
+      int before = 0;
+      for (int b = 0; b < band; ++b) before += j.a.band_valid[b];
+      w.ll_cut_rank = j.a.cut_rank - before;  // rank inside the band below which residuals enter the likelihood
+      std::memcpy(w.P_ll, j.a.P, sizeof(w.P_ll));
+      f.n_ll_blocks = w.ll_blocks, f.ll_first = w.ll_first;
+    }
+    if (j.have_b) {
+      band_range(nb_level, n_bands, band, &w.res_first, &w.res_blocks);
+      w.res_rounds = 1, w.res_buf = j.b.buf;
+      w.unit_weights = j.b.k == 0 ? 1 : 0;
+      make_kt(j.cur->lv[j.level], j.b.estimate_after, w.kt);
+      std::memcpy(w.P_res, j.have_a ? j.a.P : j.precision, sizeof(w.P_res));
+      f.records = ctx->slots[0].records;
+      f.n_blocks = w.res_blocks, f.block_first = w.res_first;
+      f.seg_prefix_out = ctx->slots[0].seg_prefix[j.b.buf];
+    }
+    max_blocks = std::max(max_blocks, w.res_blocks + w.ll_blocks);
+  }
+  ta.n_items = n_local, fa.n_items = n_local;
+  hipError_t e = launch_tick(ta, std::max(max_blocks, 1), ctx->stream);
+  if (e != hipSuccess) return fail_hip("launch_tick", e);
+  e = launch_finalize(fa, ctx->stream);
+  if (e != hipSuccess) return fail_hip("launch_finalize", e);
+
+  const FinOut *recs[kMaxBands];
+  if (exchange) {
+    // per-iteration RCCL all-gather of the band records over xGMI, then one D2H copy of all of them
+    if (ctx->p_allgather(ctx->slots[0].out_dev, ctx->gather_dev, sizeof(FinOut), ncclChar, ctx->comm, ctx->stream) != ncclSuccess) {
+      g_last_error = "ncclAllGather failed";
+      return DVO_AMD_ERR_COMM;
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->gather_host, ctx->gather_dev, sizeof(FinOut) * (size_t)n_bands, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int b = 0; b < n_bands; ++b) recs[b] = ctx->gather_host + b;
+  } else {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int b = 0; b < n_bands; ++b) recs[b] = ctx->out_host + b;
+  }
+  FinOut comb;
+  combine_bands(recs, n_bands, comb);
+  if (j.sub_res)
+    for (int b = 0; b < n_bands; ++b) j.b.band_valid[b] = recs[b]->valid;
+  if (j.sub_ll) {
+    process_loglik(j, &comb);
+  } else {
+    IterCtx bcopy = j.b;
+    process_residual(j, bcopy, comb);
+  }
+  return DVO_AMD_OK;
+}
+
+int match_one_banded(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, const double *T_init,
+                     dvo_amd_result *result, int n_bands, int band_first, int n_local, bool exchange) {
+  if (!ctx || !reference || !current || !result || n_bands < 1 || n_bands > kMaxBands || n_local < 1 ||
+      band_first < 0 || band_first + n_local > n_bands || n_local > kMaxItemsPerLaunch)
+    return DVO_AMD_ERR_INVALID_ARGUMENT;
+  const dvo_amd_config &cfg = ctx->cfg;
+  int rc = check_config(&cfg);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (reference->device != ctx->device || current->device != ctx->device) return DVO_AMD_ERR_DEVICE_MISMATCH;
+  if (reference->n_levels < cfg.first_level + 1 || current->n_levels < cfg.first_level + 1) return DVO_AMD_ERR_TOO_FEW_LEVELS;
+  for (int l = cfg.last_level; l <= cfg.first_level; ++l)
+    if (reference->lv[l].w != current->lv[l].w || reference->lv[l].h != current->lv[l].h) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  if (cfg.use_initial_estimate) {
+    if (!T_init) return DVO_AMD_ERR_INVALID_ARGUMENT;
+    double s = 0.0;
+    for (int k = 0; k < 16; ++k) s += T_init[k];
+    if (!std::isfinite(s)) return DVO_AMD_ERR_NAN_INIT;
+  }
+  const int its_needed = (cfg.first_level - cfg.last_level + 1) * (cfg.max_iterations_per_level + 1);
+  if (result->iterations && result->iterations_capacity > 0 && result->iterations_capacity < its_needed) return DVO_AMD_ERR_CAPACITY;
+  rc = ensure_slots(ctx, std::max(n_local, n_bands), reference->lv[cfg.last_level].n_pad);
+  if (rc) return rc;
+  Job j;
+  j.ref = reference, j.cur = current, j.result = result, j.slot = &ctx->slots[0], j.cfg = &ctx->cfg;
+  rc = pyramid_selection(j.ref, cfg.intensity_derivative_threshold, cfg.depth_derivative_threshold, &j.sel);
+  if (rc) return rc;
+  result->n_levels = 0, result->n_iterations = 0, result->n_ticks = 0, result->n_residual_passes = 0;
+  result->alg_bytes = 0.0, result->is_nan = 0;
+  if (!result->iterations) result->iterations_capacity = 0;
+  j.inc = cfg.use_initial_estimate ? se3_from_matrix(T_init) : SE3::identity();
+  j.initial = j.inc;
+  j.estimate = SE3::identity();
+  j.level = cfg.first_level;
+  j.done = false;
+  for (int b = 0; b < kMaxBands; ++b) j.a.band_valid[b] = j.b.band_valid[b] = 0;
+  start_level(j);
+  while (!j.done) {
+    rc = run_tick_banded(ctx, j, n_bands, band_first, n_local, exchange);
+    if (rc) return rc;
+  }
+  return DVO_AMD_OK;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -957,6 +1140,7 @@ void dvo_amd_context_destroy(dvo_amd_context *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  dvo_amd_comm_destroy(ctx);
   for (hipStream_t st : ctx->extra_streams) {
     (void)hipStreamSynchronize(st);
     (void)hipStreamDestroy(st);
@@ -1149,6 +1333,97 @@ int dvo_amd_match_many(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *refe
 int dvo_amd_match_batch(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *references, dvo_amd_pyramid *const *currents,
                         const double *T_inits, dvo_amd_result *results) {
   return dvo_amd_match_many(ctx, n, references, currents, T_inits, results, 0);
+}
+
+int dvo_amd_match_banded(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, const double *T_init,
+                         dvo_amd_result *result, int n_bands) {
+  return match_one_banded(ctx, reference, current, T_init, result, n_bands, 0, n_bands, false);
+}
+
+int dvo_amd_comm_unique_id(unsigned char *id128) {
+  if (!id128) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) {
+    g_last_error = std::string("dlopen librccl: ") + dlerror();
+    return DVO_AMD_ERR_COMM;
+  }
+  auto get_id = (ncclResult_t(*)(ncclUniqueId *))dlsym(lib, "ncclGetUniqueId");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId id;
+  if (!get_id || get_id(&id) != ncclSuccess) {
+    g_last_error = "ncclGetUniqueId failed";
+    return DVO_AMD_ERR_COMM;
+  }
+  std::memcpy(id128, &id, 128);
+  return DVO_AMD_OK;
+}
+
+int dvo_amd_comm_create(dvo_amd_context *ctx, const unsigned char *id128, int nranks, int rank) {
+  if (!ctx || !id128 || nranks < 1 || nranks > kMaxBands || rank < 0 || rank >= nranks) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  if (ctx->comm) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(ctx->device));
+  ctx->rccl_lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!ctx->rccl_lib) ctx->rccl_lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!ctx->rccl_lib) {
+    g_last_error = std::string("dlopen librccl: ") + dlerror();
+    return DVO_AMD_ERR_COMM;
+  }
+  auto init_rank = (ncclResult_t(*)(ncclComm_t *, int, ncclUniqueId, int))dlsym(ctx->rccl_lib, "ncclCommInitRank");
+  ctx->p_allgather = (decltype(ctx->p_allgather))dlsym(ctx->rccl_lib, "ncclAllGather");
+  ctx->p_comm_destroy = (decltype(ctx->p_comm_destroy))dlsym(ctx->rccl_lib, "ncclCommDestroy");
+  if (!init_rank || !ctx->p_allgather || !ctx->p_comm_destroy) {
+    g_last_error = "librccl lacks ncclCommInitRank / ncclAllGather / ncclCommDestroy";
+    return DVO_AMD_ERR_COMM;
+  }
+  ncclUniqueId id;
+  std::memcpy(&id, id128, 128);
+  if (init_rank(&ctx->comm, nranks, id, rank) != ncclSuccess) {
+    ctx->comm = nullptr;
+    g_last_error = "ncclCommInitRank failed";
+    return DVO_AMD_ERR_COMM;
+  }
+  ctx->comm_ranks = nranks, ctx->comm_rank = rank;
+  HIP_TRY(hipMalloc((void **)&ctx->gather_dev, sizeof(FinOut) * kMaxBands));
+  HIP_TRY(hipHostMalloc((void **)&ctx->gather_host, sizeof(FinOut) * kMaxBands, hipHostMallocDefault));
+  return DVO_AMD_OK;
+}
+
+void dvo_amd_comm_destroy(dvo_amd_context *ctx) {
+  if (!ctx || !ctx->comm) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  ctx->p_comm_destroy(ctx->comm);
+  ctx->comm = nullptr;
+  if (ctx->gather_dev) (void)hipFree(ctx->gather_dev);
+  if (ctx->gather_host) (void)hipHostFree(ctx->gather_host);
+  ctx->gather_dev = nullptr, ctx->gather_host = nullptr;
+}
+
+int dvo_amd_match_sharded(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, const double *T_init,
+                          dvo_amd_result *result) {
+  if (!ctx || !ctx->comm) return DVO_AMD_ERR_COMM;
+  return match_one_banded(ctx, reference, current, T_init, result, ctx->comm_ranks, ctx->comm_rank, 1, true);
+}
+
+int dvo_amd_debug_combine_bands(int n_bands, const double *bands, double *out) {
+  // bands: n x {valid, first_w, last_r0, last_r1, S[3], S_odd[3]} = 10 doubles each; out: {valid, S[3], S_odd[3]}
+  if (n_bands < 1 || n_bands > 4096 || !bands || !out) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  std::vector<FinOut> recs((size_t)n_bands);
+  std::vector<const FinOut *> ptrs((size_t)n_bands);
+  for (int b = 0; b < n_bands; ++b) {
+    FinOut &r = recs[(size_t)b];
+    std::memset(&r, 0, sizeof(r));
+    const double *s = bands + 10 * (size_t)b;
+    r.has_res = 1, r.valid = (int)s[0], r.first_w = (float)s[1], r.last_r0 = (float)s[2], r.last_r1 = (float)s[3];
+    for (int i = 0; i < 3; ++i) r.S[i] = s[4 + i], r.S_odd[i] = s[7 + i];
+    ptrs[(size_t)b] = &r;
+  }
+  FinOut comb;
+  combine_bands(ptrs.data(), n_bands, comb);
+  out[0] = comb.valid;
+  for (int i = 0; i < 3; ++i) out[1 + i] = comb.S[i], out[4 + i] = comb.S_odd[i];
+  return DVO_AMD_OK;
 }
 
 int dvo_amd_match(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, const double *T_init,

@@ -166,6 +166,26 @@ int dvo_amd_match_batch(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *ref
 int dvo_amd_match_many(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *references, dvo_amd_pyramid *const *currents,
                        const double *T_inits, dvo_amd_result *results, int max_in_flight);
 
+/*
+ * One pair tile-sharded over several GPUs (BASELINE config 4).  Every rank holds both pyramids and processes one band of
+ * scan-order blocks of every level; per Gauss-Newton tick the ranks all-gather one 784-byte record per band over RCCL and
+ * combine them left to right, so every rank runs the identical state machine and returns the identical result.
+ *   id = dvo_amd_comm_unique_id() on rank 0, broadcast by the caller (torch.distributed, MPI, a file ...);
+ *   dvo_amd_comm_create(ctx, id, nranks, rank) on every rank;  dvo_amd_match_sharded(...) on every rank, same arguments.
+ * dvo_amd_match_banded runs the same band pipeline with all n_bands bands on ONE GPU (no communicator): it is how the band
+ * logic is verified against the unsharded path on a single-GPU box.
+ */
+int dvo_amd_comm_unique_id(unsigned char *id128);
+int dvo_amd_comm_create(dvo_amd_context *ctx, const unsigned char *id128, int nranks, int rank);
+void dvo_amd_comm_destroy(dvo_amd_context *ctx);
+int dvo_amd_match_sharded(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, const double *T_init,
+                          dvo_amd_result *result);
+int dvo_amd_match_banded(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, const double *T_init,
+                         dvo_amd_result *result, int n_bands);
+/* host-only: the ordered combine of band records {valid, first_w, last_r0, last_r1, S[3], S_odd[3]} (10 doubles per band)
+ * -> {valid, S[3], S_odd[3]}; exported for the CPU tests of the multi-GPU path */
+int dvo_amd_debug_combine_bands(int n_bands, const double *bands, double *out);
+
 /* dvo::core::computeResidualsAndValidFlagsSse (dense_tracking_impl.cpp:400-403) for one level and one float transform
  * (column-major 4x4, reference -> current).  residuals: width*height x 2 floats in pixel order, NaN where the pixel is not
  * selected or its warp is invalid.  Used by the parity tests and by dvo_amd_error_image. */

@@ -70,3 +70,99 @@ def test_two_gloo_ranks_partition_and_aggregate():
         assert all_idx == list(range(n_items))  # every pair aligned exactly once
         weak = [w for _, w in gathered]
         assert weak == [[0, 1, 2, 3, 4], [5, 6, 7, 8, 9]]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# tile-shard exchange: the ordered combine of band records (host code of the multi-GPU path)
+# ---------------------------------------------------------------------------------------------------------------------
+def _pair_scale_reference(r, w):
+    """computeScaleSse's pairing (Q5) over a whole sequence: sum over pairs (w_2j + w_2j+1) r_2j r_2j^T, odd tail w r r^T"""
+    import numpy as np
+
+    S = np.zeros(3)
+    n = len(w)
+    for i in range(0, n - n % 2, 2):
+        S += (w[i] + w[i + 1]) * np.array([r[i, 0] * r[i, 0], r[i, 0] * r[i, 1], r[i, 1] * r[i, 1]])
+    if n % 2:
+        S += w[-1] * np.array([r[-1, 0] ** 2, r[-1, 0] * r[-1, 1], r[-1, 1] ** 2])
+    return S
+
+
+def _band_record(r, w):
+    """what one band reports: valid count, first weight, last residual, the pair sums if it starts on an even / odd rank
+    (the term that pairs its first pixel with the previous band's last residual is added by the combine)"""
+    import numpy as np
+
+    n = len(w)
+    if n == 0:
+        return np.zeros(10)
+    R = np.stack([r[:, 0] * r[:, 0], r[:, 0] * r[:, 1], r[:, 1] * r[:, 1]], axis=1)
+    S_even, S_odd = np.zeros(3), np.zeros(3)
+    for i in range(n):
+        # start parity 0: even i is a pair-first (adds w_i R_i), odd i a pair-second (adds w_i R_{i-1}); parity 1: swapped
+        if i % 2 == 0:
+            S_even += w[i] * R[i]
+            if i > 0:
+                S_odd += w[i] * R[i - 1]
+        else:
+            S_even += w[i] * R[i - 1]
+            S_odd += w[i] * R[i]
+    return np.concatenate([[n, w[0], r[-1, 0], r[-1, 1]], S_even, S_odd])
+
+
+def test_band_combine_matches_the_sequential_pairing():
+    import numpy as np
+
+    from dvo_slam_amd import capi
+
+    rng = np.random.default_rng(7)
+    for n, cuts in [(101, [0, 37, 37, 80, 101]), (64, [0, 1, 2, 3, 64]), (7, [0, 7]), (50, [0, 0, 25, 50, 50]),
+                    (333, [0, 100, 201, 333])]:
+        r = rng.normal(size=(n, 2)) * [0.02, 0.05]
+        w = rng.uniform(0.2, 1.4, size=n)
+        bands = np.stack([_band_record(r[a:b], w[a:b]) for a, b in zip(cuts[:-1], cuts[1:])])
+        out = capi.combine_bands(bands)
+        assert out[0] == n
+        assert np.allclose(out[1:4], _pair_scale_reference(r, w), rtol=1e-6, atol=1e-12)  # band data travels as float32
+
+
+def _band_worker(rank, world, port, out_q):
+    import numpy as np
+    import torch.distributed as dist
+
+    from dvo_slam_amd import capi
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(11)  # same sequence on every rank, each reports its own band
+    n = 1001
+    r = rng.normal(size=(n, 2)) * [0.02, 0.05]
+    w = rng.uniform(0.2, 1.4, size=n)
+    lo, hi = n * rank // world, n * (rank + 1) // world
+    mine = _band_record(r[lo:hi], w[lo:hi])
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)  # what ncclAllGather does with the 784-byte records on the GPUs
+    out = capi.combine_bands(np.stack(gathered))
+    out_q.put((rank, out, _pair_scale_reference(r, w), n))
+    dist.destroy_process_group()
+
+
+def test_two_gloo_ranks_exchange_and_combine_band_records():
+    import numpy as np
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_band_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out, ref, n in results:
+        assert out[0] == n
+        assert np.allclose(out[1:4], ref, rtol=1e-6, atol=1e-12)
+    assert np.array_equal(results[0][1], results[1][1])  # every rank ends with the identical combined record

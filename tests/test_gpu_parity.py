@@ -324,3 +324,30 @@ def test_pyramid_from_device_memory(capi, synth, pair640):
     a = trk.match(pair640["gr"], p).Transformation
     b = trk.match(pair640["gr"], pair640["gc"]).Transformation
     assert np.array_equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# tile-shard (multi-GPU) pipeline, verified with all bands on one GPU and with a 1-rank RCCL communicator
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_bands", [1, 2, 3, 8])
+def test_banded_pipeline_equals_unsharded(capi, synth, pair640, n_bands):
+    trk = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0))
+    whole = trk.match(pair640["gr"], pair640["gc"])
+    banded = trk.match_banded(pair640["gr"], pair640["gc"], n_bands)
+    assert [L["ValidPixels"] for L in banded.Levels] == [L["ValidPixels"] for L in whole.Levels]
+    # same constraints, same pairing, same likelihood cut: identical iteration structure; sums associate differently
+    assert [[it["ValidConstraints"] for it in L["Iterations"]] for L in banded.Levels] == \
+           [[it["ValidConstraints"] for it in L["Iterations"]] for L in whole.Levels]
+    assert [L["TerminationCriterion"] for L in banded.Levels] == [L["TerminationCriterion"] for L in whole.Levels]
+    assert synth.pose_error(whole.Transformation, banded.Transformation) <= 1e-7
+    assert np.allclose(banded.Information, whole.Information, rtol=1e-5)
+
+
+def test_sharded_match_with_single_rank_communicator(capi, synth, pair640):
+    """RCCL plumbing (unique id, communicator, per-tick all-gather) on the one GPU this box has"""
+    trk = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0))
+    trk.comm_create(capi.comm_unique_id(), 1, 0)
+    sharded = trk.match_sharded(pair640["gr"], pair640["gc"])
+    whole = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0)).match(pair640["gr"], pair640["gc"])
+    assert synth.pose_error(whole.Transformation, sharded.Transformation) <= 1e-7
+    assert [len(L["Iterations"]) for L in sharded.Levels] == [len(L["Iterations"]) for L in whole.Levels]
