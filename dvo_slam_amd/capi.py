@@ -28,7 +28,7 @@ EXPORTS = [
     "dvo_amd_residuals", "dvo_amd_error_image", "dvo_amd_kernel_timing", "dvo_amd_se3_exp", "dvo_amd_se3_log",
     "dvo_amd_solve6", "dvo_amd_bench_residual_pass", "dvo_amd_match_many",
     "dvo_amd_debug_finalize_stamps", "dvo_amd_comm_unique_id", "dvo_amd_comm_create", "dvo_amd_comm_destroy",
-    "dvo_amd_match_sharded", "dvo_amd_match_banded", "dvo_amd_debug_combine_bands",
+    "dvo_amd_match_sharded", "dvo_amd_match_banded", "dvo_amd_debug_combine_bands", "dvo_amd_pyramid_create_raw",
 ]
 
 
@@ -107,6 +107,9 @@ def lib():
                                          C.c_float, C.c_int, C.c_double, C.POINTER(vp)]
     L.dvo_amd_pyramid_create_from_device.argtypes = [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                                      C.c_float, C.c_float, C.c_int, C.c_double, C.POINTER(vp)]
+    L.dvo_amd_pyramid_create_raw.argtypes = [C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, C.c_float, C.c_int, C.c_int,
+                                             C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_double,
+                                             C.POINTER(vp)]
     L.dvo_amd_pyramid_retain.argtypes = [vp]
     L.dvo_amd_pyramid_retain.restype = None
     L.dvo_amd_pyramid_release.argtypes = [vp]
@@ -207,6 +210,41 @@ class RgbdImagePyramid:
         _check(lib().dvo_amd_pyramid_create_from_device(device, C.c_void_p(d_intensity), C.c_void_p(d_depth), width,
                                                         height, stride or width, fx, fy, ox, oy, levels, timestamp,
                                                         C.byref(self._h)), "dvo_amd_pyramid_create_from_device")
+        self.device = device
+        return self
+
+    @classmethod
+    def from_raw(cls, image, depth, K, levels: int, depth_scale: float = 1.0 / 5000.0, device: int = 0,
+                 timestamp: float = 0.0):
+        """Frame ingest on the device: uint8 image (HxW gray or HxWx3 BGR) + uint16 depth (0 = invalid), as a camera or a
+        TUM PNG pair delivers them (benchmark_slam.cpp:46-93).  Gray conversion and depth scaling run on the GPU."""
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        depth = np.ascontiguousarray(depth, dtype=np.uint16)
+        if image.shape[:2] != depth.shape or depth.ndim != 2 or image.ndim not in (2, 3):
+            raise ValueError("image must be HxW or HxWx3 uint8 and depth HxW uint16 of the same size")
+        channels = 1 if image.ndim == 2 else image.shape[2]
+        h, w = depth.shape
+        return cls._raw(image.ctypes.data, channels, w * channels, depth.ctypes.data, w, depth_scale, 0, w, h, K, levels,
+                        device, timestamp)
+
+    @classmethod
+    def from_raw_device(cls, d_image: int, channels: int, d_depth: int, width: int, height: int, K, levels: int,
+                        depth_scale: float = 1.0 / 5000.0, device: int = 0, timestamp: float = 0.0,
+                        image_stride_bytes: int | None = None, depth_stride: int | None = None):
+        """As from_raw, for raw frames already resident in HBM (device pointers)."""
+        return cls._raw(d_image, channels, image_stride_bytes or width * channels, d_depth, depth_stride or width,
+                        depth_scale, 1, width, height, K, levels, device, timestamp)
+
+    @classmethod
+    def _raw(cls, image_ptr, channels, image_stride, depth_ptr, depth_stride, depth_scale, on_device, w, h, K, levels,
+             device, timestamp):
+        self = cls.__new__(cls)
+        fx, fy, ox, oy = [float(k) for k in K]
+        self._h = C.c_void_p()
+        _check(lib().dvo_amd_pyramid_create_raw(device, C.c_void_p(image_ptr), channels, image_stride,
+                                                C.c_void_p(depth_ptr), depth_stride, depth_scale, on_device, w, h, fx, fy,
+                                                ox, oy, levels, timestamp, C.byref(self._h)),
+               "dvo_amd_pyramid_create_raw")
         self.device = device
         return self
 

@@ -979,6 +979,69 @@ hipError_t launch_copy_strided(const float *src, int stride, float *dst, int w, 
   return hipGetLastError();
 }
 
+// Frame ingest: raw sensor frame -> the two float base planes of level 0.
+//   depth: 0 -> NaN, else (float)raw * scale           (SurfacePyramid::convertRawDepthImageSse, surface_pyramid.cpp:65-105)
+//   gray : (B*1868 + G*9617 + R*4899 + 2^13) >> 14      (cv::cvtColor(CV_BGR2GRAY) 8-bit rule + convertTo(CV_32F),
+//          or the byte itself for 1-channel input        benchmark_slam.cpp:60-68, camera_dense_tracking.cpp:219-229)
+// One thread converts 4 consecutive pixels of a row (level widths are multiples of 4): 12 + 8 bytes in, 2 x 16 bytes out.
+__global__ void k_ingest(const unsigned char *__restrict__ img, int channels, int img_stride_bytes,
+                         const unsigned short *__restrict__ raw_z, int z_stride, float z_scale, float *__restrict__ i_plane,
+                         float *__restrict__ z_plane, int w, int h) {
+  const int x4 = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x4 * 4 >= w || y >= h) return;
+  const unsigned char *ip = img + (size_t)y * img_stride_bytes + (size_t)x4 * 4 * channels;
+  unsigned char px[12];
+  const int nb = 4 * channels;
+  if ((((size_t)ip) & 3) == 0) {
+    const unsigned *ip4 = (const unsigned *)ip;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (k < channels) {
+        const unsigned v = ip4[k];
+        px[4 * k] = (unsigned char)v, px[4 * k + 1] = (unsigned char)(v >> 8), px[4 * k + 2] = (unsigned char)(v >> 16),
+               px[4 * k + 3] = (unsigned char)(v >> 24);
+      }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 12; ++k)
+      if (k < nb) px[k] = ip[k];
+  }
+  float g[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (channels == 3) {
+      const int b = px[3 * k], gg = px[3 * k + 1], r = px[3 * k + 2];
+      g[k] = (float)((b * 1868 + gg * 9617 + r * 4899 + (1 << 13)) >> 14);
+    } else {
+      g[k] = (float)px[k];
+    }
+  }
+  const unsigned short *zp = raw_z + (size_t)y * z_stride + (size_t)x4 * 4;
+  unsigned short zr[4];
+  if ((((size_t)zp) & 7) == 0) {
+    const uint2 v = *(const uint2 *)zp;
+    zr[0] = (unsigned short)v.x, zr[1] = (unsigned short)(v.x >> 16), zr[2] = (unsigned short)v.y,
+    zr[3] = (unsigned short)(v.y >> 16);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) zr[k] = zp[k];
+  }
+  float z[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) z[k] = zr[k] == 0 ? __builtin_nanf("") : (float)zr[k] * z_scale;
+  const size_t o = (size_t)y * w + (size_t)x4 * 4;
+  *(float4 *)(i_plane + o) = make_float4(g[0], g[1], g[2], g[3]);
+  *(float4 *)(z_plane + o) = make_float4(z[0], z[1], z[2], z[3]);
+}
+
+hipError_t launch_ingest(const unsigned char *img, int channels, int img_stride_bytes, const unsigned short *raw_z,
+                         int z_stride, float z_scale, float *i_plane, float *z_plane, int w, int h, hipStream_t stream) {
+  const int wq = w / 4;
+  hipLaunchKernelGGL(k_ingest, dim3((unsigned)((wq + 63) / 64), (unsigned)h), dim3(64), 0, stream, img, channels,
+                     img_stride_bytes, raw_z, z_stride, z_scale, i_plane, z_plane, w, h);
+  return hipGetLastError();
+}
+
 __global__ void k_mask_from_zsel(const float *__restrict__ zsel, int n, int last_dropped, unsigned char *__restrict__ mask) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) mask[i] = (zsel[i] == zsel[i] || i == last_dropped) ? 1 : 0;

@@ -158,12 +158,28 @@ size_t pyramid_layout(dvo_amd_pyramid *p, char *base) {
   return off;
 }
 
-int pyramid_build(int device, const float *src_i, const float *src_z, bool src_on_device, int width, int height, int stride,
-                  float fx, float fy, float ox, float oy, int levels, double timestamp, dvo_amd_pyramid **out) {
+// a raw sensor frame (frame ingest on the device)
+struct RawFrame {
+  const unsigned char *image;  // uint8, `channels` interleaved channels (1 = gray, 3 = BGR)
+  int channels, image_stride_bytes;
+  const unsigned short *depth;  // uint16, 0 = invalid
+  int depth_stride;             // in elements
+  float depth_scale;
+};
+
+int pyramid_build(int device, const float *src_i, const float *src_z, const RawFrame *raw, bool src_on_device, int width,
+                  int height, int stride, float fx, float fy, float ox, float oy, int levels, double timestamp,
+                  dvo_amd_pyramid **out) {
   if (!out) return DVO_AMD_ERR_INVALID_ARGUMENT;
   *out = nullptr;
-  if (!src_i || !src_z || width < 4 || height < 2 || stride < width || levels < 1 || levels > DVO_AMD_MAX_LEVELS)
+  if (width < 4 || height < 2 || levels < 1 || levels > DVO_AMD_MAX_LEVELS) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  if (raw) {
+    if (!raw->image || !raw->depth || (raw->channels != 1 && raw->channels != 3) ||
+        raw->image_stride_bytes < width * raw->channels || raw->depth_stride < width || !(raw->depth_scale > 0.0f))
+      return DVO_AMD_ERR_INVALID_ARGUMENT;
+  } else if (!src_i || !src_z || stride < width) {
     return DVO_AMD_ERR_INVALID_ARGUMENT;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return DVO_AMD_ERR_NO_DEVICE;
   if (device < 0 || device >= ndev || device >= kMaxDevices) return DVO_AMD_ERR_INVALID_ARGUMENT;
@@ -210,7 +226,27 @@ int pyramid_build(int device, const float *src_i, const float *src_z, bool src_o
   };
   LevelData &L0 = p->lv[0];
   hipError_t e;
-  if (src_on_device) {
+  if (raw) {
+    const unsigned char *d_img = raw->image;
+    const unsigned short *d_z = raw->depth;
+    int img_stride = raw->image_stride_bytes, z_stride = raw->depth_stride;
+    if (!src_on_device) {
+      // stage the raw bytes (5 B/px instead of 8 B/px of float planes over PCIe) in level 0's gather plane, which is only
+      // written by launch_level_planes further down the same stream
+      unsigned char *stage_img = (unsigned char *)L0.c_a;
+      unsigned short *stage_z = (unsigned short *)(stage_img + align_up((size_t)L0.n * raw->channels, 256));
+      const size_t row_img = (size_t)width * raw->channels, row_z = sizeof(unsigned short) * (size_t)width;
+      e = hipMemcpy2DAsync(stage_img, row_img, raw->image, (size_t)raw->image_stride_bytes, row_img, height,
+                           hipMemcpyHostToDevice, st);
+      if (e == hipSuccess)
+        e = hipMemcpy2DAsync(stage_z, row_z, raw->depth, sizeof(unsigned short) * (size_t)raw->depth_stride, row_z, height,
+                             hipMemcpyHostToDevice, st);
+      if (e != hipSuccess) return bail(fail_hip("raw frame upload", e));
+      d_img = stage_img, d_z = stage_z, img_stride = (int)row_img, z_stride = width;
+    }
+    e = launch_ingest(d_img, raw->channels, img_stride, d_z, z_stride, raw->depth_scale, L0.i_plane, L0.z_plane, width,
+                      height, st);
+  } else if (src_on_device) {
     if (stride == width) {
       e = hipMemcpyAsync(L0.i_plane, src_i, sizeof(float) * L0.n, hipMemcpyDeviceToDevice, st);
       if (e == hipSuccess) e = hipMemcpyAsync(L0.z_plane, src_z, sizeof(float) * L0.n, hipMemcpyDeviceToDevice, st);
@@ -1175,13 +1211,23 @@ int dvo_amd_get_config(const dvo_amd_context *ctx, dvo_amd_config *cfg) {
 
 int dvo_amd_pyramid_create(int device, const float *intensity, const float *depth, int width, int height, int stride,
                            float fx, float fy, float ox, float oy, int levels, double timestamp, dvo_amd_pyramid **out) {
-  return pyramid_build(device, intensity, depth, false, width, height, stride, fx, fy, ox, oy, levels, timestamp, out);
+  return pyramid_build(device, intensity, depth, nullptr, false, width, height, stride, fx, fy, ox, oy, levels, timestamp, out);
 }
 
 int dvo_amd_pyramid_create_from_device(int device, const float *d_intensity, const float *d_depth, int width, int height,
                                        int stride, float fx, float fy, float ox, float oy, int levels, double timestamp,
                                        dvo_amd_pyramid **out) {
-  return pyramid_build(device, d_intensity, d_depth, true, width, height, stride, fx, fy, ox, oy, levels, timestamp, out);
+  return pyramid_build(device, d_intensity, d_depth, nullptr, true, width, height, stride, fx, fy, ox, oy, levels, timestamp,
+                       out);
+}
+
+int dvo_amd_pyramid_create_raw(int device, const unsigned char *image, int channels, int image_stride_bytes,
+                               const unsigned short *depth, int depth_stride, float depth_scale, int on_device, int width,
+                               int height, float fx, float fy, float ox, float oy, int levels, double timestamp,
+                               dvo_amd_pyramid **out) {
+  RawFrame raw{image, channels, image_stride_bytes, depth, depth_stride, depth_scale};
+  return pyramid_build(device, nullptr, nullptr, &raw, on_device != 0, width, height, width, fx, fy, ox, oy, levels,
+                       timestamp, out);
 }
 
 void dvo_amd_pyramid_retain(dvo_amd_pyramid *p) {

@@ -127,6 +127,9 @@ hipError_t launch_level_planes(const float *i_plane, const float *z_plane, int w
 // then un-selects the last selected pixel if count is odd (Q3).
 hipError_t launch_select(const float *z_plane, const float4 *c_a, const float2 *c_b, int n, int n_pad, float ti, float td,
                          float *zsel, int *counters, hipStream_t stream);
+// raw frame -> float base planes of level 0 (uint8 gray or BGR, uint16 depth with 0 = invalid)
+hipError_t launch_ingest(const unsigned char *img, int channels, int img_stride_bytes, const unsigned short *raw_z,
+                         int z_stride, float z_scale, float *i_plane, float *z_plane, int w, int h, hipStream_t stream);
 hipError_t launch_copy_strided(const float *src, int stride, float *dst, int w, int h, hipStream_t stream);
 hipError_t launch_mask_from_zsel(const float *zsel, int n, int last_dropped, unsigned char *mask, hipStream_t stream);
 hipError_t launch_unpack_plane(const float4 *c_a, const float2 *c_b, int plane, int n, float *dst, hipStream_t stream);

@@ -142,6 +142,22 @@ def render(width: int, height: int, T_cam=None, seed: int = SEED, frame_id: int 
     return intensity, depth
 
 
+def to_raw(intensity, depth, depth_factor: float = 5000.0, seed: int = SEED + 3):
+    """The frame as a sensor / a TUM PNG pair would deliver it: uint8 BGR (the gray value spread over three channels with
+    hashed per-channel offsets, so the colour conversion is exercised) and uint16 depth in 1/depth_factor metres with
+    0 = no measurement (benchmark_slam.cpp:46-93)."""
+    h, w = intensity.shape
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.uint32)
+    base = np.rint(intensity).astype(np.int32)
+    bgr = np.empty((h, w, 3), np.uint8)
+    for c in range(3):
+        off = (_hash_u32(xx, yy, seed + c) % np.uint32(31)).astype(np.int32) - 15
+        bgr[..., c] = np.clip(base + off, 0, 255).astype(np.uint8)
+    z = np.where(np.isnan(depth), 0.0, depth) * depth_factor
+    raw_z = np.clip(np.rint(z), 0, 65535).astype(np.uint16)
+    return bgr, raw_z
+
+
 def make_pair(width: int = 640, height: int = 480, xi_gt=XI_GT_PAIR, seed: int = SEED, frame_id: int = 0):
     """Reference frame at the scene origin, current frame at exp(xi_gt).  The expected DenseTracker result
     (cur <- ref convention, dense_tracking.cpp:371) is T = exp(xi_gt)."""

@@ -136,6 +136,20 @@ int dvo_amd_pyramid_create(int device, const float *intensity, const float *dept
 int dvo_amd_pyramid_create_from_device(int device, const float *d_intensity, const float *d_depth, int width, int height,
                                        int stride, float fx, float fy, float ox, float oy, int levels, double timestamp,
                                        dvo_amd_pyramid **out);
+/*
+ * Frame ingest on the device: the pyramid straight from a raw sensor frame, replacing the host-side
+ * cv::cvtColor(CV_BGR2GRAY) + convertTo(CV_32F) (benchmark_slam.cpp:60-68, camera_dense_tracking.cpp:219-229) and
+ * SurfacePyramid::convertRawDepthImageSse (surface_pyramid.cpp:65-105) in front of RgbdCameraPyramid::create.
+ *   image : uint8, `channels` = 1 (gray) or 3 (B,G,R interleaved); image_stride_bytes >= width * channels
+ *   depth : uint16, 0 = no measurement -> NaN, else (float)raw * depth_scale (1/5000 for TUM PNGs, 0.001 for OpenNI)
+ *   on_device != 0: both pointers are device memory on `device` (no PCIe traffic); else host memory (5 B/px cross PCIe
+ *   instead of the 8 B/px of two float planes).
+ * Gray conversion is OpenCV's 8-bit rule Y = (1868 B + 9617 G + 4899 R + 8192) >> 14.
+ */
+int dvo_amd_pyramid_create_raw(int device, const unsigned char *image, int channels, int image_stride_bytes,
+                               const unsigned short *depth, int depth_stride, float depth_scale, int on_device, int width,
+                               int height, float fx, float fy, float ox, float oy, int levels, double timestamp,
+                               dvo_amd_pyramid **out);
 void dvo_amd_pyramid_retain(dvo_amd_pyramid *p);
 void dvo_amd_pyramid_release(dvo_amd_pyramid *p);
 int dvo_amd_pyramid_levels(const dvo_amd_pyramid *p);

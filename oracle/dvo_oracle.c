@@ -1073,3 +1073,34 @@ int orc_match(const orc_config *cfg, orc_pyramid *ref, orc_pyramid *cur, const d
   free(weights);
   return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * frame ingest
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* surface_pyramid.cpp:44-63 (scalar) and :65-105 (SSE: cvtepi32_ps, cmpeq 0 -> or NaN, mulps): same values */
+void orc_ingest_depth_u16(const unsigned short *raw, int width, int height, int stride, float scale, float *out) {
+  for (int y = 0; y < height; ++y)
+    for (int x = 0; x < width; ++x) {
+      unsigned short v = raw[(size_t)y * stride + x];
+      out[(size_t)y * width + x] = v == 0 ? NAN : (float)v * scale;
+    }
+}
+
+/* cv::cvtColor(CV_BGR2GRAY) for CV_8UC3 (OpenCV 2.4 fixed-point rule, see the header) + convertTo(CV_32F):
+ * benchmark_slam.cpp:60-68, camera_dense_tracking.cpp:219-224 */
+void orc_ingest_gray_from_bgr8(const unsigned char *bgr, int width, int height, int stride_bytes, float *out) {
+  for (int y = 0; y < height; ++y) {
+    const unsigned char *row = bgr + (size_t)y * stride_bytes;
+    for (int x = 0; x < width; ++x) {
+      int b = row[3 * x], g = row[3 * x + 1], r = row[3 * x + 2];
+      out[(size_t)y * width + x] = (float)((b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14);
+    }
+  }
+}
+
+/* single-channel input: convertTo(CV_32F) only (benchmark_slam.cpp:64-68, camera_dense_tracking.cpp:226-229) */
+void orc_ingest_gray_from_gray8(const unsigned char *gray, int width, int height, int stride_bytes, float *out) {
+  for (int y = 0; y < height; ++y)
+    for (int x = 0; x < width; ++x) out[(size_t)y * width + x] = (float)gray[(size_t)y * stride_bytes + x];
+}

@@ -120,6 +120,18 @@ int orc_compute_residuals(orc_pyramid *ref, orc_pyramid *cur, int level, float t
 /* DenseTracker::match(RgbdImagePyramid&, RgbdImagePyramid&, Result&): dense_tracking.cpp:123-376 */
 int orc_match(const orc_config *cfg, orc_pyramid *ref, orc_pyramid *cur, const double *T_init, orc_result *res);
 
+/* Frame ingest.
+ * depth: SurfacePyramid::convertRawDepthImage / ...Sse (surface_pyramid.cpp:44-105): 0 -> NaN, else (float)raw * scale
+ * (one fp32 multiply); callers use scale 1/5000 (benchmark_slam.cpp:77) or 0.001 (camera_dense_tracking.cpp:234).
+ * gray: cv::cvtColor(CV_BGR2GRAY) on 8-bit data followed by convertTo(CV_32F) (benchmark_slam.cpp:60-68,
+ * camera_dense_tracking.cpp:219-224).  OpenCV is a build-time dependency that is NOT in the reference tree (ROS
+ * fuerte/groovy era, OpenCV 2.4.x); restated here is its published 8-bit fixed-point rule
+ *   Y = (B*1868 + G*9617 + R*4899 + (1 << 13)) >> 14                        (coefficients 0.114/0.587/0.299 in Q14)
+ * Strides are in elements of the respective type (bytes for the image). */
+void orc_ingest_depth_u16(const unsigned short *raw, int width, int height, int stride, float scale, float *out);
+void orc_ingest_gray_from_bgr8(const unsigned char *bgr, int width, int height, int stride_bytes, float *out);
+void orc_ingest_gray_from_gray8(const unsigned char *gray, int width, int height, int stride_bytes, float *out);
+
 /* small pieces exported for unit tests */
 void orc_se3_exp(const double xi[6], double T[16]);
 void orc_se3_log(const double T[16], double xi[6]);

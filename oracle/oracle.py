@@ -73,6 +73,9 @@ def lib():
         L.orc_compute_residuals.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, fp, C.c_int, fp, fp,
                                             C.POINTER(C.c_ubyte)]
         L.orc_match.argtypes = [C.POINTER(Config), C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(Result)]
+        L.orc_ingest_depth_u16.argtypes = [C.POINTER(C.c_ushort), C.c_int, C.c_int, C.c_int, C.c_float, fp]
+        L.orc_ingest_gray_from_bgr8.argtypes = [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, fp]
+        L.orc_ingest_gray_from_gray8.argtypes = [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, fp]
         L.orc_se3_exp.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_se3_log.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_jacobian.argtypes = [fp, fp, fp]
@@ -202,3 +205,26 @@ def se3_log(T):
     xi = np.zeros(6)
     lib().orc_se3_log(Tc.ctypes.data_as(C.POINTER(C.c_double)), xi.ctypes.data_as(C.POINTER(C.c_double)))
     return xi
+
+
+def ingest_depth(raw, scale=1.0 / 5000.0):
+    """uint16 depth image -> float metres, 0 -> NaN (surface_pyramid.cpp:44-105)."""
+    raw = np.ascontiguousarray(raw, dtype=np.uint16)
+    h, w = raw.shape
+    out = np.empty((h, w), np.float32)
+    lib().orc_ingest_depth_u16(raw.ctypes.data_as(C.POINTER(C.c_ushort)), w, h, w, np.float32(scale), _fp(out))
+    return out
+
+
+def ingest_gray(image):
+    """uint8 HxW (gray) or HxWx3 (BGR) -> float gray 0..255 (cv::cvtColor(BGR2GRAY) + convertTo(CV_32F))."""
+    image = np.ascontiguousarray(image, dtype=np.uint8)
+    h, w = image.shape[:2]
+    out = np.empty((h, w), np.float32)
+    ptr = image.ctypes.data_as(C.POINTER(C.c_ubyte))
+    if image.ndim == 3:
+        assert image.shape[2] == 3
+        lib().orc_ingest_gray_from_bgr8(ptr, w, h, 3 * w, _fp(out))
+    else:
+        lib().orc_ingest_gray_from_gray8(ptr, w, h, w, _fp(out))
+    return out

@@ -327,6 +327,67 @@ def test_pyramid_from_device_memory(capi, synth, pair640):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# frame ingest on the device: bit-exact against the oracle's restatement of the host-side conversion
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("channels", [3, 1])
+def test_ingest_raw_frame_bit_exact(capi, orc, synth, pair640, channels):
+    (Ir, Zr), (Ic, Zc) = pair640["frames"]
+    bgr, raw_z = synth.to_raw(Ic, Zc)
+    raw_z[5, 8:24] = 0
+    raw_z[6, 0], raw_z[6, 1] = 65535, 1
+    img = bgr if channels == 3 else bgr[..., 1].copy()
+    for scale in (1.0 / 5000.0, 0.001):
+        I_o, Z_o = orc.ingest_gray(img), orc.ingest_depth(raw_z, scale)
+        p = capi.RgbdImagePyramid.from_raw(img, raw_z, pair640["K"], 4, depth_scale=scale)
+        assert np.array_equal(_bits(p.plane(0, 0)), _bits(I_o))
+        zg = p.plane(0, 1)
+        assert np.array_equal(np.isnan(zg), np.isnan(Z_o)) and np.array_equal(_bits(zg)[~np.isnan(Z_o)], _bits(Z_o)[~np.isnan(Z_o)])
+        q = orc.Pyramid(I_o, Z_o, pair640["K"], 4)
+        for level in range(4):
+            for plane in range(6):
+                a, b = p.plane(level, plane), q.plane(level, plane)
+                assert np.array_equal(np.isnan(a), np.isnan(b)), (level, plane)
+                assert np.array_equal(_bits(a)[~np.isnan(b)], _bits(b)[~np.isnan(b)]), (level, plane)
+
+
+def test_ingest_from_device_memory_and_odd_strides(capi, orc, synth, pair640):
+    torch = pytest.importorskip("torch")
+    (Ir, Zr), (Ic, Zc) = pair640["frames"]
+    bgr, raw_z = synth.to_raw(Ic, Zc)
+    ref = capi.RgbdImagePyramid.from_raw(bgr, raw_z, pair640["K"], 4)
+    # padded rows whose strides break the 4- and 8-byte alignment of the fast loads
+    wide_img = torch.zeros((480, 640 * 3 + 7), dtype=torch.uint8, device="cuda")
+    wide_img[:, : 640 * 3] = torch.from_numpy(bgr.reshape(480, -1)).cuda()
+    wide_z = torch.zeros((480, 643), dtype=torch.int16, device="cuda")
+    wide_z[:, :640] = torch.from_numpy(raw_z.view(np.int16)).cuda()
+    torch.cuda.synchronize()
+    p = capi.RgbdImagePyramid.from_raw_device(wide_img.data_ptr(), 3, wide_z.data_ptr(), 640, 480, pair640["K"], 4,
+                                              image_stride_bytes=640 * 3 + 7, depth_stride=643)
+    for level, plane in ((0, 0), (0, 1), (1, 4), (3, 2)):
+        assert np.array_equal(p.plane(level, plane), ref.plane(level, plane), equal_nan=True)
+
+
+def test_match_from_raw_frames_equals_oracle_on_ingested_planes(capi, orc, synth, pair640):
+    (Ir, Zr), (Ic, Zc) = pair640["frames"]
+    raw_r, raw_c = synth.to_raw(Ir, Zr), synth.to_raw(Ic, Zc)
+    gr = capi.RgbdImagePyramid.from_raw(*raw_r, pair640["K"], 4)
+    gc = capi.RgbdImagePyramid.from_raw(*raw_c, pair640["K"], 4)
+    orr = orc.Pyramid(orc.ingest_gray(raw_r[0]), orc.ingest_depth(raw_r[1]), pair640["K"], 4)
+    occ = orc.Pyramid(orc.ingest_gray(raw_c[0]), orc.ingest_depth(raw_c[1]), pair640["K"], 4)
+    rg, ro, err = _check_match(capi, orc, synth, gr, gc, orr, occ, dict(FirstLevel=3, LastLevel=0))
+    assert synth.pose_error(rg.Transformation, pair640["Tgt"]) < 2e-3  # 8-bit / 0.2 mm quantisation of the raw frame
+
+
+def test_ingest_argument_errors(capi, synth, pair640):
+    img = np.zeros((480, 640, 2), np.uint8)
+    z = np.zeros((480, 640), np.uint16)
+    with pytest.raises(Exception):
+        capi.RgbdImagePyramid.from_raw(img, z, pair640["K"], 4)  # 2 channels
+    with pytest.raises(Exception):
+        capi.RgbdImagePyramid.from_raw(np.zeros((480, 640), np.uint8), z, pair640["K"], 4, depth_scale=0.0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # tile-shard (multi-GPU) pipeline, verified with all bands on one GPU and with a 1-rank RCCL communicator
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n_bands", [1, 2, 3, 8])

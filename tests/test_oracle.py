@@ -350,3 +350,47 @@ def test_oracle_reproduces_golden_vectors(name):
     assert np.allclose(got["T"], want["T"], atol=1e-12)
     assert np.allclose(got["iterations"], want["iterations"], rtol=1e-9, atol=1e-12)
     assert np.allclose(got["information"], want["information"], rtol=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# frame ingest
+# ---------------------------------------------------------------------------------------------------------------------
+def test_ingest_depth_zero_is_nan_and_scale_is_one_fp32_multiply(orc):
+    rng = np.random.default_rng(5)
+    raw = rng.integers(0, 65536, size=(24, 32), dtype=np.uint16)
+    raw[3, 4:9] = 0
+    raw[0, 0], raw[0, 1] = 65535, 1
+    for scale in (1.0 / 5000.0, 0.001):  # benchmark_slam.cpp:77, camera_dense_tracking.cpp:234
+        out = orc.ingest_depth(raw, scale)
+        expect = raw.astype(np.float32) * np.float32(scale)
+        expect[raw == 0] = np.nan
+        assert np.array_equal(out.view(np.uint32)[raw != 0], expect.view(np.uint32)[raw != 0])
+        assert np.isnan(out[raw == 0]).all() and np.isfinite(out[raw != 0]).all()
+
+
+def test_ingest_gray_known_answers_of_the_8bit_rule(orc):
+    # the well-known 8-bit luma values of cv::cvtColor(BGR2GRAY): pure blue 29, green 150, red 76; grays are fixed points
+    img = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255]],
+                    [[0, 0, 0], [128, 128, 128], [17, 17, 17], [10, 200, 90]]], np.uint8)
+    out = orc.ingest_gray(img)
+    assert out.dtype == np.float32
+    assert out.tolist() == [[29.0, 150.0, 76.0, 255.0], [0.0, 128.0, 17.0, float((10 * 1868 + 200 * 9617 + 90 * 4899 + 8192) >> 14)]]
+    rng = np.random.default_rng(6)
+    img = rng.integers(0, 256, size=(20, 28, 3), dtype=np.uint8)
+    b, g, r = [img[..., c].astype(np.int64) for c in range(3)]
+    assert np.array_equal(orc.ingest_gray(img), ((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14).astype(np.float32))
+    # within half a gray level of the real-valued luma everywhere
+    assert np.abs(orc.ingest_gray(img) - (0.114 * b + 0.587 * g + 0.299 * r)).max() <= 0.5 + 0.02  # Q14 coefficients
+    gray = rng.integers(0, 256, size=(8, 12), dtype=np.uint8)
+    assert np.array_equal(orc.ingest_gray(gray), gray.astype(np.float32))
+
+
+def test_raw_synthetic_frame_round_trips_through_ingest(orc, synth):
+    (I, Z), _, _ = synth.make_pair(64, 48)
+    bgr, raw_z = synth.to_raw(I, Z)
+    assert bgr.shape == (48, 64, 3) and raw_z.dtype == np.uint16
+    Ig, Zg = orc.ingest_gray(bgr), orc.ingest_depth(raw_z)
+    assert np.array_equal(np.isnan(Zg), np.isnan(Z))
+    m = ~np.isnan(Z)
+    assert np.abs(Zg[m] - Z[m]).max() <= 0.5 / 5000.0 + 1e-6
+    assert np.abs(Ig - I).max() <= 16.5
