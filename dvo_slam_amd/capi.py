@@ -29,6 +29,7 @@ EXPORTS = [
     "dvo_amd_solve6", "dvo_amd_bench_residual_pass", "dvo_amd_match_many",
     "dvo_amd_debug_finalize_stamps", "dvo_amd_comm_unique_id", "dvo_amd_comm_create", "dvo_amd_comm_destroy",
     "dvo_amd_match_sharded", "dvo_amd_match_banded", "dvo_amd_debug_combine_bands", "dvo_amd_pyramid_create_raw",
+    "dvo_amd_default_validator_stages", "dvo_amd_proposals_for_candidates", "dvo_amd_validate_proposals",
 ]
 
 

@@ -183,3 +183,26 @@ def loop_closure_poses(n_candidates: int = 32, seed: int = SEED + 2, max_trans: 
         om = om / max(np.linalg.norm(om), 1e-9) * np.deg2rad(max_rot_deg) * abs(hs[7])
         out.append(se3_exp(np.concatenate([ups, om])))
     return out
+
+
+def loop_closure_scenario(width: int = 640, height: int = 480, n_candidates: int = 6, seed: int = SEED, decoys: bool = True,
+                          pose_error: float = 0.1):
+    """Config 5 as a validator workload: one keyframe (id 100, pose = identity) and candidate keyframes at the hashed poses of
+    loop_closure_poses().  Every entry: dict(id, frame=(I, Z), pose_true, pose) where `pose` is the pose the pose graph
+    believes (the true one with `pose_error` of its twist removed, mirroring the 10 % perturbation of SURVEY.md config 5).
+    With decoys, three candidates that validation must throw out are appended: a neighbour in id (odometry constraint),
+    a frame of a different scene (seed + 77), and a frame without any depth (NaN result)."""
+    key = dict(id=100, frame=render(width, height, None, seed, 0), pose_true=np.eye(4), pose=np.eye(4))
+    cands = []
+    for i, T in enumerate(loop_closure_poses(n_candidates)):
+        xi = se3_log(T)
+        cands.append(dict(id=2 * i, frame=render(width, height, T, seed, 1 + i), pose_true=T,
+                          pose=se3_exp(xi * (1.0 - pose_error))))
+    if decoys:
+        T = se3_exp(XI_STEP_STREAM)
+        cands.append(dict(id=101, frame=render(width, height, T, seed, 50), pose_true=T, pose=T))
+        T = se3_exp(XI_GT_PAIR)
+        cands.append(dict(id=60, frame=render(width, height, T, seed + 77, 51), pose_true=T, pose=T))
+        I, Z = render(width, height, T, seed, 52)
+        cands.append(dict(id=70, frame=(I, np.full_like(Z, np.nan)), pose_true=T, pose=T))
+    return key, cands

@@ -200,6 +200,84 @@ int dvo_amd_match_banded(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_a
  * -> {valid, S[3], S_odd[3]}; exported for the CPU tests of the multi-GPU path */
 int dvo_amd_debug_combine_bands(int n_bands, const double *bands, double *out);
 
+/*
+ * Batched 2-stage loop-closure validation: dvo_slam::constraints::ConstraintProposalValidator::validate
+ * (constraint_proposal_validator.cpp:69-166) with the voters of constraint_proposal_voter.cpp:34-186, fed by ONE call: every
+ * stage aligns all of its proposals (and the cross-validation inverses) as one batch on the GPU (dvo_amd_match_many), in
+ * place of the tbb::parallel_reduce over single proposals in keyframe_graph.cpp:525-593.
+ */
+/* dvo_slam::TrackingResultEvaluation subclasses (tracking_result_evaluation.cpp:54-67): value(r) */
+typedef enum {
+  DVO_AMD_EVAL_LOGLIKELIHOOD = 0,            /* -r.LogLikelihood (the one KeyframeTracker creates, keyframe_tracker.cpp:95) */
+  DVO_AMD_EVAL_NORMALIZED_LOGLIKELIHOOD = 1, /* -r.LogLikelihood / Levels.back().Iterations.back().ValidConstraints */
+  DVO_AMD_EVAL_ENTROPY = 2                   /* log(det(r.Information)) */
+} dvo_amd_evaluation_kind;
+
+/* dvo_slam::Keyframe as the validator reads it (id(), image(), pose(), evaluation()) */
+typedef struct {
+  int id;
+  dvo_amd_pyramid *image;
+  double pose[16];               /* column-major 4x4 */
+  int evaluation_kind;           /* dvo_amd_evaluation_kind */
+  double evaluation_average;     /* TrackingResultEvaluation::average_ (sum of the values added so far) */
+  double evaluation_n;           /* TrackingResultEvaluation::n_ */
+} dvo_amd_keyframe;
+
+typedef enum {
+  DVO_AMD_VOTER_ODOMETRY_CONSTRAINT = 0,        /* reject |ref.id - cur.id| <= 1                    (voter.cpp:167-184) */
+  DVO_AMD_VOTER_NAN_RESULT = 1,                 /* reject TrackingResult.isNaN()                     (voter.cpp:147-162) */
+  DVO_AMD_VOTER_CONSTRAINT_RATIO = 2,           /* ValidConstraints / ValidPixels >= threshold       (voter.cpp:124-142) */
+  DVO_AMD_VOTER_TRACKING_RESULT_EVALUATION = 3, /* ratioWithAverage >= threshold, Score = ratio      (voter.cpp:103-119) */
+  DVO_AMD_VOTER_CROSS_VALIDATION = 4            /* |t(T_inverse * T)| <= threshold; adds the inverse proposals (voter.cpp:34-97) */
+} dvo_amd_voter_kind;
+
+#define DVO_AMD_MAX_VOTERS 8
+typedef struct {
+  int kind;          /* dvo_amd_voter_kind */
+  double threshold;
+} dvo_amd_voter;
+
+/* ConstraintProposalValidator::Stage (constraint_proposal_validator.h) */
+typedef struct {
+  int id;
+  int only_keep_best;               /* keepBest() / keepAll() */
+  dvo_amd_config tracking_config;
+  int n_voters;
+  dvo_amd_voter voters[DVO_AMD_MAX_VOTERS];
+} dvo_amd_validator_stage;
+
+/* ConstraintProposal::Vote; `value` is the quantity the voter tested (what the reference prints into Vote::Reason) */
+typedef struct {
+  int voter_kind;
+  int reject;       /* Vote::Decision: 0 Accept, 1 Reject */
+  double score;
+  double value;
+} dvo_amd_vote;
+
+/* dvo_slam::constraints::ConstraintProposal: reference / current are indices into the keyframe array */
+typedef struct {
+  int reference, current;
+  double initial_transformation[16];
+  dvo_amd_result tracking_result;  /* of the last stage the proposal went through; iterations is ignored (set to NULL) */
+  int n_votes;
+  dvo_amd_vote votes[DVO_AMD_MAX_VOTERS];
+} dvo_amd_constraint_proposal;
+
+/* the two stages KeyframeGraph builds (keyframe_graph.cpp:500-523) with the tracker configs of configureValidationTracking
+ * (:819-838): stage 1 = level 3 only, keepAll, {Odometry, NaN, ConstraintRatio(min_constraint_ratio), Evaluation(ratio_coarse),
+ * CrossValidation(1.0)}; stage 2 = levels 3..1, keepBest, {NaN, ConstraintRatio, Evaluation(ratio_fine)} */
+void dvo_amd_default_validator_stages(const dvo_amd_config *frontend_cfg, double min_constraint_ratio, double ratio_coarse,
+                                      double ratio_fine, dvo_amd_validator_stage stages[2]);
+/* the initial proposal list of validateKeyframeConstraintsParallel (keyframe_graph.cpp:577-585): for every candidate one
+ * proposal with identity and one with the relative pose current.pose^-1 * reference.pose.  proposals: 2 * n_candidates */
+int dvo_amd_proposals_for_candidates(const dvo_amd_keyframe *keyframes, int keyframe, int n_candidates, const int *candidates,
+                                     dvo_amd_constraint_proposal *proposals);
+/* validate(): proposals[0..n_proposals) in, survivors compacted to the front in the reference's order, *n_out of them.
+ * The context's tracker configuration is restored before returning.  max_in_flight as in dvo_amd_match_many. */
+int dvo_amd_validate_proposals(dvo_amd_context *ctx, int n_keyframes, const dvo_amd_keyframe *keyframes, int n_stages,
+                               const dvo_amd_validator_stage *stages, int n_proposals,
+                               dvo_amd_constraint_proposal *proposals, int *n_out, int max_in_flight);
+
 /* dvo::core::computeResidualsAndValidFlagsSse (dense_tracking_impl.cpp:400-403) for one level and one float transform
  * (column-major 4x4, reference -> current).  residuals: width*height x 2 floats in pixel order, NaN where the pixel is not
  * selected or its warp is invalid.  Used by the parity tests and by dvo_amd_error_image. */
