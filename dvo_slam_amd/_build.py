@@ -8,7 +8,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("DVO_AMD_LIB") or os.path.join(_HERE, "libdvo_amd.so")
-SOURCES = ["dvo_kernels.hip", "dvo_tracker.cpp", "dvo_validator.cpp"]
+SOURCES = ["dvo_kernels.hip", "dvo_tracker.cpp", "dvo_validator.cpp", "dvo_frontend.cpp"]
 HEADERS = ["dvo_types.h", "se3.h", os.path.join("..", "..", "include", "dvo_amd.h")]
 
 

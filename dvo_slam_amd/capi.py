@@ -30,6 +30,7 @@ EXPORTS = [
     "dvo_amd_debug_finalize_stamps", "dvo_amd_comm_unique_id", "dvo_amd_comm_create", "dvo_amd_comm_destroy",
     "dvo_amd_match_sharded", "dvo_amd_match_banded", "dvo_amd_debug_combine_bands", "dvo_amd_pyramid_create_raw",
     "dvo_amd_default_validator_stages", "dvo_amd_proposals_for_candidates", "dvo_amd_validate_proposals",
+    "dvo_amd_track_frame",
 ]
 
 
@@ -57,6 +58,13 @@ class CResult(C.Structure):
                 ("n_iterations", C.c_int), ("iterations_capacity", C.c_int),
                 ("iterations", C.POINTER(CIterationStats)), ("n_ticks", C.c_int), ("n_residual_passes", C.c_int),
                 ("alg_bytes", C.c_double)]
+
+
+class CFrameCriteria(C.Structure):
+    _fields_ = [("odometry_is_nan", C.c_int), ("keyframe_is_nan", C.c_int), ("odometry_translation_norm", C.c_double),
+                ("keyframe_translation_norm", C.c_double), ("keyframe_constraint_ratio", C.c_double),
+                ("odometry_neg_loglik", C.c_double), ("keyframe_neg_loglik", C.c_double),
+                ("odometry_condition_number", C.c_double), ("keyframe_condition_number", C.c_double)]
 
 
 class DvoAmdError(RuntimeError):
@@ -111,6 +119,7 @@ def lib():
     L.dvo_amd_pyramid_create_raw.argtypes = [C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, C.c_float, C.c_int, C.c_int,
                                              C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_double,
                                              C.POINTER(vp)]
+    L.dvo_amd_track_frame.argtypes = [vp, vp, vp, vp, dp, C.POINTER(CResult), C.POINTER(CResult), C.POINTER(CFrameCriteria)]
     L.dvo_amd_pyramid_retain.argtypes = [vp]
     L.dvo_amd_pyramid_retain.restype = None
     L.dvo_amd_pyramid_release.argtypes = [vp]
@@ -381,6 +390,22 @@ class DenseTracker:
         if not stats:
             return [Result(res[i], None) for i in range(n)]
         return [Result(res[i], its[i]) for i in range(n)]
+
+    def track_frame(self, keyframe: RgbdImagePyramid, last_frame: RgbdImagePyramid, frame: RgbdImagePyramid,
+                    last_keyframe_pose=None):
+        """The two alignments of LocalTracker::update (local_tracker.cpp:170-186) as one two-pair batch:
+        (r_keyframe, r_odometry, criteria) with criteria = the inputs of KeyframeTracker's accept callbacks."""
+        res, its = self._alloc_results(2)
+        crit = CFrameCriteria()
+        P = None
+        if last_keyframe_pose is not None:
+            P = np.ascontiguousarray(np.asarray(last_keyframe_pose, dtype=np.float64).T)
+        _check(lib().dvo_amd_track_frame(self._h, keyframe._h, last_frame._h, frame._h,
+                                         P.ctypes.data_as(C.POINTER(C.c_double)) if P is not None else None,
+                                         C.byref(res[0]), C.byref(res[1]), C.byref(crit)), "dvo_amd_track_frame")
+        criteria = {name: getattr(crit, name) for name, _ in CFrameCriteria._fields_}
+        criteria["odometry_is_nan"], criteria["keyframe_is_nan"] = bool(crit.odometry_is_nan), bool(crit.keyframe_is_nan)
+        return Result(res[0], its[0]), Result(res[1], its[1]), criteria
 
     def match_banded(self, reference: RgbdImagePyramid, current: RgbdImagePyramid, n_bands: int, T_init=None) -> Result:
         """The tile-shard pipeline with all n_bands bands on this one GPU (verification of the multi-GPU path)."""

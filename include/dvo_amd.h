@@ -278,6 +278,28 @@ int dvo_amd_validate_proposals(dvo_amd_context *ctx, int n_keyframes, const dvo_
                                const dvo_amd_validator_stage *stages, int n_proposals,
                                dvo_amd_constraint_proposal *proposals, int *n_out, int max_in_flight);
 
+/*
+ * Dual-match front-end step: the two alignments LocalTracker::update runs per frame with
+ * tbb::parallel_invoke (local_tracker.cpp:170-186) -- keyframe -> frame starting from last_keyframe_pose^-1 and
+ * last frame -> frame starting from identity -- as ONE two-pair batch sharing the frame's pyramid, plus the quantities the
+ * accept callbacks of KeyframeTracker test on the two results (keyframe_tracker.cpp:105-190).
+ */
+typedef struct {
+  int odometry_is_nan, keyframe_is_nan;   /* force a new keyframe (local_tracker.cpp:191) */
+  double odometry_translation_norm;       /* onAcceptCriterionEstimateDivergence: rejects > 0.1 */
+  double keyframe_translation_norm;       /* ... and > 1.5 MaxTranslationalDistance; onAcceptCriterionDistance */
+  double keyframe_constraint_ratio;       /* onAcceptCriterionConstraintRatio: Levels.back().Iterations.back().ValidConstraints / ValidPixels */
+  double odometry_neg_loglik;             /* onAcceptCriterionTrackingResultEvaluation: -LogLikelihood (value() of the evaluation) */
+  double keyframe_neg_loglik;
+  double odometry_condition_number;       /* onAcceptCriterionConditionNumber: |lambda_max / lambda_min| of Information */
+  double keyframe_condition_number;
+} dvo_amd_frame_criteria;
+/* last_keyframe_pose: column-major 4x4 (LocalTrackerImpl::last_keyframe_pose_), NULL = identity.  r_keyframe / r_odometry
+ * follow dvo_amd_match's conventions; criteria may be NULL. */
+int dvo_amd_track_frame(dvo_amd_context *ctx, dvo_amd_pyramid *keyframe, dvo_amd_pyramid *last_frame, dvo_amd_pyramid *frame,
+                        const double *last_keyframe_pose, dvo_amd_result *r_keyframe, dvo_amd_result *r_odometry,
+                        dvo_amd_frame_criteria *criteria);
+
 /* dvo::core::computeResidualsAndValidFlagsSse (dense_tracking_impl.cpp:400-403) for one level and one float transform
  * (column-major 4x4, reference -> current).  residuals: width*height x 2 floats in pixel order, NaN where the pixel is not
  * selected or its warp is invalid.  Used by the parity tests and by dvo_amd_error_image. */

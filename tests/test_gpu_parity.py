@@ -388,6 +388,50 @@ def test_ingest_argument_errors(capi, synth, pair640):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# dual-match front-end step
+# ---------------------------------------------------------------------------------------------------------------------
+def test_track_frame_equals_oracle_and_two_single_matches(capi, orc, synth):
+    from oracle import frontend
+
+    K = synth.intrinsics_for(640, 480)
+    poses = synth.stream_poses(7)
+    frames = [synth.render(640, 480, poses[t], frame_id=t) for t in (0, 5, 6)]  # keyframe, last frame, new frame
+    g = [capi.RgbdImagePyramid(I, Z, K, 4) for I, Z in frames]
+    o = [orc.Pyramid(I, Z, K, 4) for I, Z in frames]
+    for cfg_kw in (dict(FirstLevel=3, LastLevel=1, UseInitialEstimate=True), dict(FirstLevel=3, LastLevel=0, UseInitialEstimate=False)):
+        gcfg = capi.Config(**cfg_kw)
+        trk = capi.DenseTracker(gcfg)
+        ocfg = orc.default_config(first_level=gcfg.FirstLevel, last_level=gcfg.LastLevel,
+                                  use_initial_estimate=int(gcfg.UseInitialEstimate), rcp_mode=orc.RCP_EXACT)
+        last_kf_pose = poses[5] @ synth.se3_exp(np.array([0.002, -0.001, 0.001, 0.0005, 0.001, -0.0005]))  # a slightly-off estimate
+        rk, ro, crit = trk.track_frame(g[0], g[1], g[2], last_kf_pose)
+        ok, oo, ocrit = frontend.track_frame(ocfg, o[0], o[1], o[2], last_kf_pose)
+        assert synth.pose_error(rk.Transformation, ok["T"]) <= DIVERGED_PATH_TOL
+        assert synth.pose_error(ro.Transformation, oo["T"]) <= DIVERGED_PATH_TOL
+        assert synth.pose_error(rk.Transformation, poses[6]) < 1e-3 and synth.pose_error(ro.Transformation, poses[6] @ np.linalg.inv(poses[5])) < 1e-3
+        # the likelihood is discontinuous in the valid-constraint count (Q5 re-pairing, Q6 tail): +-1 constraint moves it by
+        # ~1e4 of ~4e6 even on the same iteration path, so it is only comparable to a few percent (chaos caveat above)
+        for name, want in ocrit.items():
+            got = crit[name]
+            if isinstance(want, bool):
+                assert got == want, name
+            else:
+                rtol = 3e-2 if name.endswith("neg_loglik") else 2e-3
+                assert abs(got - want) <= rtol * abs(want) + 1e-6, (name, got, want)
+        # one two-pair batch == the two single alignments the reference runs side by side
+        init = np.eye(4)
+        init[:3, :3], init[:3, 3] = last_kf_pose[:3, :3].T, -last_kf_pose[:3, :3].T @ last_kf_pose[:3, 3]
+        a = trk.match(g[0], g[2], init if gcfg.UseInitialEstimate else None)
+        b = trk.match(g[1], g[2], np.eye(4) if gcfg.UseInitialEstimate else None)
+        assert np.array_equal(b.Transformation, ro.Transformation)  # identical inputs: identical result
+        assert synth.pose_error(a.Transformation, rk.Transformation) <= 1e-7  # the inverse of the pose is rounded differently
+        kf_last = rk.Levels[-1]
+        assert crit["keyframe_constraint_ratio"] == kf_last["Iterations"][-1]["ValidConstraints"] / kf_last["ValidPixels"]
+        ev = np.linalg.eigvalsh(rk.Information)
+        assert abs(crit["keyframe_condition_number"] - abs(ev[-1] / ev[0])) <= 1e-9 * abs(ev[-1] / ev[0])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # tile-shard (multi-GPU) pipeline, verified with all bands on one GPU and with a 1-rank RCCL communicator
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n_bands", [1, 2, 3, 8])
