@@ -8,7 +8,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("DVO_AMD_LIB") or os.path.join(_HERE, "libdvo_amd.so")
-SOURCES = ["dvo_kernels.hip", "dvo_tracker.cpp", "dvo_validator.cpp", "dvo_frontend.cpp"]
+SOURCES = ["dvo_kernels.hip", "dvo_tracker.cpp", "dvo_validator.cpp", "dvo_frontend.cpp", "dvo_tum.cpp"]
 HEADERS = ["dvo_types.h", "se3.h", os.path.join("..", "..", "include", "dvo_amd.h")]
 
 
@@ -37,7 +37,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         "-fno-fast-math",
         "-Wall", "-Wno-unused-function",
         "-x", "hip",
-    ] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH + ".tmp"]
+    ] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lz", "-o", LIB_PATH + ".tmp"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout)

@@ -1120,6 +1120,8 @@ const char *dvo_amd_status_string(int s) {
     case DVO_AMD_ERR_DEVICE_MISMATCH: return "pyramid and context live on different devices";
     case DVO_AMD_ERR_NAN_INIT: return "initial estimate is NaN";
     case DVO_AMD_ERR_COMM: return "communicator error";
+    case DVO_AMD_ERR_IO: return "file cannot be opened or read";
+    case DVO_AMD_ERR_FORMAT: return "unsupported or corrupt file format";
     default: return "unknown status";
   }
 }

@@ -41,7 +41,9 @@ typedef enum {
   DVO_AMD_ERR_CAPACITY = 7,         /* caller-provided iteration array too small */
   DVO_AMD_ERR_DEVICE_MISMATCH = 8,
   DVO_AMD_ERR_NAN_INIT = 9,         /* UseInitialEstimate with a NaN transform (dense_tracking.cpp:139 assert) */
-  DVO_AMD_ERR_COMM = 10
+  DVO_AMD_ERR_COMM = 10,
+  DVO_AMD_ERR_IO = 11,              /* file cannot be opened / read */
+  DVO_AMD_ERR_FORMAT = 12           /* file is not what the reader supports (see the reader's comment) */
 } dvo_amd_status;
 
 /* DenseTracker::TerminationCriteria::Enum, dense_tracking.h:71-81 */
@@ -299,6 +301,23 @@ typedef struct {
 int dvo_amd_track_frame(dvo_amd_context *ctx, dvo_amd_pyramid *keyframe, dvo_amd_pyramid *last_frame, dvo_amd_pyramid *frame,
                         const double *last_keyframe_pose, dvo_amd_result *r_keyframe, dvo_amd_result *r_odometry,
                         dvo_amd_frame_criteria *criteria);
+
+/*
+ * TUM RGB-D benchmark on-disk formats, host code only.
+ * The reference reads frames with cv::imread (benchmark_slam.cpp:50-51): the colour image as 3-channel 8-bit BGR
+ * (flag 1), the depth image unchanged (flag -1, 16-bit gray in TUM sequences).  OpenCV is not available here, so a PNG
+ * decoder (zlib inflate + the five PNG filters; 8/16-bit gray, gray+alpha, RGB, RGBA, and 1/2/4/8-bit palette or gray;
+ * non-interlaced only) stands in for those two calls.  16-bit colour samples keep their high byte, alpha is dropped,
+ * gray is replicated to B=G=R: what imread(.., 1) returns.
+ */
+int dvo_amd_png_info(const char *path, int *width, int *height, int *channels, int *bit_depth);
+int dvo_amd_png_read_bgr8(const char *path, unsigned char *dst, int width, int height);      /* width*height*3 bytes */
+int dvo_amd_png_read_gray16(const char *path, unsigned short *dst, int width, int height);   /* gray PNGs only; 8-bit values are widened */
+/* One line of the estimated trajectory exactly as benchmark_slam.cpp:490-504 / map_serializer.cpp:61-66 print it:
+ * "<sec>.<nsec, 9 digits> tx ty tz qx qy qz qw \n" with the default ostream formatting of doubles (%g, 6 significant
+ * digits), the stamp split like ros::Time::fromSec, the quaternion as Eigen::Quaterniond(rotation) builds it.
+ * T: column-major 4x4.  Returns the number of characters written (excluding the terminator), or -1 if capacity is too small. */
+int dvo_amd_format_trajectory_line(double timestamp, const double *T, char *buf, int capacity);
 
 /* dvo::core::computeResidualsAndValidFlagsSse (dense_tracking_impl.cpp:400-403) for one level and one float transform
  * (column-major 4x4, reference -> current).  residuals: width*height x 2 floats in pixel order, NaN where the pixel is not
