@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--distinct", type=int, default=8, help="distinct current frames cycled through the batch")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the informational side measurements (STREAM copy, frame ingest, loop-closure validator, "
+                         "all-core CPU baseline); rank 0 at N=1 only")
     ap.add_argument("--tile-shard", action="store_true",
                     help="BASELINE config 4 instead of the default: ONE pair at a time, every level tile-sharded over the "
                          "N GPUs with a per-iteration RCCL all-gather of the band records (strong scaling, expected to be "
@@ -217,6 +220,16 @@ def main():
             line["roofline_isolated_kernel"] = {"error": str(exc)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, ref_frame, cur_frames, K, levels, first_level)
+        if world == 1 and not args.no_extras:
+            for name, fn in (("stream_copy", lambda: stream_copy(device)),
+                             ("ingest", lambda: ingest_timing(capi, synth, cur_frames, K, levels, device)),
+                             ("loop_closure_validator", lambda: validator_timing(capi, synth, W, H, device)),
+                             ("cpu_baseline_all_cores", lambda: None if args.no_cpu_baseline else
+                              cpu_baseline_threads(args, ref_frame, cur_frames, K, levels, first_level))):
+                try:
+                    line[name] = fn()
+                except Exception as exc:  # pragma: no cover - side measurements never fail the bench line
+                    line[name] = {"error": repr(exc)}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
@@ -273,6 +286,121 @@ def tile_shard_bench(args, capi, synth, sharding, dist, rank, world, device, ref
         }), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def stream_copy(device):
+    """The 'achievable' HBM figure SURVEY.md 8d asks for: a plain device-to-device copy of 1 GiB on the same GPU
+    (read + write bytes / time), next to the nominal 8 TB/s the roofline uses."""
+    import torch
+
+    n = 1 << 28  # floats: 1 GiB
+    a = torch.empty(n, dtype=torch.float32, device=f"cuda:{device}").normal_()
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize(device)
+    ms = e0.elapsed_time(e1) / reps
+    return {"GBps": 2 * 4 * n / ms / 1e6, "what": "torch device-to-device copy of 1 GiB, read+write bytes / time",
+            "frac_of_nominal_peak": 2 * 4 * n / ms / 1e6 / HBM_PEAK_GBS}
+
+
+def ingest_timing(capi, synth, frames, K, levels, device):
+    """Frame ingest: a full pyramid straight from a raw uint8 BGR + uint16 depth frame."""
+    import torch
+
+    raws = [synth.to_raw(I, Z) for I, Z in frames[:4]]
+    h, w = raws[0][1].shape
+    for bgr, z in raws:  # warm the slab pool
+        capi.RgbdImagePyramid.from_raw(bgr, z, K, levels, device=device)
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        for bgr, z in raws:
+            capi.RgbdImagePyramid.from_raw(bgr, z, K, levels, device=device)
+    host_ms = (time.perf_counter() - t0) * 1e3 / (reps * len(raws))
+    dev = [(torch.from_numpy(bgr).to(f"cuda:{device}"), torch.from_numpy(z.view("int16")).to(f"cuda:{device}")) for bgr, z in raws]
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for bgr, z in dev:
+            capi.RgbdImagePyramid.from_raw_device(bgr.data_ptr(), 3, z.data_ptr(), w, h, K, levels, device=device)
+    dev_ms = (time.perf_counter() - t0) * 1e3 / (reps * len(raws))
+    return {"ms_per_frame_from_host_raw": host_ms, "ms_per_frame_from_device_raw": dev_ms,
+            "what": f"{w}x{h} uint8 BGR + uint16 depth -> {levels}-level pyramid (gray conversion, depth scaling, "
+                    "derivatives, gather layout) through the Python binding; host: pageable memory, 5 B/px over PCIe"}
+
+
+def validator_timing(capi, synth, W, H, device):
+    """BASELINE config 5 in the reference's real shape: one keyframe against 32 candidates, two
+    proposals each, stage 1 = level 3 only on proposal + inverse, stage 2 = levels 3..1 on the survivors, keep-best."""
+    from dvo_slam_amd import constraints as Cn
+
+    K = synth.intrinsics_for(W, H)
+    key, cands = synth.loop_closure_scenario(W, H, 32, decoys=False)
+    trk = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=1), device=device)
+
+    def mk(e):
+        p = capi.RgbdImagePyramid(e["frame"][0], e["frame"][1], K, 4, device=device)
+        return Cn.Keyframe(e["id"], p, e["pose"], Cn.LogLikelihoodTrackingResultEvaluation(trk.match(p, p)))
+
+    kkey, kc = mk(key), [mk(c) for c in cands]
+    val = Cn.createConstraintProposalValidator(min_constraint_ratio=0.2, ratio_coarse=-1e300, ratio_fine=-1e300,
+                                               device=device, max_in_flight=27)
+    val.validate(Cn.proposalsForCandidates(kkey, kc))
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = val.validate(Cn.proposalsForCandidates(kkey, kc))
+    ms = (time.perf_counter() - t0) * 1e3 / reps
+    n_align = 2 * 64 + 64
+    return {"ms_per_validate": ms, "proposals": 64, "alignments": n_align, "alignments_per_s": n_align / ms * 1e3,
+            "constraints_kept": len(out),
+            "what": "dvo_amd_validate_proposals: 64 proposals (32 candidates x {identity, relative pose}), stage 1 = 128 "
+                    "level-3 alignments (proposals + cross-validation inverses), stage 2 = 64 alignments over levels 3..1, "
+                    "evaluation thresholds open so that every proposal reaches stage 2"}
+
+
+def cpu_baseline_threads(args, ref_frame, cur_frames, K, levels, first_level):
+    """SURVEY.md 8d (ii): one oracle tracker per hardware thread over independent pairs (the shape of tbb::parallel_reduce
+    over proposals); ctypes releases the GIL inside orc_match."""
+    import threading
+
+    from oracle import oracle as orc
+
+    n_threads = min(os.cpu_count() or 1, 64)
+    try:
+        n_threads = min(n_threads, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    pr = orc.Pyramid(ref_frame[0], ref_frame[1], K, levels)
+    pcs = [orc.Pyramid(f[0], f[1], K, levels) for f in cur_frames]
+    cfg = orc.default_config(first_level=first_level, last_level=0, rcp_mode=orc.RCP_SSE)
+    budget = min(args.cpu_seconds, 8.0)
+    counts = [0] * n_threads
+    t0 = time.perf_counter()
+
+    def worker(t):
+        k = t
+        while time.perf_counter() - t0 < budget:
+            orc.match(cfg, pr, pcs[k % len(pcs)])
+            k += 1
+            counts[t] += 1
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    dt = time.perf_counter() - t0
+    return {"value": sum(counts) / dt, "unit": "frame-pairs/s", "cores": n_threads, "kind": "port",
+            "sample": f"{sum(counts)} match() calls in {dt:.1f} s, {n_threads} threads, one oracle tracker each, shared pyramids"}
 
 
 def cpu_baseline(args, ref_frame, cur_frames, K, levels, first_level):
