@@ -30,7 +30,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="frame pairs aligned per step per GPU")
+    ap.add_argument("--batch", type=int, default=576, help="frame pairs aligned per step per GPU")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--distinct", type=int, default=8, help="distinct current frames cycled through the batch")
@@ -46,9 +46,9 @@ def parse():
     ap.add_argument("--prime", type=int, default=2,
                     help="untimed priming steps run as part of set-up before the W warm-up steps: the first calls grow "
                          "scratch buffers, streams and the HIP runtime's internal pools (a one-off ~40 ms stall)")
-    ap.add_argument("--in-flight", type=int, default=27,
+    ap.add_argument("--in-flight", type=int, default=36,
                     help="pairs resident per tracker at a time (0 = the whole share in lock step)")
-    ap.add_argument("--threads", type=int, default=4,
+    ap.add_argument("--threads", type=int, default=8,
                     help="host threads per GPU, each with its own tracker (HIP stream) and an equal share of the batch")
     return ap.parse_args()
 
@@ -211,9 +211,9 @@ def main():
             },
         }
         try:
-            ms_i, ab_i, nl_i = trk.bench_residual_pass(ref, curs[0], 0, synth.se3_exp(synth.XI_GT_PAIR * 0.6), 27, 0, reps=20)
+            ms_i, ab_i, nl_i = trk.bench_residual_pass(ref, curs[0], 0, synth.se3_exp(synth.XI_GT_PAIR * 0.6), 36, 0, reps=20)
             line["roofline_isolated_kernel"] = {
-                "what": "the residual pass alone: level 0, 27 pairs in one launch (one launch's worth of resident pairs)",
+                "what": "the residual pass alone: level 0, 36 pairs in one launch (one launch's worth of resident pairs)",
                 "achieved": ab_i / ms_i / 1e6, "unit": "GB/s", "frac": ab_i / ms_i / 1e6 / HBM_PEAK_GBS,
                 "launch_us": ms_i * 1e3 / nl_i, "alg_bytes_per_launch": ab_i / nl_i}
         except Exception as exc:  # pragma: no cover
@@ -352,7 +352,7 @@ def validator_timing(capi, synth, W, H, device):
 
     kkey, kc = mk(key), [mk(c) for c in cands]
     val = Cn.createConstraintProposalValidator(min_constraint_ratio=0.2, ratio_coarse=-1e300, ratio_fine=-1e300,
-                                               device=device, max_in_flight=27)
+                                               device=device, max_in_flight=36)
     val.validate(Cn.proposalsForCandidates(kkey, kc))
     reps = 5
     t0 = time.perf_counter()

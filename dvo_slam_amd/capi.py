@@ -31,7 +31,7 @@ EXPORTS = [
     "dvo_amd_match_sharded", "dvo_amd_match_banded", "dvo_amd_debug_combine_bands", "dvo_amd_pyramid_create_raw",
     "dvo_amd_default_validator_stages", "dvo_amd_proposals_for_candidates", "dvo_amd_validate_proposals",
     "dvo_amd_track_frame", "dvo_amd_png_info", "dvo_amd_png_read_bgr8", "dvo_amd_png_read_gray16",
-    "dvo_amd_format_trajectory_line",
+    "dvo_amd_format_trajectory_line", "dvo_amd_debug_tick_log",
 ]
 
 
@@ -458,6 +458,16 @@ class DenseTracker:
         _check(lib().dvo_amd_bench_residual_pass(self._h, reference._h, current._h, level, _fp(Tf), n_items, rounds, reps,
                                                  C.byref(ms), C.byref(ab), C.byref(nl)), "dvo_amd_bench_residual_pass")
         return ms.value, ab.value, nl.value
+
+    def tick_log(self) -> np.ndarray:
+        """Per-launch log of the timed k_tick launches: rows {ms, items, residual blocks, likelihood blocks, grid.x, px}."""
+        n = C.c_int()
+        L = lib()
+        L.dvo_amd_debug_tick_log.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]
+        _check(L.dvo_amd_debug_tick_log(self._h, None, 0, C.byref(n)), "tick_log")
+        out = np.zeros((max(n.value, 1), 6))
+        _check(L.dvo_amd_debug_tick_log(self._h, out.ctypes.data_as(C.POINTER(C.c_double)), n.value, C.byref(n)), "tick_log")
+        return out[: n.value]
 
     def kernel_timing(self, enable: bool, reset: bool = False):
         ms = C.c_double()

@@ -243,10 +243,10 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
   bool carry_has = false;
 
   const unsigned long long below = (1ull << lane) - 1ull;
-  const bool unit_w = it.unit_weights != 0;
-  const float P0 = it.P_res[0], P1 = it.P_res[1], P2 = it.P_res[2], P3 = it.P_res[3];
+  const bool unit_w = (it.flags & kItemUnitWeights) != 0;
+  const float P0 = it.P[0], P1 = it.P[1], P2 = it.P[2], P3 = it.P[3];
   const gcf p_z = (gcf)d.r_zsel, p_i = (gcf)d.r_i, p_ix = (gcf)d.r_ix, p_iy = (gcf)d.r_iy, p_tx = (gcf)d.tx, p_ty = (gcf)d.ty;
-  DVO_GLOBAL v2f *const p_res = (DVO_GLOBAL v2f *)(it.res_buf ? d.res[1] : d.res[0]);  // no dynamic index: keeps d in registers
+  DVO_GLOBAL v2f *const p_res = (DVO_GLOBAL v2f *)((it.flags & kItemResBuf) ? d.res[1] : d.res[0]);  // no dynamic index: keeps d in registers
 
   // reference scalars of the step about to be processed (loaded one step ahead)
   float n_z = p_z[idx], n_i = p_i[idx], n_ix = p_ix[idx], n_iy = p_iy[idx];
@@ -561,14 +561,14 @@ __device__ void loglik_pass(const TickItem &it, const LevelPairDesc &d, const in
   const int wave = threadIdx.x >> 6;
   const int seg = lb * kWavesPerBlock + wave;
   // valid pixels of this band that precede the segment (written by k_finalize of the residual pass that filled the buffer)
-  const int seg_before = ((const DVO_GLOBAL int *)(it.ll_buf ? d.seg_prefix[1] : d.seg_prefix[0]))[seg];
+  const int seg_before = ((const DVO_GLOBAL int *)((it.flags & kItemLlBuf) ? d.seg_prefix[1] : d.seg_prefix[0]))[seg];
   const int cut_rank = it.ll_cut_rank;
-  const float P0 = it.P_ll[0], P1 = it.P_ll[1], P2 = it.P_ll[2], P3 = it.P_ll[3];
+  const float P0 = it.P[0], P1 = it.P[1], P2 = it.P[2], P3 = it.P[3];
   const unsigned long long below = (1ull << lane) - 1ull;
   double total = 0.0;
   if (seg_before < cut_rank) {
     const int steps = it.ll_rounds * kPxPerLane;
-    const DVO_GLOBAL v2f *src = (const DVO_GLOBAL v2f *)(it.ll_buf ? d.res[1] : d.res[0]) + seg * (kSegPxPerRound * it.ll_rounds) + lane;
+    const DVO_GLOBAL v2f *src = (const DVO_GLOBAL v2f *)((it.flags & kItemLlBuf) ? d.res[1] : d.res[0]) + seg * (kSegPxPerRound * it.ll_rounds) + lane;
     int run_count = seg_before;
     // four steps (256 pixels) per trip: one log of a product of up to four terms per lane
     for (int step = 0; step < steps; step += 4) {

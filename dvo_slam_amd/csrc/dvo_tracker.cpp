@@ -391,6 +391,8 @@ struct dvo_amd_context {
   bool timing = false;
   double timing_ms = 0.0;
   long long timing_launches = 0;
+  std::vector<double> tick_log;  // timing mode: per launch {ms, items, residual blocks, likelihood blocks, grid.x, selected px}
+  std::vector<double> tick_log_pending;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   size_t events_used = 0;
 };
@@ -766,7 +768,12 @@ int timing_collect(dvo_amd_context *ctx) {
     HIP_TRY(hipEventElapsedTime(&ms, ctx->events[i].first, ctx->events[i].second));
     ctx->timing_ms += ms;
     ctx->timing_launches++;
+    if (6 * i + 5 < ctx->tick_log_pending.size() && ctx->tick_log.size() < 6 * 65536) {
+      ctx->tick_log.push_back((double)ms);
+      for (int k = 1; k < 6; ++k) ctx->tick_log.push_back(ctx->tick_log_pending[6 * i + k]);
+    }
   }
+  ctx->tick_log_pending.clear();
   ctx->events_used = 0;
   return DVO_AMD_OK;
 }
@@ -829,11 +836,10 @@ int run_tick(dvo_amd_context *ctx, std::vector<Job> &jobs) {
     f.ll_partials = j.slot->ll_partials;
     f.seg_prefix_out = j.slot->seg_prefix[0], f.out = j.slot->out, f.out_dev = nullptr, f.seq = seq, f.pad = 0;
     if (j.have_a) {
-      w.ll_blocks = j.a.n_blocks;
-      w.ll_rounds = j.a.rounds;
-      w.ll_buf = j.a.buf;
+      w.ll_blocks = (uint16_t)j.a.n_blocks;
+      w.ll_rounds = (uint8_t)j.a.rounds;
+      if (j.a.buf) w.flags |= kItemLlBuf;
       w.ll_cut_rank = j.a.cut_rank;
-      std::memcpy(w.P_ll, j.a.P, sizeof(w.P_ll));
       f.n_ll_blocks = w.ll_blocks;
       j.sub_ll = true;
     }
@@ -841,13 +847,11 @@ int run_tick(dvo_amd_context *ctx, std::vector<Job> &jobs) {
       j.b.rounds = rounds_now;
       while (j.b.rounds < kMaxRounds && blocks_for(j.ref->lv[j.level].n, j.b.rounds) > 2048) j.b.rounds *= 2;
       j.b.n_blocks = blocks_for(j.ref->lv[j.level].n, j.b.rounds);
-      w.res_blocks = j.b.n_blocks;
-      w.res_rounds = j.b.rounds;
-      w.res_buf = j.b.buf;
-      w.unit_weights = j.b.k == 0 ? 1 : 0;  // dense_tracking.cpp:286-293
+      w.res_blocks = (uint16_t)j.b.n_blocks;
+      w.res_rounds = (uint8_t)j.b.rounds;
+      if (j.b.buf) w.flags |= kItemResBuf;
+      if (j.b.k == 0) w.flags |= kItemUnitWeights;  // dense_tracking.cpp:286-293
       make_kt(j.cur->lv[j.level], j.b.estimate_after, w.kt);
-      // weights of iteration k use the precision of iteration k-1, which is iteration a's (unused at k = 0)
-      std::memcpy(w.P_res, j.have_a ? j.a.P : j.precision, sizeof(w.P_res));
       f.records = j.slot->records;
       f.n_blocks = w.res_blocks;
       f.seg_prefix_out = j.slot->seg_prefix[j.b.buf];
@@ -855,6 +859,9 @@ int run_tick(dvo_amd_context *ctx, std::vector<Job> &jobs) {
       j.result->n_residual_passes++;
       j.alg_px += (double)j.ref->selections[j.sel].count[j.level];
     }
+    // the likelihood of iteration k and the weights of iteration k+1 both use the precision of iteration k (a's); without a
+    // pending likelihood the weights use the job's current precision (unused at the first iteration of a level)
+    std::memcpy(w.P, j.have_a ? j.a.P : j.precision, sizeof(w.P));
     items.push_back(w);
     fin_items.push_back(f);
     j.result->n_ticks++;
@@ -889,6 +896,16 @@ int run_tick(dvo_amd_context *ctx, std::vector<Job> &jobs) {
     if (ctx->timing) {
       int rc = timing_begin(ctx, st, &ev);
       if (rc) return rc;
+      double rb = 0, lb = 0, px = 0;
+      for (int i = 0; i < ta.n_items; ++i) rb += ta.items[i].res_blocks, lb += ta.items[i].ll_blocks;
+      for (size_t ji = 0, k = 0; ji < jobs.size(); ++ji) {
+        const Job &j = jobs[ji];
+        if (j.done || !(j.sub_ll || j.sub_res)) continue;
+        if (k >= first && k < first + (size_t)ta.n_items && j.sub_res) px += (double)j.ref->selections[j.sel].count[j.level];
+        ++k;
+      }
+      const double rec[6] = {0.0, (double)ta.n_items, rb, lb, (double)max_blocks, px};
+      ctx->tick_log_pending.insert(ctx->tick_log_pending.end(), rec, rec + 6);
     }
     hipError_t e = launch_tick(ta, max_blocks, st);
     if (e != hipSuccess) return fail_hip("launch_tick", e);
@@ -1001,24 +1018,29 @@ int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, i
     f.out_dev = exchange ? ctx->slots[(size_t)li].out_dev : nullptr;
     f.seq = seq;
     if (j.have_a) {
-      band_range(j.a.n_blocks, n_bands, band, &w.ll_first, &w.ll_blocks);
-      w.ll_rounds = 1, w.ll_buf = j.a.buf;
+      int first = 0, count = 0;
+      band_range(j.a.n_blocks, n_bands, band, &first, &count);
+      w.ll_first = (uint16_t)first, w.ll_blocks = (uint16_t)count;
+      w.ll_rounds = 1;
+      if (j.a.buf) w.flags |= kItemLlBuf;
       int before = 0;
       for (int b = 0; b < band; ++b) before += j.a.band_valid[b];
       w.ll_cut_rank = j.a.cut_rank - before;  // rank inside the band below which residuals enter the likelihood
-      std::memcpy(w.P_ll, j.a.P, sizeof(w.P_ll));
       f.n_ll_blocks = w.ll_blocks, f.ll_first = w.ll_first;
     }
     if (j.have_b) {
-      band_range(nb_level, n_bands, band, &w.res_first, &w.res_blocks);
-      w.res_rounds = 1, w.res_buf = j.b.buf;
-      w.unit_weights = j.b.k == 0 ? 1 : 0;
+      int first = 0, count = 0;
+      band_range(nb_level, n_bands, band, &first, &count);
+      w.res_first = (uint16_t)first, w.res_blocks = (uint16_t)count;
+      w.res_rounds = 1;
+      if (j.b.buf) w.flags |= kItemResBuf;
+      if (j.b.k == 0) w.flags |= kItemUnitWeights;
       make_kt(j.cur->lv[j.level], j.b.estimate_after, w.kt);
-      std::memcpy(w.P_res, j.have_a ? j.a.P : j.precision, sizeof(w.P_res));
       f.records = ctx->slots[0].records;
       f.n_blocks = w.res_blocks, f.block_first = w.res_first;
       f.seg_prefix_out = ctx->slots[0].seg_prefix[j.b.buf];
     }
+    std::memcpy(w.P, j.have_a ? j.a.P : j.precision, sizeof(w.P));
     max_blocks = std::max(max_blocks, w.res_blocks + w.ll_blocks);
   }
   ta.n_items = n_local, fa.n_items = n_local;
@@ -1504,9 +1526,8 @@ int dvo_amd_residuals(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_
   w.slot = ctx->slot_desc;
   w.res_rounds = 1;
   while (w.res_rounds < kMaxRounds && blocks_for(R.n, w.res_rounds) > 2048) w.res_rounds *= 2;
-  w.res_blocks = blocks_for(R.n, w.res_rounds);
-  w.unit_weights = 1;
-  w.res_buf = 0;
+  w.res_blocks = (uint16_t)blocks_for(R.n, w.res_rounds);
+  w.flags = kItemUnitWeights;
   const float K[9] = {C.fx, 0.0f, C.ox, 0.0f, C.fy, C.oy, 0.0f, 0.0f, 1.0f};
   for (int i = 0; i < 3; ++i)
     for (int c = 0; c < 4; ++c)
@@ -1576,9 +1597,9 @@ int dvo_amd_bench_residual_pass(dvo_amd_context *ctx, dvo_amd_pyramid *reference
   proto.ref = reference->selections[sel].ref_desc + level;
   proto.cur = current->cur_desc + level;
   proto.res_rounds = rounds;
-  proto.res_blocks = blocks_for(R.n, rounds);
-  proto.unit_weights = 0;
-  proto.P_res[0] = 1500.0f, proto.P_res[3] = 7000.0f;  // a typical precision: the weights take the non-trivial branch
+  proto.res_blocks = (uint16_t)blocks_for(R.n, rounds);
+  proto.flags = 0;
+  proto.P[0] = 1500.0f, proto.P[3] = 7000.0f;  // a typical precision: the weights take the non-trivial branch
   const float K[9] = {C.fx, 0.0f, C.ox, 0.0f, C.fy, C.oy, 0.0f, 0.0f, 1.0f};
   for (int i = 0; i < 3; ++i)
     for (int cc = 0; cc < 4; ++cc)
@@ -1627,6 +1648,17 @@ int dvo_amd_debug_finalize_stamps(dvo_amd_context *ctx, unsigned long long *stam
 void dvo_amd_se3_exp(const double *xi, double *T) { se3_matrix(se3_exp(xi), T); }
 void dvo_amd_se3_log(const double *T, double *xi) { se3_log(se3_from_matrix(T), xi); }
 void dvo_amd_solve6(const double *A, const double *b, double *x) { solve_ldlt6(A, b, x); }
+
+int dvo_amd_debug_tick_log(dvo_amd_context *ctx, double *out, int capacity_records, int *n_records) {
+  if (!ctx || !n_records) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  const int n = (int)(ctx->tick_log.size() / 6);
+  *n_records = n;
+  if (out) {
+    for (int i = 0; i < std::min(n, capacity_records) * 6; ++i) out[i] = ctx->tick_log[(size_t)i];
+    ctx->tick_log.clear();
+  }
+  return DVO_AMD_OK;
+}
 
 int dvo_amd_kernel_timing(dvo_amd_context *ctx, int enable, double *ms_residual_pass, long long *n_launches, int reset) {
   if (!ctx) return DVO_AMD_ERR_INVALID_ARGUMENT;

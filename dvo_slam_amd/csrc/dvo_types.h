@@ -59,18 +59,22 @@ struct TickItem {
   const RefLevelDesc *ref;
   const CurLevelDesc *cur;
   const SlotDesc *slot;
-  int res_blocks, ll_blocks;  // blocks this item runs (a band of the level when the pair is sharded)
-  int res_first, ll_first;    // first logical block of the band (0 for the whole level)
-  int res_rounds, ll_rounds;  // rounds per wave
-  int res_buf, ll_buf;        // which residual buffer is written / read
-  int unit_weights;           // first iteration on a level: weights = 1 (dense_tracking.cpp:286-289)
-  int ll_cut_rank;            // log-likelihood pass: keep valid pixels whose rank within the band is below this (Q6)
-  float kt[12];               // K * T[0:3,0:4], row-major, float (dense_tracking_impl.cpp:142-152)
-  float P_res[4];             // precision of the previous iteration (weights), column-major
-  float P_ll[4];              // precision of the iteration whose likelihood is evaluated
+  uint16_t res_blocks, ll_blocks;  // blocks this item runs (a band of the level when the pair is sharded), <= 2048 each
+  uint16_t res_first, ll_first;    // first logical block of the band (0 for the whole level)
+  uint8_t res_rounds, ll_rounds;   // rounds per wave
+  uint8_t flags;                   // kItem* bits
+  uint8_t pad;
+  int ll_cut_rank;                 // log-likelihood pass: keep valid pixels whose rank within the band is below this (Q6)
+  float kt[12];                    // K * T[0:3,0:4], row-major, float (dense_tracking_impl.cpp:142-152)
+  float P[4];                      // column-major 2x2 precision: of the iteration whose likelihood is evaluated, which is
+                                   // also the one the residual pass of the next iteration takes its weights from
 };
+constexpr unsigned kItemResBuf = 1;       // which residual buffer the residual pass writes
+constexpr unsigned kItemLlBuf = 2;        // which residual buffer the log-likelihood pass reads
+constexpr unsigned kItemUnitWeights = 4;  // first iteration on a level: weights = 1 (dense_tracking.cpp:286-289)
+static_assert(sizeof(TickItem) == 104, "TickItem is packed to fit many items into one kernel-argument block");
 
-constexpr int kMaxItemsPerLaunch = 26;
+constexpr int kMaxItemsPerLaunch = 36;
 struct TickArgs {
   int n_items;
   int pad;

@@ -332,7 +332,7 @@ int dvo_amd_error_image(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_am
  * `reps` timed repetitions of the fused residual pass over `n_items` copies of one (reference level, current level) pair
  * at the float transform T (column-major 4x4), `rounds` rounds per wave (1, 2, 4, 8 or 16; 0 = the driver's choice).
  * avg_ms: HIP-event time per repetition on the context's stream; alg_bytes: 56 B x selected points x n_items;
- * n_launches: kernel launches one repetition needs (the argument block holds 30 items). */
+ * n_launches: kernel launches one repetition needs (the argument block holds 36 items). */
 int dvo_amd_bench_residual_pass(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, int level,
                                 const float *T, int n_items, int rounds, int reps, double *avg_ms, double *alg_bytes,
                                 int *n_launches);
@@ -340,6 +340,11 @@ int dvo_amd_bench_residual_pass(dvo_amd_context *ctx, dvo_amd_pyramid *reference
 /* Diagnostic: with DVO_AMD_FIN_STAMPS=1 in the environment the finalize kernel records 8 shader-clock stamps of its phases
  * (block 0 of the most recent launch); this reads them back. */
 int dvo_amd_debug_finalize_stamps(dvo_amd_context *ctx, unsigned long long *stamps8);
+
+/* Diagnostic: while dvo_amd_kernel_timing is enabled every k_tick launch is logged as 6 doubles {ms, items, residual-pass
+ * blocks, likelihood blocks, grid.x, selected reference pixels of the residual items}; this reads and clears the log
+ * (out may be NULL to query the count). */
+int dvo_amd_debug_tick_log(dvo_amd_context *ctx, double *out, int capacity_records, int *n_records);
 
 /* Host-side helpers (no GPU needed): the SE(3) exponential / logarithm with Sophus' tangent order (upsilon, omega) and the
  * pivoted LDL^T 6x6 solve the driver uses in place of Sophus::SE3d::exp/log and Eigen::LDLT (dense_tracking.cpp:238,259,347).
