@@ -100,6 +100,12 @@ typedef float v4f __attribute__((ext_vector_type(4)));               // plain ve
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f_a8 __attribute__((ext_vector_type(4), aligned(8)));  // 16 bytes that are only 8-byte aligned
 typedef const DVO_GLOBAL float *gcf;
+// load at (uniform base) + (32-bit unsigned byte offset): selects the scalar-base + 32-bit vector-offset addressing
+// mode of global_load, so no 64-bit address arithmetic is spent per access
+template <class T, int IMM = 0>
+__device__ __forceinline__ T ld_off(const DVO_GLOBAL void *base, unsigned byte_off) {
+  return *reinterpret_cast<const DVO_GLOBAL T *>(reinterpret_cast<const DVO_GLOBAL char *>(base) + byte_off + IMM);
+}
 typedef const DVO_GLOBAL v4f *gcf4;
 
 
@@ -159,13 +165,15 @@ __device__ __forceinline__ Proj project_pixel_rtz(const TickItem &it, const Leve
 }
 
 __device__ __forceinline__ Gathered gather_pixel(const LevelPairDesc &d, int base) {
-  const gcf4 ca = (gcf4)d.c_a;
-  const gcf cb = (gcf)d.c_b;
+  const DVO_GLOBAL void *ca = (const DVO_GLOBAL void *)d.c_a, *cb = (const DVO_GLOBAL void *)d.c_b;
+  const unsigned ub = (unsigned)base, row = (unsigned)d.w;
+  const unsigned oa0 = ub * 16u, oa1 = (ub + row) * 16u;  // {I, Z, Ix, Iy}: 16 bytes per pixel
+  const unsigned ob0 = ub * 8u, ob1 = (ub + row) * 8u;    // {Zx, Zy}: 8 bytes per pixel
   Gathered g;
-  g.a00 = ca[base], g.a10 = ca[base + 1];
-  g.a01 = ca[base + d.w], g.a11 = ca[base + d.w + 1];
-  g.b0 = *reinterpret_cast<const DVO_GLOBAL v4f_a8 *>(cb + 2 * base);
-  g.b1 = *reinterpret_cast<const DVO_GLOBAL v4f_a8 *>(cb + 2 * (base + d.w));
+  g.a00 = ld_off<v4f>(ca, oa0), g.a10 = ld_off<v4f, 16>(ca, oa0);
+  g.a01 = ld_off<v4f>(ca, oa1), g.a11 = ld_off<v4f, 16>(ca, oa1);
+  g.b0 = ld_off<v4f_a8>(cb, ob0);
+  g.b1 = ld_off<v4f_a8>(cb, ob1);
   return g;
 }
 
@@ -226,9 +234,9 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
   const int seg = lb * kWavesPerBlock + wave;
   const int w = d.w;
   const int steps = it.res_rounds * kPxPerLane;  // a segment is res_rounds * 256 pixels = steps * 64
-  int idx = seg * (kSegPxPerRound * it.res_rounds) + lane;
-  int prow = idx / w;
-  int pcol = idx - prow * w;
+  unsigned idx = (unsigned)(seg * (kSegPxPerRound * it.res_rounds) + lane);
+  unsigned prow = idx / (unsigned)w;
+  unsigned pcol = idx - prow * (unsigned)w;
 
   float acc[ACC == 0 ? kNumAcc : 1];
 #pragma unroll
@@ -245,25 +253,49 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
   const unsigned long long below = (1ull << lane) - 1ull;
   const bool unit_w = (it.flags & kItemUnitWeights) != 0;
   const float P0 = it.P[0], P1 = it.P[1], P2 = it.P[2], P3 = it.P[3];
-  const gcf p_z = (gcf)d.r_zsel, p_i = (gcf)d.r_i, p_ix = (gcf)d.r_ix, p_iy = (gcf)d.r_iy, p_tx = (gcf)d.tx, p_ty = (gcf)d.ty;
-  DVO_GLOBAL v2f *const p_res = (DVO_GLOBAL v2f *)((it.flags & kItemResBuf) ? d.res[1] : d.res[0]);  // no dynamic index: keeps d in registers
+  const DVO_GLOBAL void *const p_z = (const DVO_GLOBAL void *)d.r_zsel, *const p_i = (const DVO_GLOBAL void *)d.r_i,
+                         *const p_ix = (const DVO_GLOBAL void *)d.r_ix, *const p_iy = (const DVO_GLOBAL void *)d.r_iy,
+                         *const p_tx = (const DVO_GLOBAL void *)d.tx, *const p_ty = (const DVO_GLOBAL void *)d.ty;
+  DVO_GLOBAL char *const p_res = (DVO_GLOBAL char *)((it.flags & kItemResBuf) ? d.res[1] : d.res[0]);  // no dynamic index: keeps d in registers
 
-  // reference scalars of the step about to be processed (loaded one step ahead)
-  float n_z = p_z[idx], n_i = p_i[idx], n_ix = p_ix[idx], n_iy = p_iy[idx];
-  float n_tx = p_tx[pcol], n_ty = p_ty[prow < d.h ? prow : d.h - 1];
+  // reference scalars of the step about to be processed (loaded one step ahead); all accesses are uniform base + 32-bit offset
+  float n_z = ld_off<float>(p_z, 4u * idx), n_i = ld_off<float>(p_i, 4u * idx), n_ix = ld_off<float>(p_ix, 4u * idx),
+        n_iy = ld_off<float>(p_iy, 4u * idx);
+  float n_tx = ld_off<float>(p_tx, 4u * pcol), n_ty = ld_off<float>(p_ty, 4u * (prow < d.h ? prow : d.h - 1));
 
-  for (int step = 0; step < steps; ++step) {
-    const int cur_idx = idx;
+  // Operand fetch of the Gram-matrix accumulation: lane l supplies component l & 15 of points 4 m + (l >> 4), m = 0..15, of
+  // the 64 points a step staged.  With the write swizzle below, chunk (comp >> 2) of point p sits at chunk position
+  // (comp >> 2) ^ ((p >> 1) & 3) = cb for even m and cb ^ 2 for odd m (cb = (comp >> 2) ^ (l >> 5)): two lane-constant
+  // offsets plus compile-time immediates, no per-step address arithmetic.
+  const int g_comp = lane & 15, g_sub = lane >> 4, g_cb = (g_comp >> 2) ^ (g_sub >> 1);
+  const float *const g_even = stage + (wave * 2 * kWave + g_sub) * 16 + ((g_cb << 2) | (g_comp & 3));
+  const float *const g_odd = stage + (wave * 2 * kWave + g_sub) * 16 + (((g_cb ^ 2) << 2) | (g_comp & 3));
+  auto gram_from_stage = [&](const int q) __attribute__((always_inline)) {
+#pragma unroll
+    for (int m = 0; m < 16; m += 2) {
+      const float va = g_even[q * kWave * 16 + 64 * m];
+      const float vb = g_odd[q * kWave * 16 + 64 * (m + 1)];
+      gram_a = __builtin_amdgcn_mfma_f32_16x16x4f32(va, va, gram_a, 0, 0, 0);
+      gram_b = __builtin_amdgcn_mfma_f32_16x16x4f32(vb, vb, gram_b, 0, 0, 0);
+    }
+  };
+
+  // One step = 64 consecutive pixels, one per lane.  The loop is unrolled by two (a segment always has a multiple of four
+  // steps) so that the staging-buffer parity q is a compile-time constant and the one-step-ahead prefetch registers need
+  // no rotation moves.
+  auto do_step = [&](const int step, const int q) __attribute__((always_inline)) {
+    const unsigned cur_idx = idx;
     // ---- round-to-nearest: reference point = pixel ray * depth (RgbdCamera::buildPointCloud, rgbd_image.cpp:245-262)
     float z = n_z, ri = n_i, rix = n_ix, riy = n_iy;
     float x = n_tx * z, y = n_ty * z;
     // prefetch the next step's reference scalars; they are consumed a whole step later
     idx += kWave;
     pcol += kWave;
-    while (pcol >= w) pcol -= w, ++prow;
+    while (pcol >= (unsigned)w) pcol -= (unsigned)w, ++prow;
     if (step + 1 < steps) {
-      n_z = p_z[idx], n_i = p_i[idx], n_ix = p_ix[idx], n_iy = p_iy[idx];
-      n_tx = p_tx[pcol], n_ty = p_ty[prow < d.h ? prow : d.h - 1];
+      n_z = ld_off<float>(p_z, 4u * idx), n_i = ld_off<float>(p_i, 4u * idx), n_ix = ld_off<float>(p_ix, 4u * idx),
+      n_iy = ld_off<float>(p_iy, 4u * idx);
+      n_tx = ld_off<float>(p_tx, 4u * pcol), n_ty = ld_off<float>(p_ty, 4u * (prow < d.h ? prow : d.h - 1));
     }
 
     // ---- switch to round-toward-zero: every float that crosses is made opaque on both sides of the s_setreg
@@ -287,16 +319,7 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
       // the toward-zero window).  This overlaps ~512 matrix-pipe cycles with the gather latency and with the next
       // wave's arithmetic instead of serialising them behind this wave's own VALU work.
       if (ACC == 1 && !(DVO_ABLATE & 1) && step > 0) {
-        const float *buf = stage + ((wave * 2 + ((step - 1) & 1)) * kWave) * 16;
-        const int comp = lane & 15, sub = lane >> 4;
-#pragma unroll
-        for (int m = 0; m < 16; m += 2) {
-          const int pa = 4 * m + sub, pb = pa + 4;
-          const float va = buf[pa * 16 + ((((comp >> 2) ^ ((pa >> 1) & 3)) << 2) | (comp & 3))];
-          const float vb = buf[pb * 16 + ((((comp >> 2) ^ ((pb >> 1) & 3)) << 2) | (comp & 3))];
-          gram_a = __builtin_amdgcn_mfma_f32_16x16x4f32(va, va, gram_a, 0, 0, 0);
-          gram_b = __builtin_amdgcn_mfma_f32_16x16x4f32(vb, vb, gram_b, 0, 0, 0);
-        }
+        gram_from_stage(q ^ 1);
         __builtin_amdgcn_sched_barrier(0);
       }
       finish_pixel_rtz(d, p, g, z, ri, rix, riy, r0, r1, e2, e3, e4, e5, ok);
@@ -317,7 +340,7 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
         DVO_KEEP(sv.x);
         DVO_KEEP(sv.y);
       } else {
-        p_res[cur_idx] = sv;
+        *reinterpret_cast<DVO_GLOBAL v2f *>(p_res + 8u * cur_idx) = sv;
       }
     }
 
@@ -325,9 +348,10 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
     // computeWeightsSse / computeWeight: w = (2+5)/(5 + r^T P r), mean 0 (dense_tracking_impl.cpp:640-707)
     float wgt = 1.0f;
     if (!unit_w) {
-      const float t0 = r0 * P0 + r1 * P1;
-      const float t1 = r0 * P2 + r1 * P3;
-      const float dd = t0 * r0 + t1 * r1;
+      // (round-to-nearest section: fused multiply-adds are fine here, only the toward-zero stage is bit-matched)
+      const float t0 = __builtin_fmaf(r0, P0, r1 * P1);
+      const float t1 = __builtin_fmaf(r0, P2, r1 * P3);
+      const float dd = __builtin_fmaf(t0, r0, t1 * r1);
       wgt = 7.0f * __builtin_amdgcn_rcpf(5.0f + dd);
     }
     wgt = ok ? wgt : 0.0f;
@@ -337,22 +361,22 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
     const float iz = __builtin_amdgcn_rcpf(z);
     const float iz2 = iz * iz;
     const float j02 = -x * iz2, j12 = -y * iz2;
-    const float j03 = j02 * y, j13 = -1.0f + j12 * y;
-    const float j04 = 1.0f - j02 * x, j14 = -j03;
+    const float j03 = j02 * y, j13 = __builtin_fmaf(j12, y, -1.0f);
+    const float j04 = __builtin_fmaf(-j02, x, 1.0f), j14 = -j03;
     const float j05 = -y * iz, j15 = x * iz;
     float Ja[6], Jb[6];
     Ja[0] = e2 * iz;
     Ja[1] = e3 * iz;
-    Ja[2] = e2 * j02 + e3 * j12;
-    Ja[3] = e2 * j03 + e3 * j13;
-    Ja[4] = e2 * j04 + e3 * j14;
-    Ja[5] = e2 * j05 + e3 * j15;
+    Ja[2] = __builtin_fmaf(e2, j02, e3 * j12);
+    Ja[3] = __builtin_fmaf(e2, j03, e3 * j13);
+    Ja[4] = __builtin_fmaf(e2, j04, e3 * j14);
+    Ja[5] = __builtin_fmaf(e2, j05, e3 * j15);
     Jb[0] = e4 * iz;
     Jb[1] = e5 * iz;
-    Jb[2] = (e4 * j02 + e5 * j12) - 1.0f;
-    Jb[3] = (e4 * j03 + e5 * j13) - y;
-    Jb[4] = (e4 * j04 + e5 * j14) + x;
-    Jb[5] = e4 * j05 + e5 * j15;
+    Jb[2] = __builtin_fmaf(e4, j02, __builtin_fmaf(e5, j12, -1.0f));
+    Jb[3] = __builtin_fmaf(e4, j03, __builtin_fmaf(e5, j13, -y));
+    Jb[4] = __builtin_fmaf(e4, j04, __builtin_fmaf(e5, j14, x));
+    Jb[5] = __builtin_fmaf(e4, j05, e5 * j15);
     // A += J^T (w P) J and b -= J^T (w P) r are linear in P: accumulate the P-free moments (87 sums)
     if (ACC == 0) {
       float wa[6], wb[6];
@@ -383,7 +407,7 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
       // stage sqrt(w) * v for this lane's pixel; chunk c of point p sits at chunk position c ^ ((p >> 1) & 3).
       // Two buffers alternate: the matrix pipe consumes this one during the NEXT step (see above).
       const float sw = __builtin_amdgcn_sqrtf(wgt);
-      float *buf = stage + ((wave * 2 + (step & 1)) * kWave) * 16;
+      float *buf = stage + ((wave * 2 + q) * kWave) * 16;
       v4f *row = reinterpret_cast<v4f *>(buf + lane * 16);
       const int swz = (lane >> 1) & 3;
       v4f c0 = {sw * Ja[0], sw * Ja[1], sw * Ja[2], sw * Ja[3]};
@@ -405,7 +429,7 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
     if (DVO_ABLATE & 4) {
       S0[0] += wgt * r0;
       run_count += ok ? 1 : 0;
-      continue;
+      return;
     }
     // ---- rank of every valid pixel in scan order within this wave's segment (needed by the pair quirk Q5)
     const unsigned long long bk = __ballot(ok);
@@ -440,20 +464,13 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
       carry_has = true;
     }
     run_count += __popcll(bk);
+  };
+  for (int step = 0; step < steps; step += 2) {
+    do_step(step, 0);
+    do_step(step + 1, 1);
   }
 
-  if (ACC == 1 && !(DVO_ABLATE & 1) && steps > 0) {
-    const float *buf = stage + ((wave * 2 + ((steps - 1) & 1)) * kWave) * 16;
-    const int comp = lane & 15, sub = lane >> 4;
-#pragma unroll
-    for (int m = 0; m < 16; m += 2) {
-      const int pa = 4 * m + sub, pb = pa + 4;
-      const float va = buf[pa * 16 + ((((comp >> 2) ^ ((pa >> 1) & 3)) << 2) | (comp & 3))];
-      const float vb = buf[pb * 16 + ((((comp >> 2) ^ ((pb >> 1) & 3)) << 2) | (comp & 3))];
-      gram_a = __builtin_amdgcn_mfma_f32_16x16x4f32(va, va, gram_a, 0, 0, 0);
-      gram_b = __builtin_amdgcn_mfma_f32_16x16x4f32(vb, vb, gram_b, 0, 0, 0);
-    }
-  }
+  if (ACC == 1 && !(DVO_ABLATE & 1) && steps > 0) gram_from_stage(1);  // the last step (odd index) staged into buffer 1
 
   // ---- wave reduction, then the four waves of the block through LDS
   __shared__ float sm[kWavesPerBlock][kRecStride];

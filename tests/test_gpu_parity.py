@@ -157,7 +157,12 @@ def test_match_640x480_4_levels(capi, orc, synth, pair640):
     src = its[-2] if last["TerminationCriterion"] == 2 else its[-1]
     assert np.allclose(rg.Information, src["EstimateInformation"] * 0.008 * 0.008)
     assert rg.LogLikelihood == src["TDistributionLogLikelihood"] + src["PriorLogLikelihood"]
-    assert np.allclose(rg.Information, ro["information"], rtol=5e-3, atol=5e-3 * np.abs(ro["information"]).max())
+    # the final information matrix carries the scale P of the last accepted iteration; if GPU and oracle end on different
+    # iterations of the last level (forked path, see DIVERGED_PATH_TOL) it is only comparable to the size of that step
+    same_path = all(Lg["TerminationCriterion"] == Lo["termination"] and len(Lg["Iterations"]) == len(Lo["iterations"])
+                    for Lg, Lo in zip(rg.Levels, ro["levels"]))
+    tol = 5e-3 if same_path else 0.15
+    assert np.allclose(rg.Information, ro["information"], rtol=tol, atol=tol * np.abs(ro["information"]).max())
 
 
 def test_match_reference_default_levels(capi, orc, synth, pair640):

@@ -194,7 +194,8 @@ def _compare(synth, got, want):
         assert g[2] == w[2], (g[0], g[1], g[2], w[2], g[3], w[3])
         # the likelihood of a finished alignment moves by ~1e-3 relative when GPU and oracle fork by one accepted step
         # (chaos caveat of tests/test_gpu_parity.py); thresholds are placed mid-gap so that decisions cannot flip on that
-        assert np.allclose(g[3], w[3], rtol=1e-2, atol=1e-4), (g[3], w[3])
+        # (the cross-validation value is the norm of a pose difference: absolute tolerance = two forked alignments)
+        assert np.allclose(g[3], w[3], rtol=1e-2, atol=2 * DIVERGED_PATH_TOL), (g[3], w[3])
         assert abs(g[5] - w[5]) <= 1e-2 * max(1.0, abs(w[5]))
         err = synth.pose_error(g[4], w[4])
         assert err <= DIVERGED_PATH_TOL, err
