@@ -148,8 +148,7 @@ struct Gathered {
   v4f_a8 b0, b1;           // {Zx, Zy} pairs of the upper and lower row
 };
 
-__device__ __forceinline__ Proj project_pixel_rtz(const TickItem &it, const LevelPairDesc &d, float x, float y, float z) {
-  const float *kt = it.kt;
+__device__ __forceinline__ Proj project_pixel_rtz(const float *kt, const LevelPairDesc &d, float x, float y, float z) {
   // hadd(hadd()) adds lanes (0,1) and (2,3) first (:178-188); the point's w is 1
   const float sx = (kt[0] * x + kt[1] * y) + (kt[2] * z + kt[3]);
   const float sy = (kt[4] * x + kt[5] * y) + (kt[6] * z + kt[7]);
@@ -250,6 +249,14 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
   float carry_r0 = 0.0f, carry_r1 = 0.0f;   // wave uniform: residual of the last valid pixel of earlier steps
   bool carry_has = false;
 
+  // K*T lives in vector registers: as scalars the 12 values do not fit next to the descriptors, and the compiler re-reads
+  // them from the kernel arguments inside every step, with a full scalar-memory wait in front of the projection
+  float kt[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    kt[i] = it.kt[i];
+    DVO_OPAQUE(kt[i]);
+  }
   const unsigned long long below = (1ull << lane) - 1ull;
   const bool unit_w = (it.flags & kItemUnitWeights) != 0;
   const float P0 = it.P[0], P1 = it.P[1], P2 = it.P[2], P3 = it.P[3];
@@ -283,7 +290,7 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
   // One step = 64 consecutive pixels, one per lane.  The loop is unrolled by two (a segment always has a multiple of four
   // steps) so that the staging-buffer parity q is a compile-time constant and the one-step-ahead prefetch registers need
   // no rotation moves.
-  auto do_step = [&](const int step, const int q) __attribute__((always_inline)) {
+  auto do_step = [&](const int step, const int q, const bool prefetch) __attribute__((always_inline)) {
     const unsigned cur_idx = idx;
     // ---- round-to-nearest: reference point = pixel ray * depth (RgbdCamera::buildPointCloud, rgbd_image.cpp:245-262)
     float z = n_z, ri = n_i, rix = n_ix, riy = n_iy;
@@ -292,7 +299,7 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
     idx += kWave;
     pcol += kWave;
     while (pcol >= (unsigned)w) pcol -= (unsigned)w, ++prow;
-    if (step + 1 < steps) {
+    if (prefetch) {
       n_z = ld_off<float>(p_z, 4u * idx), n_i = ld_off<float>(p_i, 4u * idx), n_ix = ld_off<float>(p_ix, 4u * idx),
       n_iy = ld_off<float>(p_iy, 4u * idx);
       n_tx = ld_off<float>(p_tx, 4u * pcol), n_ty = ld_off<float>(p_ty, 4u * (prow < d.h ? prow : d.h - 1));
@@ -305,7 +312,7 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
     float r0, r1, e2, e3, e4, e5;
     bool ok;
     {
-      const Proj p = project_pixel_rtz(it, d, x, y, z);
+      const Proj p = project_pixel_rtz(kt, d, x, y, z);
       Gathered g;
       if (DVO_ABLATE & 2) {
         const v4f c = {p.u, 1.5f, p.v, 0.25f};
@@ -445,8 +452,8 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
       // computeScaleSse with Q5: a pair (2j, 2j+1) contributes (w_2j + w_2j+1) r_2j r_2j^T (:603-621).
       // S0 assumes this segment starts on an even global rank, S1 on an odd one.  Invalid pixels have weight 0.
       const float sxx = r0 * r0, sxy = r0 * r1, syy = r1 * r1;
-      const float pxx = prev_has ? prev_r0 * prev_r0 : 0.0f, pxy = prev_has ? prev_r0 * prev_r1 : 0.0f,
-                  pyy = prev_has ? prev_r1 * prev_r1 : 0.0f;
+      // without a preceding valid pixel prev_r0 = prev_r1 = 0 (the initial carry), so the products vanish by themselves
+      const float pxx = prev_r0 * prev_r0, pxy = prev_r0 * prev_r1, pyy = prev_r1 * prev_r1;
       const bool odd = (rank & 1) != 0;
       S0[0] = __builtin_fmaf(wgt, odd ? pxx : sxx, S0[0]);
       S0[1] = __builtin_fmaf(wgt, odd ? pxy : sxy, S0[1]);
@@ -465,10 +472,13 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
     }
     run_count += __popcll(bk);
   };
-  for (int step = 0; step < steps; step += 2) {
-    do_step(step, 0);
-    do_step(step + 1, 1);
+  // the last pair of steps is peeled so that "is there a next step to prefetch" is a compile-time fact in every copy
+  for (int step = 0; step + 2 < steps; step += 2) {
+    do_step(step, 0, true);
+    do_step(step + 1, 1, true);
   }
+  do_step(steps - 2, 0, true);
+  do_step(steps - 1, 1, false);
 
   if (ACC == 1 && !(DVO_ABLATE & 1) && steps > 0) gram_from_stage(1);  // the last step (odd index) staged into buffer 1
 
