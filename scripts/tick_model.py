@@ -29,6 +29,14 @@ order = np.argsort(px)
 for q in (0.0, 0.1, 0.25, 0.5, 0.75, 0.9, 1.0):
     i = order[min(int(q * (len(order) - 1)), len(order) - 1)]
     print(f"q{q:.2f}: {t[i] * 1e3:7.1f} us items {int(items[i]):3d} res_blocks {int(rb[i]):6d} ll_blocks {int(lb[i]):6d} grid.x {int(gx[i]):5d} "
-          f"px {int(px[i]):9d} -> {px[i] * 56 / t[i] / 1e9:7.1f} GB/s")
+          f"px {int(px[i]):9d} -> {px[i] * 56 / t[i] / 1e9:7.2f} TB/s")
 print("time share by px-quartile:", [round(float(t[order[int(a * len(order)):int(b * len(order))]].sum() / t.sum()), 3)
                                     for a, b in ((0, .25), (.25, .5), (.5, .75), (.75, 1))])
+# by level (lock-step batches are homogeneous): group launches by their selected pixels per residual item
+per_item = np.where(items > 0, px / np.maximum(items, 1), 0)
+for lo, hi, name in ((0, 1, "LL only"), (1, 6000, "L3"), (6000, 25000, "L2"), (25000, 100000, "L1"), (100000, 1e9, "L0")):
+    m = (per_item >= lo) & (per_item < hi)
+    if m.any():
+        print(f"{name:8s}: {int(m.sum()):4d} launches, avg {t[m].mean() * 1e3:7.1f} us, time share {t[m].sum() / t.sum():.3f}, "
+              f"bytes share {px[m].sum() / max(px.sum(), 1):.3f}, {px[m].sum() * 56 / t[m].sum() / 1e9:.2f} TB/s, "
+              f"avg items {items[m].mean():.1f}, avg ll_blocks/item {lb[m].sum() / items[m].sum():.0f}")
