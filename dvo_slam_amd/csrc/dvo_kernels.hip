@@ -650,9 +650,8 @@ __device__ __forceinline__ LevelPairDesc load_desc(const TickItem &it) {
   return d;
 }
 
-template <int RMODE, int ACC, int OCC>
-__global__ __launch_bounds__(kBlockThreads, OCC) void k_tick(const TickArgs args) {
-  const TickItem &it = args.items[blockIdx.y];
+template <int RMODE, int ACC>
+__device__ __forceinline__ void tick_body(const TickItem &it) {
   const int bx = (int)blockIdx.x;
   if (bx >= it.res_blocks + it.ll_blocks) return;
   const LevelPairDesc d = load_desc(it);
@@ -660,6 +659,28 @@ __global__ __launch_bounds__(kBlockThreads, OCC) void k_tick(const TickArgs args
     residual_pass<RMODE, ACC>(it, d, it.res_first + xcd_contiguous_block(bx, it.res_blocks));
   else
     loglik_pass(it, d, it.ll_first + (bx - it.res_blocks));
+}
+
+template <int RMODE, int ACC, int OCC>
+__global__ __launch_bounds__(kBlockThreads, OCC) void k_tick(const TickArgs args) {
+  tick_body<RMODE, ACC>(args.items[blockIdx.y]);
+}
+
+// The same tick with the items in a device-resident table (uploaded in-stream before the launch): for launches with more
+// resident pairs than fit the 4 KB kernel-argument block.  The item is pulled into scalar registers once per block.
+template <int RMODE, int ACC, int OCC>
+__global__ __launch_bounds__(kBlockThreads, OCC) void k_tick_table(const TickItem *items) {
+  const DVO_CONST TickItem *p = (const DVO_CONST TickItem *)items + blockIdx.y;
+  TickItem it;
+  it.ref = p->ref, it.cur = p->cur, it.slot = p->slot;
+  it.res_blocks = p->res_blocks, it.ll_blocks = p->ll_blocks, it.res_first = p->res_first, it.ll_first = p->ll_first;
+  it.res_rounds = p->res_rounds, it.ll_rounds = p->ll_rounds, it.flags = p->flags, it.pad = 0;
+  it.ll_cut_rank = p->ll_cut_rank;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) it.kt[i] = p->kt[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) it.P[i] = p->P[i];
+  tick_body<RMODE, ACC>(it);
 }
 
 static int g_reduce_mode = -1;  // DVO_AMD_REDUCE=0: ds_bpermute butterfly instead of DPP (debug cross-check)
@@ -690,6 +711,13 @@ hipError_t launch_tick(const TickArgs &args, int max_blocks, hipStream_t stream)
     else
       hipLaunchKernelGGL((k_tick<1, 1, 4>), grid, dim3(kBlockThreads), 0, stream, args);
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_tick_table(const TickItem *items_dev, int n_items, int max_blocks, hipStream_t stream) {
+  if (n_items <= 0 || max_blocks <= 0) return hipSuccess;
+  dim3 grid((unsigned)((max_blocks + 7) & ~7), (unsigned)n_items, 1);
+  hipLaunchKernelGGL((k_tick_table<1, 1, 4>), grid, dim3(kBlockThreads), 0, stream, items_dev);
   return hipGetLastError();
 }
 

@@ -377,6 +377,10 @@ struct dvo_amd_context {
   int out_capacity = 0;
   SlotDesc *slot_desc = nullptr;       // device, [slot]
   unsigned *tickets = nullptr;         // device, one arrival counter per tick stream
+  // item tables for launches with more pairs than the kernel-argument block holds: per tick stream a pinned host staging
+  // area and its device copy (uploaded in-stream in front of the launch)
+  TickItem *item_host = nullptr, *item_dev = nullptr;  // [kMaxTickStreams][kMaxTableItems]
+  int items_per_launch = kMaxItemsPerLaunch;           // DVO_AMD_ITEMS_PER_LAUNCH (<= kMaxTableItems)
   // tile-shard exchange (RCCL, loaded with dlopen so that single-GPU users do not depend on it)
   void *rccl_lib = nullptr;
   ncclComm_t comm = nullptr;
@@ -870,8 +874,13 @@ int run_tick(dvo_amd_context *ctx, std::vector<Job> &jobs) {
 
   // split evenly over as few launches as the argument block allows; launch i (and the finalize of its jobs) goes to stream
   // i so that the launches of one tick overlap instead of queueing behind each other's latency floor
-  const size_t n_launch = (items.size() + kMaxItemsPerLaunch - 1) / kMaxItemsPerLaunch;
+  const size_t cap = (size_t)std::min(std::max(ctx->items_per_launch, 1), kMaxTableItems);
+  const size_t n_launch = (items.size() + cap - 1) / cap;
   const size_t per = (items.size() + n_launch - 1) / n_launch;
+  if (per > (size_t)kMaxItemsPerLaunch && !ctx->item_host) {
+    HIP_TRY(hipHostMalloc((void **)&ctx->item_host, sizeof(TickItem) * kMaxTickStreams * kMaxTableItems, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void **)&ctx->item_dev, sizeof(TickItem) * kMaxTickStreams * kMaxTableItems));
+  }
   size_t launch_index = 0;
   for (size_t first = 0; first < items.size(); first += per, ++launch_index) {
     hipStream_t st;
@@ -880,38 +889,49 @@ int run_tick(dvo_amd_context *ctx, std::vector<Job> &jobs) {
       if (rc) return rc;
     }
     TickArgs ta;
-    FinArgs fa;
-    ta.n_items = (int)std::min(per, items.size() - first);
+    const int n_here = (int)std::min(per, items.size() - first);
+    const bool use_table = n_here > kMaxItemsPerLaunch;
+    const size_t stream_slot = (ctx->timing ? 0 : launch_index) % kMaxTickStreams;
+    ta.n_items = use_table ? 0 : n_here;
     ta.pad = 0;
-    fa.n_items = ta.n_items;
-    fa.pad = ctx->fin_stamps ? 0x57A3 : 0;
-    fa.ticket = ctx->tickets + 16 * ((ctx->timing ? 0 : launch_index) % kMaxTickStreams);  // one counter per stream
     int max_blocks = 0;
-    for (int i = 0; i < ta.n_items; ++i) {
-      ta.items[i] = items[first + i];
-      fa.items[i] = fin_items[first + i];
-      max_blocks = std::max(max_blocks, ta.items[i].res_blocks + ta.items[i].ll_blocks);
+    TickItem *stage = use_table ? ctx->item_host + stream_slot * kMaxTableItems : ta.items;
+    for (int i = 0; i < n_here; ++i) {
+      stage[i] = items[first + i];
+      max_blocks = std::max(max_blocks, (int)stage[i].res_blocks + (int)stage[i].ll_blocks);
     }
+    if (use_table && launch_index >= kMaxTickStreams) HIP_TRY(hipStreamSynchronize(st));  // staging of this stream is still in use
+    if (use_table)  // otherwise the staging area is free: the tick that used it has been waited for
+      HIP_TRY(hipMemcpyAsync(ctx->item_dev + stream_slot * kMaxTableItems, stage, sizeof(TickItem) * (size_t)n_here,
+                             hipMemcpyHostToDevice, st));
     size_t ev = 0;
     if (ctx->timing) {
       int rc = timing_begin(ctx, st, &ev);
       if (rc) return rc;
       double rb = 0, lb = 0, px = 0;
-      for (int i = 0; i < ta.n_items; ++i) rb += ta.items[i].res_blocks, lb += ta.items[i].ll_blocks;
+      for (int i = 0; i < n_here; ++i) rb += stage[i].res_blocks, lb += stage[i].ll_blocks;
       for (size_t ji = 0, k = 0; ji < jobs.size(); ++ji) {
         const Job &j = jobs[ji];
         if (j.done || !(j.sub_ll || j.sub_res)) continue;
-        if (k >= first && k < first + (size_t)ta.n_items && j.sub_res) px += (double)j.ref->selections[j.sel].count[j.level];
+        if (k >= first && k < first + (size_t)n_here && j.sub_res) px += (double)j.ref->selections[j.sel].count[j.level];
         ++k;
       }
-      const double rec[6] = {0.0, (double)ta.n_items, rb, lb, (double)max_blocks, px};
+      const double rec[6] = {0.0, (double)n_here, rb, lb, (double)max_blocks, px};
       ctx->tick_log_pending.insert(ctx->tick_log_pending.end(), rec, rec + 6);
     }
-    hipError_t e = launch_tick(ta, max_blocks, st);
+    hipError_t e = use_table ? launch_tick_table(ctx->item_dev + stream_slot * kMaxTableItems, n_here, max_blocks, st)
+                             : launch_tick(ta, max_blocks, st);
     if (e != hipSuccess) return fail_hip("launch_tick", e);
     if (ctx->timing) HIP_TRY(hipEventRecord(ctx->events[ev].second, st));
-    e = launch_finalize(fa, st);
-    if (e != hipSuccess) return fail_hip("launch_finalize", e);
+    for (int f0 = 0; f0 < n_here; f0 += kMaxFinItems) {  // the reduce kernel takes its items by value, 48 per launch
+      FinArgs fa;
+      fa.n_items = std::min(kMaxFinItems, n_here - f0);
+      fa.pad = ctx->fin_stamps ? 0x57A3 : 0;
+      fa.ticket = ctx->tickets + 16 * stream_slot;  // one counter per stream
+      for (int i = 0; i < fa.n_items; ++i) fa.items[i] = fin_items[first + (size_t)f0 + (size_t)i];
+      e = launch_finalize(fa, st);
+      if (e != hipSuccess) return fail_hip("launch_finalize", e);
+    }
   }
   {
     int rc = wait_tick(ctx, jobs, seq);
@@ -1192,6 +1212,10 @@ int dvo_amd_context_create(int device, const dvo_amd_config *cfg, dvo_amd_contex
   ctx->poll = !(pe && pe[0] == '0');
   const char *fs = getenv("DVO_AMD_FIN_STAMPS");
   ctx->fin_stamps = fs && fs[0] == '1';
+  if (const char *ipl = getenv("DVO_AMD_ITEMS_PER_LAUNCH")) {
+    const int v = atoi(ipl);
+    if (v >= 1 && v <= kMaxTableItems) ctx->items_per_launch = v;
+  }
   *out = ctx;
   return DVO_AMD_OK;
 }
@@ -1211,6 +1235,8 @@ void dvo_amd_context_destroy(dvo_amd_context *ctx) {
   if (ctx->out_host) (void)hipHostFree(ctx->out_host);
   if (ctx->slot_desc) (void)hipFree(ctx->slot_desc);
   if (ctx->tickets) (void)hipFree(ctx->tickets);
+  if (ctx->item_host) (void)hipHostFree(ctx->item_host);
+  if (ctx->item_dev) (void)hipFree(ctx->item_dev);
   for (auto &ev : ctx->events) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
