@@ -202,12 +202,13 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic_from_profiles(),
                 "kernel": "k_tick (fused warp+residual+weights+normal equations, with the log-likelihood items of the tick)",
                 "launches": int(k_launches),
                 "avg_launch_us": (k_ms * 1e3 / k_launches) if k_launches else None,
                 "alg_bytes_per_launch": (alg_bytes_k / k_launches) if k_launches else None,
-                "measured": "HIP events on the launching stream, " + ("inside the timed region" if T == 1 else
+                "measured": "HIP events stamped by the dispatch itself (hipExtLaunchKernel start / stop) on the launching "
+                            "stream, " + ("inside the timed region" if T == 1 else
                             "single-stream pass over one host thread's share of the batch, same pairs in flight, right after the timed "
                             "region (which used %d streams at once)" % T),
                 "residual_passes": int(passes),
@@ -289,6 +290,17 @@ def tile_shard_bench(args, capi, synth, sharding, dist, rank, world, device, ref
         }), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def traffic_from_profiles():
+    """HBM-side bytes per k_tick launch from the committed PMC passes (profiles/r01_traffic.json: rocprofv3 --pmc FETCH_SIZE
+    and WRITE_SIZE in separate runs of this command, gfx950 correction applied); counters cannot be read from inside the
+    bench, so this is the figure of the profiled run, not of this one."""
+    try:
+        here = os.path.dirname(os.path.abspath(__file__))
+        return json.load(open(os.path.join(here, "profiles", "r01_traffic.json")))["traffic_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def stream_copy(device):

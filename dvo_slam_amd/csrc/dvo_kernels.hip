@@ -687,7 +687,7 @@ static int g_reduce_mode = -1;  // DVO_AMD_REDUCE=0: ds_bpermute butterfly inste
 static int g_acc_mode = -1;     // DVO_AMD_ACCUM=valu: 87 register accumulators instead of the MFMA Gram matrix
 static int g_occ = 4;           // DVO_AMD_OCC=5: compile-time register budget for 5 waves/SIMD (MFMA form only)
 
-hipError_t launch_tick(const TickArgs &args, int max_blocks, hipStream_t stream) {
+hipError_t launch_tick(const TickArgs &args, int max_blocks, hipStream_t stream, hipEvent_t t_start, hipEvent_t t_stop) {
   if (g_reduce_mode < 0) {
     const char *e = getenv("DVO_AMD_REDUCE");
     g_reduce_mode = (e && e[0] == '0') ? 0 : 1;
@@ -708,16 +708,30 @@ hipError_t launch_tick(const TickArgs &args, int max_blocks, hipStream_t stream)
   } else {
     if (g_reduce_mode == 0)
       hipLaunchKernelGGL((k_tick<0, 1, 4>), grid, dim3(kBlockThreads), 0, stream, args);
+    else if (t_start && t_stop)
+    {
+      void *kargs[] = {const_cast<TickArgs *>(&args)};
+      (void)hipExtLaunchKernel(reinterpret_cast<const void *>(&k_tick<1, 1, 4>), grid, dim3(kBlockThreads), kargs, 0, stream,
+                               t_start, t_stop, 0);
+    }
     else
       hipLaunchKernelGGL((k_tick<1, 1, 4>), grid, dim3(kBlockThreads), 0, stream, args);
   }
   return hipGetLastError();
 }
 
-hipError_t launch_tick_table(const TickItem *items_dev, int n_items, int max_blocks, hipStream_t stream) {
+hipError_t launch_tick_table(const TickItem *items_dev, int n_items, int max_blocks, hipStream_t stream, hipEvent_t t_start,
+                             hipEvent_t t_stop) {
   if (n_items <= 0 || max_blocks <= 0) return hipSuccess;
   dim3 grid((unsigned)((max_blocks + 7) & ~7), (unsigned)n_items, 1);
-  hipLaunchKernelGGL((k_tick_table<1, 1, 4>), grid, dim3(kBlockThreads), 0, stream, items_dev);
+  if (t_start && t_stop)
+  {
+    void *kargs[] = {&items_dev};
+    (void)hipExtLaunchKernel(reinterpret_cast<const void *>(&k_tick_table<1, 1, 4>), grid, dim3(kBlockThreads), kargs, 0,
+                             stream, t_start, t_stop, 0);
+  }
+  else
+    hipLaunchKernelGGL((k_tick_table<1, 1, 4>), grid, dim3(kBlockThreads), 0, stream, items_dev);
   return hipGetLastError();
 }
 

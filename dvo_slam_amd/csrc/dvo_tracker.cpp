@@ -737,7 +737,8 @@ int pick_rounds(long long total_px) {
   return waves1 >= 65536 ? 4 : waves1 >= 8192 ? 2 : 1;
 }
 
-int timing_begin(dvo_amd_context *ctx, hipStream_t stream, size_t *slot) {
+// a pair of events for the next timed launch; the launch itself stamps them (begin / end of that dispatch)
+int timing_begin(dvo_amd_context *ctx, size_t *slot) {
   if (ctx->events_used == ctx->events.size()) {
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a));
@@ -745,7 +746,6 @@ int timing_begin(dvo_amd_context *ctx, hipStream_t stream, size_t *slot) {
     ctx->events.emplace_back(a, b);
   }
   *slot = ctx->events_used++;
-  HIP_TRY(hipEventRecord(ctx->events[*slot].first, stream));
   return DVO_AMD_OK;
 }
 
@@ -906,7 +906,7 @@ int run_tick(dvo_amd_context *ctx, std::vector<Job> &jobs) {
                              hipMemcpyHostToDevice, st));
     size_t ev = 0;
     if (ctx->timing) {
-      int rc = timing_begin(ctx, st, &ev);
+      int rc = timing_begin(ctx, &ev);
       if (rc) return rc;
       double rb = 0, lb = 0, px = 0;
       for (int i = 0; i < n_here; ++i) rb += stage[i].res_blocks, lb += stage[i].ll_blocks;
@@ -919,10 +919,10 @@ int run_tick(dvo_amd_context *ctx, std::vector<Job> &jobs) {
       const double rec[6] = {0.0, (double)n_here, rb, lb, (double)max_blocks, px};
       ctx->tick_log_pending.insert(ctx->tick_log_pending.end(), rec, rec + 6);
     }
-    hipError_t e = use_table ? launch_tick_table(ctx->item_dev + stream_slot * kMaxTableItems, n_here, max_blocks, st)
-                             : launch_tick(ta, max_blocks, st);
+    hipEvent_t t0 = ctx->timing ? ctx->events[ev].first : nullptr, t1 = ctx->timing ? ctx->events[ev].second : nullptr;
+    hipError_t e = use_table ? launch_tick_table(ctx->item_dev + stream_slot * kMaxTableItems, n_here, max_blocks, st, t0, t1)
+                             : launch_tick(ta, max_blocks, st, t0, t1);
     if (e != hipSuccess) return fail_hip("launch_tick", e);
-    if (ctx->timing) HIP_TRY(hipEventRecord(ctx->events[ev].second, st));
     for (int f0 = 0; f0 < n_here; f0 += kMaxFinItems) {  // the reduce kernel takes its items by value, 48 per launch
       FinArgs fa;
       fa.n_items = std::min(kMaxFinItems, n_here - f0);
@@ -1637,7 +1637,6 @@ int dvo_amd_bench_residual_pass(dvo_amd_context *ctx, dvo_amd_pyramid *reference
   HIP_TRY(hipEventCreate(&e1));
   double total_ms = 0.0;
   for (int rep = -1; rep < reps; ++rep) {  // rep -1 warms up
-    HIP_TRY(hipEventRecord(e0, ctx->stream));
     for (int first = 0; first < n_items; first += per) {
       TickArgs ta;
       ta.n_items = std::min(per, n_items - first);
@@ -1646,14 +1645,13 @@ int dvo_amd_bench_residual_pass(dvo_amd_context *ctx, dvo_amd_pyramid *reference
         ta.items[i] = proto;
         ta.items[i].slot = ctx->slot_desc + (first + i);
       }
-      hipError_t e = launch_tick(ta, proto.res_blocks, ctx->stream);
+      hipError_t e = launch_tick(ta, proto.res_blocks, ctx->stream, e0, e1);  // stamped by the dispatch itself
       if (e != hipSuccess) return fail_hip("launch_tick", e);
+      HIP_TRY(hipEventSynchronize(e1));
+      float ms = 0.0f;
+      HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+      if (rep >= 0) total_ms += ms;
     }
-    HIP_TRY(hipEventRecord(e1, ctx->stream));
-    HIP_TRY(hipEventSynchronize(e1));
-    float ms = 0.0f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    if (rep >= 0) total_ms += ms;
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);

@@ -117,10 +117,14 @@ struct FinArgs {
 static_assert(sizeof(FinArgs) <= 3800, "kernel argument block too large");
 
 // ---- launch wrappers (dvo_kernels.hip) ----------------------------------------------------------------------------
-hipError_t launch_tick(const TickArgs &args, int max_blocks, hipStream_t stream);
+// t_start / t_stop (both or neither): events that receive the begin / end time stamps of this dispatch itself
+// (hipExtLaunchKernelGGL), i.e. the kernel's own duration without the launch latency an event pair around it would add
+hipError_t launch_tick(const TickArgs &args, int max_blocks, hipStream_t stream, hipEvent_t t_start = nullptr,
+                       hipEvent_t t_stop = nullptr);
 // the same kernel reading its items from a device-resident table (more pairs per launch than the argument block holds)
 constexpr int kMaxTableItems = 288;
-hipError_t launch_tick_table(const TickItem *items_dev, int n_items, int max_blocks, hipStream_t stream);
+hipError_t launch_tick_table(const TickItem *items_dev, int n_items, int max_blocks, hipStream_t stream,
+                             hipEvent_t t_start = nullptr, hipEvent_t t_stop = nullptr);
 hipError_t launch_finalize(const FinArgs &args, hipStream_t stream);
 hipError_t read_finalize_stamps(unsigned long long out[8]);
 
