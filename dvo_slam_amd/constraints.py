@@ -135,7 +135,14 @@ class ConstraintProposal:
 
     @staticmethod
     def createWithRelative(reference, current):
-        return ConstraintProposal(reference, current, np.linalg.inv(current.pose) @ reference.pose)
+        """InitialTransformation = current.pose^-1 * reference.pose (constraint_proposal.cpp:41-49), evaluated by the library
+        so that every binding starts from bit-identical transforms."""
+        ckf = (CKeyframe * 2)()
+        ckf[0].pose, ckf[1].pose = _colmajor(reference.pose), _colmajor(current.pose)
+        out = (CProposal * 2)()
+        cand = (C.c_int * 1)(1)
+        capi._check(_lib().dvo_amd_proposals_for_candidates(ckf, 0, 1, cand, out), "dvo_amd_proposals_for_candidates")
+        return ConstraintProposal(reference, current, np.array(out[1].initial_transformation[:]).reshape(4, 4).T)
 
     def TotalScore(self) -> float:
         return sum(v.Score for v in self.Votes) if self.Votes else 0.0

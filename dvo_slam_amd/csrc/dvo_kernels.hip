@@ -212,6 +212,7 @@ typedef float v4acc __attribute__((ext_vector_type(4)));
 
 // Timing-only ablation builds (scripts/ablate.sh: -DDVO_ABLATE=<mask>); never defined in the shipped library.
 // 1: no LDS staging / MFMA   2: no gather loads   4: no rank / pair-sum logic   8: no residual spill store
+// 16: no pixel steps at all (prologue + epilogue only)
 #ifndef DVO_ABLATE
 #define DVO_ABLATE 0
 #endif
@@ -473,12 +474,14 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
     run_count += __popcll(bk);
   };
   // the last pair of steps is peeled so that "is there a next step to prefetch" is a compile-time fact in every copy
-  for (int step = 0; step + 2 < steps; step += 2) {
-    do_step(step, 0, true);
-    do_step(step + 1, 1, true);
+  if (!(DVO_ABLATE & 16)) {  // (ablation 16: prologue + epilogue only)
+    for (int step = 0; step + 2 < steps; step += 2) {
+      do_step(step, 0, true);
+      do_step(step + 1, 1, true);
+    }
+    do_step(steps - 2, 0, true);
+    do_step(steps - 1, 1, false);
   }
-  do_step(steps - 2, 0, true);
-  do_step(steps - 1, 1, false);
 
   if (ACC == 1 && !(DVO_ABLATE & 1) && steps > 0) gram_from_stage(1);  // the last step (odd index) staged into buffer 1
 

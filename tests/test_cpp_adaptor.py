@@ -11,18 +11,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "examples", "_build", "adaptor_example")
 
 
-def _compile():
+VEXE = os.path.join(ROOT, "examples", "_build", "validator_example")
+
+
+def _compile(name="adaptor_example"):
     from dvo_slam_amd import _build
 
     _build.build()
-    os.makedirs(os.path.dirname(EXE), exist_ok=True)
+    exe = os.path.join(ROOT, "examples", "_build", name)
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
     libdir = os.path.join(ROOT, "dvo_slam_amd")
     cmd = ["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "examples", "adaptor_example.cpp"), "-o", EXE, "-L" + libdir, "-ldvo_amd",
+           os.path.join(ROOT, "examples", name + ".cpp"), "-o", exe, "-L" + libdir, "-ldvo_amd",
            "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
-    return EXE
+    return exe
 
 
 def test_adaptor_compiles_as_plain_cxx11():
@@ -31,6 +35,14 @@ def test_adaptor_compiles_as_plain_cxx11():
     # also with every warning a strict downstream build would enable, syntax only
     res = subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Wpedantic", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"),
                           os.path.join(ROOT, "examples", "adaptor_example.cpp")], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+
+
+def test_constraints_adaptor_compiles_as_plain_cxx11():
+    """include/dvo_amd/constraints.hpp: dvo_slam::constraints::ConstraintProposalValidator and friends."""
+    assert os.path.exists(_compile("validator_example"))
+    res = subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Wpedantic", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"),
+                          os.path.join(ROOT, "examples", "validator_example.cpp")], capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
 
 
@@ -59,3 +71,44 @@ def test_adaptor_matches_python_binding(tmp_path, synth):
     assert synth.pose_error(ref.Transformation, T) <= 1e-9  # same library, same inputs
     assert synth.pose_error(Tgt, T) < 2e-5
     assert sum(1 for ln in lines if ln.startswith("level ")) == 4
+
+
+@pytest.mark.gpu
+def test_constraints_adaptor_matches_python_binding(tmp_path, synth):
+    """A caller written like keyframe_graph.cpp (C++ adaptor) keeps the same constraints as the Python mirror."""
+    from dvo_slam_amd import capi, constraints as Cn
+
+    exe = VEXE if os.path.exists(VEXE) else _compile("validator_example")
+    w, h = 640, 480
+    K = synth.intrinsics_for(w, h)
+    key, cands = synth.loop_closure_scenario(w, h, 4)
+    entries = [key] + cands
+    with open(tmp_path / "frames.txt", "w") as fh:
+        for e in entries:
+            fh.write(str(e["id"]) + " " + " ".join(repr(float(v)) for v in np.asarray(e["pose"]).reshape(-1)) + "\n")
+            np.ascontiguousarray(e["frame"][0], dtype=np.float32).tofile(tmp_path / f"{e['id']}_i.f32")
+            np.ascontiguousarray(e["frame"][1], dtype=np.float32).tofile(tmp_path / f"{e['id']}_z.f32")
+    thresholds = dict(min_constraint_ratio=0.2, ratio_coarse=-1e300, ratio_fine=-1e300)
+    res = subprocess.run([exe, str(tmp_path), str(w), str(h)] + [repr(float(k)) for k in K] +
+                         [repr(thresholds["min_constraint_ratio"]), "-1e300", "-1e300"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    lines = res.stdout.strip().splitlines()
+    got = []
+    for ln in lines[1:]:
+        t = ln.split()
+        got.append((int(t[1]), int(t[2]), float(t[4]), int(t[6]), int(t[8]), np.array([float(v) for v in t[9:25]]).reshape(4, 4)))
+    # the same scenario through the Python mirror (evaluation seeded the same way: every frame against itself)
+    trk = capi.DenseTracker(capi.Config())
+
+    def mk(e):
+        p = capi.RgbdImagePyramid(e["frame"][0], e["frame"][1], K, 4)
+        return Cn.Keyframe(e["id"], p, e["pose"], Cn.LogLikelihoodTrackingResultEvaluation(trk.match(p, p)))
+
+    kfs = [mk(e) for e in entries]
+    want = Cn.createConstraintProposalValidator(**thresholds).validate(Cn.proposalsForCandidates(kfs[0], kfs[1:]))
+    assert int(lines[0].split()[1]) == len(want) == len(got) > 0
+    for g, p in zip(got, want):
+        assert (g[0], g[1]) == (p.Reference.id, p.Current.id)
+        assert g[3] == len(p.Votes) and g[4] == int(p.Accept())
+        assert abs(g[2] - p.TotalScore()) <= 1e-9 * max(1.0, abs(p.TotalScore()))
+        assert synth.pose_error(g[5], p.TrackingResult.Transformation) <= 1e-9  # same library, same inputs
