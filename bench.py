@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--distinct", type=int, default=8, help="distinct current frames cycled through the batch")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="multi-rank rehearsal on a one-GPU box: every rank uses GPU 0 and the ranks synchronise over gloo "
+                         "(exercises the N > 1 code path; the figure is meaningless)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the informational side measurements (STREAM copy, frame ingest, loop-closure validator, "
                          "all-core CPU baseline); rank 0 at N=1 only")
@@ -63,8 +66,12 @@ def main():
         import torch
         import torch.distributed as dist  # noqa: F811
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            local_rank = 0
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     from dvo_slam_amd import capi, synth
 
     if capi.lib().dvo_amd_device_count() < 1:
@@ -162,7 +169,8 @@ def main():
         k_ms, k_launches = trk.kernel_timing(False)
         alg_bytes_k = sum(o.alg_bytes for o in out)
     # MAX over ranks of the elapsed time, SUM over ranks of the pairs aligned
-    elapsed, pairs = sharding.aggregate(elapsed, B * args.steps, dist, "cuda" if dist is not None else None)
+    elapsed, pairs = sharding.aggregate(elapsed, B * args.steps, dist,
+                                        None if dist is None else ("cpu" if args.rehearse_on_one_gpu else "cuda"))
     value = pairs / elapsed
 
     if rank == 0:
