@@ -30,7 +30,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=576, help="frame pairs aligned per step per GPU")
+    ap.add_argument("--batch", type=int, default=1152, help="frame pairs aligned per step per GPU")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--distinct", type=int, default=8, help="distinct current frames cycled through the batch")
@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--prime", type=int, default=2,
                     help="untimed priming steps run as part of set-up before the W warm-up steps: the first calls grow "
                          "scratch buffers, streams and the HIP runtime's internal pools (a one-off ~40 ms stall)")
-    ap.add_argument("--in-flight", type=int, default=36,
+    ap.add_argument("--in-flight", type=int, default=72,
                     help="pairs resident per tracker at a time (0 = the whole share in lock step)")
     ap.add_argument("--threads", type=int, default=8,
                     help="host threads per GPU, each with its own tracker (HIP stream) and an equal share of the batch")
@@ -117,8 +117,9 @@ def main():
             r, c = [refs[i] for i in idx], [curb[i] for i in idx]
             for s in range(n_steps):
                 ts = time.perf_counter()
-                out = trackers[t].match_batch(r, c, stats=False, in_flight=args.in_flight)
-                collect.append((sum(o.alg_bytes for o in out), sum(o.n_residual_passes for o in out)))
+                out = trackers[t].match_batch(r, c, stats=False, in_flight=args.in_flight, raw=True)
+                collect.append((sum(o.alg_bytes for o in out), sum(o.n_residual_passes for o in out),
+                                sum(o.is_nan for o in out)))
                 if os.environ.get("DVO_BENCH_DEBUG"):
                     print(f"thread {t} step {s}: {(time.perf_counter() - ts) * 1e3:.2f} ms", file=sys.stderr, flush=True)
         if T == 1:
@@ -159,6 +160,8 @@ def main():
     elapsed = time.perf_counter() - t0
     alg_bytes = sum(c[0] for c in col)
     passes = sum(c[1] for c in col)
+    if sum(c[2] for c in col):
+        raise SystemExit("bench.py: a pair of the timed region came back NaN")
     if T == 1:
         k_ms, k_launches = trk.kernel_timing(False)
     else:

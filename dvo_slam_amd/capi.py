@@ -372,9 +372,10 @@ class DenseTracker:
         _check(lib().dvo_amd_match(self._h, reference._h, current._h, T0, C.byref(res[0])), "dvo_amd_match")
         return Result(res[0], its[0])
 
-    def match_batch(self, references, currents, T_inits=None, stats: bool = True, in_flight: int = 0):
+    def match_batch(self, references, currents, T_inits=None, stats: bool = True, in_flight: int = 0, raw: bool = False):
         """n independent match() calls on this tracker's GPU.  in_flight = 0: all advanced in lock step; otherwise at most
-        in_flight pairs are resident and a finished pair hands its slot to the next one."""
+        in_flight pairs are resident and a finished pair hands its slot to the next one.  raw=True returns the array of C
+        result structs as the library filled them (no per-pair Python objects: for throughput loops)."""
         n = len(references)
         assert len(currents) == n
         if stats:
@@ -388,6 +389,9 @@ class DenseTracker:
             T0a = np.ascontiguousarray(np.stack([np.asarray(T, dtype=np.float64).T for T in T_inits]))
             T0 = T0a.ctypes.data_as(C.POINTER(C.c_double))
         _check(lib().dvo_amd_match_many(self._h, n, refs, curs, T0, res, in_flight), "dvo_amd_match_many")
+        if raw:
+            res._keepalive = its  # the iteration arrays the structs point into
+            return res
         if not stats:
             return [Result(res[i], None) for i in range(n)]
         return [Result(res[i], its[i]) for i in range(n)]

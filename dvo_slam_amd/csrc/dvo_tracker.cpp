@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -45,6 +46,8 @@ int fail_hip(const char *what, hipError_t e) {
   } while (0)
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+constexpr int kMaxTickStreams = 8;  // streams a context spreads the launches / pair groups of its ticks over
 
 // ---- per-device shared state: a prep stream and a pool of pyramid slabs ------------------------------------------
 struct DeviceState {
@@ -381,6 +384,10 @@ struct dvo_amd_context {
   // area and its device copy (uploaded in-stream in front of the launch)
   TickItem *item_host = nullptr, *item_dev = nullptr;  // [kMaxTickStreams][kMaxTableItems]
   int items_per_launch = kMaxItemsPerLaunch;           // DVO_AMD_ITEMS_PER_LAUNCH (<= kMaxTableItems)
+  // DVO_AMD_HOST_PROF=1: where the host thread spends its time (printed when the context is destroyed)
+  bool host_prof = false;
+  double prof_submit_ns = 0.0, prof_wait_ns = 0.0, prof_process_ns = 0.0;
+  long long prof_ticks = 0, prof_job_ticks = 0;
   // tile-shard exchange (RCCL, loaded with dlopen so that single-GPU users do not depend on it)
   void *rccl_lib = nullptr;
   ncclComm_t comm = nullptr;
@@ -691,8 +698,8 @@ int ensure_slots(dvo_amd_context *ctx, int n_jobs, int n_pad) {
   ctx->slot_desc = nullptr;
   HIP_TRY(hipMalloc((void **)&ctx->slot_desc, sizeof(SlotDesc) * n_slots));
   if (!ctx->tickets) {
-    HIP_TRY(hipMalloc((void **)&ctx->tickets, sizeof(unsigned) * 64));
-    HIP_TRY(hipMemset(ctx->tickets, 0, sizeof(unsigned) * 64));
+    HIP_TRY(hipMalloc((void **)&ctx->tickets, sizeof(unsigned) * 16 * kMaxTickStreams));
+    HIP_TRY(hipMemset(ctx->tickets, 0, sizeof(unsigned) * 16 * kMaxTickStreams));
   }
   std::vector<SlotDesc> slot_host((size_t)n_slots);
   const int max_blocks = new_pad / (kSegPxPerRound * kWavesPerBlock);
@@ -749,7 +756,6 @@ int timing_begin(dvo_amd_context *ctx, size_t *slot) {
   return DVO_AMD_OK;
 }
 
-constexpr int kMaxTickStreams = 4;
 
 int tick_stream(dvo_amd_context *ctx, size_t index, hipStream_t *out) {
   index %= kMaxTickStreams;
@@ -783,13 +789,14 @@ int timing_collect(dvo_amd_context *ctx) {
 }
 
 // wait until the finalize kernel has published this tick's record of every submitted job
-int wait_tick(dvo_amd_context *ctx, const std::vector<Job> &jobs, unsigned seq) {
+int wait_tick(dvo_amd_context *ctx, const std::vector<Job> &jobs, size_t lo, size_t hi, unsigned seq) {
   if (!ctx->poll || ctx->timing) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     for (hipStream_t s : ctx->extra_streams) HIP_TRY(hipStreamSynchronize(s));
     return DVO_AMD_OK;
   }
-  for (const Job &j : jobs) {
+  for (size_t ji = lo; ji < hi; ++ji) {
+    const Job &j = jobs[ji];
     if (j.done || !(j.sub_ll || j.sub_res)) continue;
     const volatile unsigned *p = &ctx->out_host[j.slot - ctx->slots.data()].seq;
     unsigned long long spins = 0;
@@ -812,19 +819,35 @@ int wait_tick(dvo_amd_context *ctx, const std::vector<Job> &jobs, unsigned seq) 
   return DVO_AMD_OK;
 }
 
-// submit what every unfinished job needs, wait, advance the jobs
-int run_tick(dvo_amd_context *ctx, std::vector<Job> &jobs) {
+// One tick of a group of resident pairs (slots [lo, hi) of a context): submit_tick enqueues what every unfinished pair of
+// the group needs, complete_tick waits for the records and advances the pairs.  Groups of one context tick independently
+// on their own streams, so the host work of one group overlaps the kernels of the others.
+struct GroupTick {
+  size_t lo = 0, hi = 0;
+  size_t stream_first = 0;  // tick stream of the group's first launch
+  unsigned seq = 0;
+  bool in_flight = false;
+};
+
+inline double now_ns() {
+  return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
+  const double t_begin = ctx->host_prof ? now_ns() : 0.0;
+  grp.in_flight = false;
   long long total_px = 0;
-  for (Job &j : jobs)
-    if (!j.done && j.have_b) total_px += j.ref->lv[j.level].n;
+  for (size_t ji = grp.lo; ji < grp.hi; ++ji)
+    if (!jobs[ji].done && jobs[ji].have_b) total_px += jobs[ji].ref->lv[jobs[ji].level].n;
   const int rounds_now = pick_rounds(total_px);
   const unsigned seq = ++ctx->tick_seq;
+  grp.seq = seq;
 
   std::vector<TickItem> items;
   std::vector<FinItem> fin_items;
-  items.reserve(jobs.size());
-  fin_items.reserve(jobs.size());
-  for (size_t ji = 0; ji < jobs.size(); ++ji) {
+  items.reserve(grp.hi - grp.lo);
+  fin_items.reserve(grp.hi - grp.lo);
+  for (size_t ji = grp.lo; ji < grp.hi; ++ji) {
     Job &j = jobs[ji];
     if (j.done) continue;
     j.sub_ll = j.sub_res = false;
@@ -885,13 +908,13 @@ int run_tick(dvo_amd_context *ctx, std::vector<Job> &jobs) {
   for (size_t first = 0; first < items.size(); first += per, ++launch_index) {
     hipStream_t st;
     {
-      int rc = tick_stream(ctx, ctx->timing ? 0 : launch_index, &st);  // timed launches run alone, on stream 0
+      int rc = tick_stream(ctx, ctx->timing ? 0 : grp.stream_first + launch_index, &st);  // timed launches run alone, on stream 0
       if (rc) return rc;
     }
     TickArgs ta;
     const int n_here = (int)std::min(per, items.size() - first);
     const bool use_table = n_here > kMaxItemsPerLaunch;
-    const size_t stream_slot = (ctx->timing ? 0 : launch_index) % kMaxTickStreams;
+    const size_t stream_slot = ctx->timing ? 0 : (grp.stream_first + launch_index) % kMaxTickStreams;
     ta.n_items = use_table ? 0 : n_here;
     ta.pad = 0;
     int max_blocks = 0;
@@ -910,7 +933,7 @@ int run_tick(dvo_amd_context *ctx, std::vector<Job> &jobs) {
       if (rc) return rc;
       double rb = 0, lb = 0, px = 0;
       for (int i = 0; i < n_here; ++i) rb += stage[i].res_blocks, lb += stage[i].ll_blocks;
-      for (size_t ji = 0, k = 0; ji < jobs.size(); ++ji) {
+      for (size_t ji = grp.lo, k = 0; ji < grp.hi; ++ji) {
         const Job &j = jobs[ji];
         if (j.done || !(j.sub_ll || j.sub_res)) continue;
         if (k >= first && k < first + (size_t)n_here && j.sub_res) px += (double)j.ref->selections[j.sel].count[j.level];
@@ -933,16 +956,26 @@ int run_tick(dvo_amd_context *ctx, std::vector<Job> &jobs) {
       if (e != hipSuccess) return fail_hip("launch_finalize", e);
     }
   }
+  grp.in_flight = true;
+  if (ctx->host_prof) ctx->prof_submit_ns += now_ns() - t_begin, ctx->prof_ticks++, ctx->prof_job_ticks += (long long)items.size();
+  return DVO_AMD_OK;
+}
+
+int complete_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
+  if (!grp.in_flight) return DVO_AMD_OK;
+  grp.in_flight = false;
+  const double t_begin = ctx->host_prof ? now_ns() : 0.0;
   {
-    int rc = wait_tick(ctx, jobs, seq);
+    int rc = wait_tick(ctx, jobs, grp.lo, grp.hi, grp.seq);
     if (rc) return rc;
   }
+  const double t_waited = ctx->host_prof ? now_ns() : 0.0;
   if (ctx->timing) {
     int rc = timing_collect(ctx);
     if (rc) return rc;
   }
 
-  for (size_t ji = 0; ji < jobs.size(); ++ji) {
+  for (size_t ji = grp.lo; ji < grp.hi; ++ji) {
     Job &j = jobs[ji];
     if (j.done || !(j.sub_ll || j.sub_res)) continue;
     const FinOut *o = ctx->out_host + (j.slot - ctx->slots.data());
@@ -953,6 +986,7 @@ int run_tick(dvo_amd_context *ctx, std::vector<Job> &jobs) {
       process_residual(j, b, *o);
     }
   }
+  if (ctx->host_prof) ctx->prof_wait_ns += t_waited - t_begin, ctx->prof_process_ns += now_ns() - t_waited;
   return DVO_AMD_OK;
 }
 
@@ -1212,6 +1246,8 @@ int dvo_amd_context_create(int device, const dvo_amd_config *cfg, dvo_amd_contex
   ctx->poll = !(pe && pe[0] == '0');
   const char *fs = getenv("DVO_AMD_FIN_STAMPS");
   ctx->fin_stamps = fs && fs[0] == '1';
+  const char *hp = getenv("DVO_AMD_HOST_PROF");
+  ctx->host_prof = hp && hp[0] == '1';
   if (const char *ipl = getenv("DVO_AMD_ITEMS_PER_LAUNCH")) {
     const int v = atoi(ipl);
     if (v >= 1 && v <= kMaxTableItems) ctx->items_per_launch = v;
@@ -1222,6 +1258,12 @@ int dvo_amd_context_create(int device, const dvo_amd_config *cfg, dvo_amd_contex
 
 void dvo_amd_context_destroy(dvo_amd_context *ctx) {
   if (!ctx) return;
+  if (ctx->host_prof && ctx->prof_ticks > 0)
+    std::fprintf(stderr, "[dvo_amd host profile] ticks %lld, pair-ticks %lld: submit %.2f us/tick, wait %.2f us/tick, process %.2f us/tick "
+                         "(%.2f us per pair-tick of host work)\n",
+                 ctx->prof_ticks, ctx->prof_job_ticks, ctx->prof_submit_ns / ctx->prof_ticks * 1e-3,
+                 ctx->prof_wait_ns / ctx->prof_ticks * 1e-3, ctx->prof_process_ns / ctx->prof_ticks * 1e-3,
+                 (ctx->prof_submit_ns + ctx->prof_process_ns) / std::max(1LL, ctx->prof_job_ticks) * 1e-3);
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   dvo_amd_comm_destroy(ctx);
@@ -1390,16 +1432,38 @@ int dvo_amd_match_many(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *refe
   std::vector<Job> jobs((size_t)in_flight);
   std::vector<int> job_of_slot((size_t)in_flight, -1);
   for (Job &j : jobs) j.done = true;
+  // More resident pairs than one launch takes are split into groups that tick independently, each on its own stream, in
+  // round-robin: while the host advances the pairs of one group the kernels of the other groups keep the GPU busy.
+  // (Kernel timing wants every launch alone on the GPU: one group then.)
+  const int cap = std::min(std::max(ctx->items_per_launch, 1), kMaxTableItems);
+  const int n_groups = ctx->timing ? 1 : std::min(kMaxTickStreams, (in_flight + cap - 1) / cap);
+  const int per_group = (in_flight + n_groups - 1) / n_groups;
+  std::vector<GroupTick> groups((size_t)n_groups);
+  for (int g = 0; g < n_groups; ++g) {
+    groups[(size_t)g].lo = (size_t)std::min(g * per_group, in_flight);
+    groups[(size_t)g].hi = (size_t)std::min((g + 1) * per_group, in_flight);
+    groups[(size_t)g].stream_first = (size_t)g;
+  }
   int next = 0, finished = 0;
+  int g = 0;
   while (finished < n) {
-    for (int sidx = 0; sidx < in_flight && next < n; ++sidx) {
-      Job &j = jobs[(size_t)sidx];
+    GroupTick &grp = groups[(size_t)g];
+    g = (g + 1) % n_groups;
+    rc = complete_tick(ctx, jobs, grp);
+    if (rc) return rc;
+    for (size_t sidx = grp.lo; sidx < grp.hi; ++sidx)
+      if (jobs[sidx].done && job_of_slot[sidx] >= 0) {
+        job_of_slot[sidx] = -1;
+        ++finished;
+      }
+    for (size_t sidx = grp.lo; sidx < grp.hi && next < n; ++sidx) {
+      Job &j = jobs[sidx];
       if (!j.done) continue;
       const int i = next++;
       j = Job();
       j.ref = references[i], j.cur = currents[i];
       j.result = &results[i];
-      j.slot = &ctx->slots[(size_t)sidx];
+      j.slot = &ctx->slots[sidx];
       j.cfg = &ctx->cfg;
       rc = pyramid_selection(j.ref, cfg.intensity_derivative_threshold, cfg.depth_derivative_threshold, &j.sel);
       if (rc) return rc;
@@ -1412,16 +1476,11 @@ int dvo_amd_match_many(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *refe
       j.estimate = SE3::identity();
       j.level = cfg.first_level;
       j.done = false;
-      job_of_slot[(size_t)sidx] = i;
+      job_of_slot[sidx] = i;
       start_level(j);
     }
-    rc = run_tick(ctx, jobs);
+    rc = submit_tick(ctx, jobs, grp);
     if (rc) return rc;
-    for (int sidx = 0; sidx < in_flight; ++sidx)
-      if (jobs[(size_t)sidx].done && job_of_slot[(size_t)sidx] >= 0) {
-        job_of_slot[(size_t)sidx] = -1;
-        ++finished;
-      }
   }
   return DVO_AMD_OK;
 }
