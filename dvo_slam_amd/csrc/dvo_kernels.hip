@@ -233,8 +233,9 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
   const int wave = threadIdx.x >> 6;
   const int seg = lb * kWavesPerBlock + wave;
   const int w = d.w;
-  const int steps = it.res_rounds * kPxPerLane;  // a segment is res_rounds * 256 pixels = steps * 64
-  unsigned idx = (unsigned)(seg * (kSegPxPerRound * it.res_rounds) + lane);
+  const int res_rounds = item_res_rounds(it);
+  const int steps = res_rounds * kPxPerLane;  // a segment is res_rounds * 256 pixels = steps * 64
+  unsigned idx = (unsigned)(seg * (kSegPxPerRound * res_rounds) + lane);
   unsigned prow = idx / (unsigned)w;
   unsigned pcol = idx - prow * (unsigned)w;
 
@@ -597,8 +598,9 @@ __device__ void loglik_pass(const TickItem &it, const LevelPairDesc &d, const in
   const unsigned long long below = (1ull << lane) - 1ull;
   double total = 0.0;
   if (seg_before < cut_rank) {
-    const int steps = it.ll_rounds * kPxPerLane;
-    const DVO_GLOBAL v2f *src = (const DVO_GLOBAL v2f *)((it.flags & kItemLlBuf) ? d.res[1] : d.res[0]) + seg * (kSegPxPerRound * it.ll_rounds) + lane;
+    const int ll_rounds = item_ll_rounds(it);
+    const int steps = ll_rounds * kPxPerLane;
+    const DVO_GLOBAL v2f *src = (const DVO_GLOBAL v2f *)((it.flags & kItemLlBuf) ? d.res[1] : d.res[0]) + seg * (kSegPxPerRound * ll_rounds) + lane;
     int run_count = seg_before;
     // four steps (256 pixels) per trip: one log of a product of up to four terms per lane
     for (int step = 0; step < steps; step += 4) {
@@ -656,12 +658,19 @@ __device__ __forceinline__ LevelPairDesc load_desc(const TickItem &it) {
 template <int RMODE, int ACC>
 __device__ __forceinline__ void tick_body(const TickItem &it) {
   const int bx = (int)blockIdx.x;
-  if (bx >= it.res_blocks + it.ll_blocks) return;
+  const int rp = it.res_phys;
+  if (bx >= rp + it.ll_blocks) return;
   const LevelPairDesc d = load_desc(it);
-  if (bx < it.res_blocks)
-    residual_pass<RMODE, ACC>(it, d, it.res_first + xcd_contiguous_block(bx, it.res_blocks));
-  else
-    loglik_pass(it, d, it.ll_first + (bx - it.res_blocks));
+  if (bx < rp) {
+    // a physical block walks several logical blocks when the launch holds many more blocks than the GPU has slots: the
+    // item and its descriptors are fetched once, and only the first logical block pays the dependent-load prologue
+    for (int lb = bx; lb < it.res_blocks; lb += rp) {
+      residual_pass<RMODE, ACC>(it, d, it.res_first + xcd_contiguous_block(lb, it.res_blocks));
+      __syncthreads();  // the reduction scratch in LDS is reused by the next logical block
+    }
+  } else {
+    loglik_pass(it, d, it.ll_first + (bx - rp));
+  }
 }
 
 template <int RMODE, int ACC, int OCC>
@@ -677,7 +686,7 @@ __global__ __launch_bounds__(kBlockThreads, OCC) void k_tick_table(const TickIte
   TickItem it;
   it.ref = p->ref, it.cur = p->cur, it.slot = p->slot;
   it.res_blocks = p->res_blocks, it.ll_blocks = p->ll_blocks, it.res_first = p->res_first, it.ll_first = p->ll_first;
-  it.res_rounds = p->res_rounds, it.ll_rounds = p->ll_rounds, it.flags = p->flags, it.pad = 0;
+  it.rounds_log2 = p->rounds_log2, it.flags = p->flags, it.res_phys = p->res_phys;
   it.ll_cut_rank = p->ll_cut_rank;
 #pragma unroll
   for (int i = 0; i < 12; ++i) it.kt[i] = p->kt[i];

@@ -384,6 +384,8 @@ struct dvo_amd_context {
   // area and its device copy (uploaded in-stream in front of the launch)
   TickItem *item_host = nullptr, *item_dev = nullptr;  // [kMaxTickStreams][kMaxTableItems]
   int items_per_launch = kMaxItemsPerLaunch;           // DVO_AMD_ITEMS_PER_LAUNCH (<= kMaxTableItems)
+  int phys_block_target = 1 << 30;                     // DVO_AMD_PHYS_BLOCKS=n: fold a launch's residual-pass blocks down to ~n
+                                                       // physical blocks that walk several logical ones (measured: slower, off)
   // DVO_AMD_HOST_PROF=1: where the host thread spends its time (printed when the context is destroyed)
   bool host_prof = false;
   double prof_submit_ns = 0.0, prof_wait_ns = 0.0, prof_process_ns = 0.0;
@@ -855,6 +857,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
     const size_t slot_index = (size_t)(j.slot - ctx->slots.data());
     TickItem w;
     std::memset(&w, 0, sizeof(w));
+    int res_rounds = 1, ll_rounds = 1;
     w.ref = j.ref->selections[j.sel].ref_desc + j.level;
     w.cur = j.cur->cur_desc + j.level;
     w.slot = ctx->slot_desc + slot_index;
@@ -864,7 +867,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
     f.seg_prefix_out = j.slot->seg_prefix[0], f.out = j.slot->out, f.out_dev = nullptr, f.seq = seq, f.pad = 0;
     if (j.have_a) {
       w.ll_blocks = (uint16_t)j.a.n_blocks;
-      w.ll_rounds = (uint8_t)j.a.rounds;
+      ll_rounds = j.a.rounds;
       if (j.a.buf) w.flags |= kItemLlBuf;
       w.ll_cut_rank = j.a.cut_rank;
       f.n_ll_blocks = w.ll_blocks;
@@ -875,7 +878,8 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
       while (j.b.rounds < kMaxRounds && blocks_for(j.ref->lv[j.level].n, j.b.rounds) > 2048) j.b.rounds *= 2;
       j.b.n_blocks = blocks_for(j.ref->lv[j.level].n, j.b.rounds);
       w.res_blocks = (uint16_t)j.b.n_blocks;
-      w.res_rounds = (uint8_t)j.b.rounds;
+      w.res_phys = w.res_blocks;
+      res_rounds = j.b.rounds;
       if (j.b.buf) w.flags |= kItemResBuf;
       if (j.b.k == 0) w.flags |= kItemUnitWeights;  // dense_tracking.cpp:286-293
       make_kt(j.cur->lv[j.level], j.b.estimate_after, w.kt);
@@ -889,6 +893,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
     // the likelihood of iteration k and the weights of iteration k+1 both use the precision of iteration k (a's); without a
     // pending likelihood the weights use the job's current precision (unused at the first iteration of a level)
     std::memcpy(w.P, j.have_a ? j.a.P : j.precision, sizeof(w.P));
+    item_set_rounds(w, res_rounds, ll_rounds);
     items.push_back(w);
     fin_items.push_back(f);
     j.result->n_ticks++;
@@ -919,9 +924,17 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
     ta.pad = 0;
     int max_blocks = 0;
     TickItem *stage = use_table ? ctx->item_host + stream_slot * kMaxTableItems : ta.items;
+    // Optionally (DVO_AMD_PHYS_BLOCKS) a physical block walks several logical ones, so that only the first pays the
+    // dependent-load prologue.  Measured on MI355X: the coarser scheduling loses more than the prologue costs (36 level-0
+    // pairs: 129 us with one block per logical block, 141 us folded 2x, 157 us folded 5x), so the default is no folding.
+    long long total_res_blocks = 0;
+    for (int i = 0; i < n_here; ++i) total_res_blocks += items[first + i].res_blocks;
+    const int walk = (int)std::min<long long>(8, std::max<long long>(1, total_res_blocks / ctx->phys_block_target));
     for (int i = 0; i < n_here; ++i) {
       stage[i] = items[first + i];
-      max_blocks = std::max(max_blocks, (int)stage[i].res_blocks + (int)stage[i].ll_blocks);
+      // (a multiple of 8, so that a physical block's logical blocks keep its XCD in the XCD-contiguous block mapping)
+      stage[i].res_phys = (uint16_t)std::min<int>(stage[i].res_blocks, ((stage[i].res_blocks + walk - 1) / walk + 7) & ~7);
+      max_blocks = std::max(max_blocks, (int)stage[i].res_phys + (int)stage[i].ll_blocks);
     }
     if (use_table && launch_index >= kMaxTickStreams) HIP_TRY(hipStreamSynchronize(st));  // staging of this stream is still in use
     if (use_table)  // otherwise the staging area is free: the tick that used it has been waited for
@@ -1075,7 +1088,6 @@ int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, i
       int first = 0, count = 0;
       band_range(j.a.n_blocks, n_bands, band, &first, &count);
       w.ll_first = (uint16_t)first, w.ll_blocks = (uint16_t)count;
-      w.ll_rounds = 1;
       if (j.a.buf) w.flags |= kItemLlBuf;
       int before = 0;
       for (int b = 0; b < band; ++b) before += j.a.band_valid[b];
@@ -1086,7 +1098,7 @@ int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, i
       int first = 0, count = 0;
       band_range(nb_level, n_bands, band, &first, &count);
       w.res_first = (uint16_t)first, w.res_blocks = (uint16_t)count;
-      w.res_rounds = 1;
+      w.res_phys = w.res_blocks;
       if (j.b.buf) w.flags |= kItemResBuf;
       if (j.b.k == 0) w.flags |= kItemUnitWeights;
       make_kt(j.cur->lv[j.level], j.b.estimate_after, w.kt);
@@ -1248,6 +1260,10 @@ int dvo_amd_context_create(int device, const dvo_amd_config *cfg, dvo_amd_contex
   ctx->fin_stamps = fs && fs[0] == '1';
   const char *hp = getenv("DVO_AMD_HOST_PROF");
   ctx->host_prof = hp && hp[0] == '1';
+  if (const char *pb = getenv("DVO_AMD_PHYS_BLOCKS")) {
+    const int v = atoi(pb);
+    if (v >= 64) ctx->phys_block_target = v;
+  }
   if (const char *ipl = getenv("DVO_AMD_ITEMS_PER_LAUNCH")) {
     const int v = atoi(ipl);
     if (v >= 1 && v <= kMaxTableItems) ctx->items_per_launch = v;
@@ -1609,9 +1625,11 @@ int dvo_amd_residuals(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_
   w.ref = reference->selections[sel].ref_desc + level;
   w.cur = current->cur_desc + level;
   w.slot = ctx->slot_desc;
-  w.res_rounds = 1;
-  while (w.res_rounds < kMaxRounds && blocks_for(R.n, w.res_rounds) > 2048) w.res_rounds *= 2;
-  w.res_blocks = (uint16_t)blocks_for(R.n, w.res_rounds);
+  int res_rounds = 1;
+  while (res_rounds < kMaxRounds && blocks_for(R.n, res_rounds) > 2048) res_rounds *= 2;
+  item_set_rounds(w, res_rounds, 1);
+  w.res_blocks = (uint16_t)blocks_for(R.n, res_rounds);
+  w.res_phys = w.res_blocks;
   w.flags = kItemUnitWeights;
   const float K[9] = {C.fx, 0.0f, C.ox, 0.0f, C.fy, C.oy, 0.0f, 0.0f, 1.0f};
   for (int i = 0; i < 3; ++i)
@@ -1681,8 +1699,13 @@ int dvo_amd_bench_residual_pass(dvo_amd_context *ctx, dvo_amd_pyramid *reference
   std::memset(&proto, 0, sizeof(proto));
   proto.ref = reference->selections[sel].ref_desc + level;
   proto.cur = current->cur_desc + level;
-  proto.res_rounds = rounds;
+  item_set_rounds(proto, rounds, 1);
   proto.res_blocks = (uint16_t)blocks_for(R.n, rounds);
+  {
+    const long long total = (long long)proto.res_blocks * std::min(n_items, kMaxItemsPerLaunch);
+    const int walk = (int)std::min<long long>(8, std::max<long long>(1, total / ctx->phys_block_target));
+    proto.res_phys = (uint16_t)std::min<int>(proto.res_blocks, ((proto.res_blocks + walk - 1) / walk + 7) & ~7);
+  }
   proto.flags = 0;
   proto.P[0] = 1500.0f, proto.P[3] = 7000.0f;  // a typical precision: the weights take the non-trivial branch
   const float K[9] = {C.fx, 0.0f, C.ox, 0.0f, C.fy, C.oy, 0.0f, 0.0f, 1.0f};
@@ -1704,7 +1727,7 @@ int dvo_amd_bench_residual_pass(dvo_amd_context *ctx, dvo_amd_pyramid *reference
         ta.items[i] = proto;
         ta.items[i].slot = ctx->slot_desc + (first + i);
       }
-      hipError_t e = launch_tick(ta, proto.res_blocks, ctx->stream, e0, e1);  // stamped by the dispatch itself
+      hipError_t e = launch_tick(ta, proto.res_phys, ctx->stream, e0, e1);  // stamped by the dispatch itself
       if (e != hipSuccess) return fail_hip("launch_tick", e);
       HIP_TRY(hipEventSynchronize(e1));
       float ms = 0.0f;

@@ -61,14 +61,22 @@ struct TickItem {
   const SlotDesc *slot;
   uint16_t res_blocks, ll_blocks;  // blocks this item runs (a band of the level when the pair is sharded), <= 2048 each
   uint16_t res_first, ll_first;    // first logical block of the band (0 for the whole level)
-  uint8_t res_rounds, ll_rounds;   // rounds per wave
+  uint8_t rounds_log2;             // rounds per wave, log2: low nibble residual pass, high nibble log-likelihood pass
   uint8_t flags;                   // kItem* bits
-  uint8_t pad;
+  uint16_t res_phys;               // physical blocks of the residual pass: block b walks logical blocks b, b + res_phys, ...
   int ll_cut_rank;                 // log-likelihood pass: keep valid pixels whose rank within the band is below this (Q6)
   float kt[12];                    // K * T[0:3,0:4], row-major, float (dense_tracking_impl.cpp:142-152)
   float P[4];                      // column-major 2x2 precision: of the iteration whose likelihood is evaluated, which is
                                    // also the one the residual pass of the next iteration takes its weights from
 };
+__host__ __device__ inline int item_res_rounds(const TickItem &it) { return 1 << (it.rounds_log2 & 15); }
+__host__ __device__ inline int item_ll_rounds(const TickItem &it) { return 1 << (it.rounds_log2 >> 4); }
+inline void item_set_rounds(TickItem &it, int res_rounds, int ll_rounds) {
+  int a = 0, b = 0;
+  while ((1 << a) < res_rounds) ++a;
+  while ((1 << b) < ll_rounds) ++b;
+  it.rounds_log2 = (uint8_t)(a | (b << 4));
+}
 constexpr unsigned kItemResBuf = 1;       // which residual buffer the residual pass writes
 constexpr unsigned kItemLlBuf = 2;        // which residual buffer the log-likelihood pass reads
 constexpr unsigned kItemUnitWeights = 4;  // first iteration on a level: weights = 1 (dense_tracking.cpp:286-289)
