@@ -312,9 +312,20 @@ def test_deterministic_and_batch_equals_single(capi, synth, pair640):
     for o, s in zip(rolling, singles):
         assert synth.pose_error(s.Transformation, o.Transformation) <= POSE_TOL
         assert [len(L["Iterations"]) for L in o.Levels] == [len(L["Iterations"]) for L in s.Levels]
-    big = trk.match_batch([pair640["gr"]] * 40, [pair640["gc"]] * 40, stats=False)  # > one launch worth of items
+    big = trk.match_batch([pair640["gr"]] * 40, [pair640["gc"]] * 40, stats=False)  # > one launch worth of items: 2 groups
     assert all(np.array_equal(big[0].Transformation, o.Transformation) for o in big)
     assert synth.pose_error(a.Transformation, big[0].Transformation) <= POSE_TOL
+    # 90 resident pairs = three groups ticking independently on their own streams, 130 pairs rolling through them; raw
+    # result structs; mixed pairs so that the groups finish levels at different times
+    n = 130
+    refs = [pair640["gr"] if i % 3 else pair640["gc"] for i in range(n)]
+    curs = [pair640["gc"] if i % 3 else pair640["gr"] for i in range(n)]
+    raw = trk.match_batch(refs, curs, stats=False, in_flight=90, raw=True)
+    fwd, bwd = singles[0], singles[1]
+    for i in range(n):
+        T = np.array(raw[i].transformation[:]).reshape(4, 4).T
+        assert synth.pose_error((fwd if i % 3 else bwd).Transformation, T) <= POSE_TOL
+        assert raw[i].is_nan == 0 and raw[i].n_levels == 4
 
 
 def test_pyramid_from_device_memory(capi, synth, pair640):
