@@ -378,7 +378,7 @@ def validator_timing(capi, synth, W, H, device):
 
     kkey, kc = mk(key), [mk(c) for c in cands]
     val = Cn.createConstraintProposalValidator(min_constraint_ratio=0.2, ratio_coarse=-1e300, ratio_fine=-1e300,
-                                               device=device, max_in_flight=36)
+                                               device=device, max_in_flight=72)
     val.validate(Cn.proposalsForCandidates(kkey, kc))
     reps = 5
     t0 = time.perf_counter()
