@@ -426,16 +426,19 @@ static void tdist_weights(const float *res, int n, const float *P, int rcp_mode,
 }
 
 /* computeScaleSse, dense_tracking_impl.cpp:590-638, including Q5 (first residual of a pair used twice) */
-static void tdist_scale(const float *res, int n, const float *w, float cov[4]) {
+static void tdist_scale(const float *res, int n, const float *w, float cov[4], int clean) {
   const int n2 = n - (n % 2);
   const float scale = 1.0f / (float)(size_t)(n - 2 - 1);
   float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   for (int i = 0; i < n2; i += 2) {
     const float x = res[2 * i], y = res[2 * i + 1];
     const float f[4] = {x * x, y * x, x * y, y * y}; /* fac1*fac2, :608-612 */
+    /* ORC_CLEAN: the second residual of the pair contributes its own outer product (what the code was meant to do) */
+    const float x2 = clean ? res[2 * i + 2] : x, y2 = clean ? res[2 * i + 3] : y;
+    const float g[4] = {x2 * x2, y2 * x2, x2 * y2, y2 * y2};
     for (int k = 0; k < 4; ++k) {
       const float p1 = scale * (w[i] * f[k]);
-      const float p2 = scale * (w[i + 1] * f[k]);
+      const float p2 = scale * (w[i + 1] * g[k]);
       acc[k] = acc[k] + (p1 + p2);
     }
   }
@@ -464,7 +467,7 @@ static void inverse2f(const float m[4], float r[4]) {
 }
 
 /* computeCompleteDataLogLikelihood, dense_tracking_impl.cpp:406-425, including Q6 (tail of n % 50 dropped) */
-static float tdist_loglik(const float *res, int n, const float *P) {
+static float tdist_loglik(const float *res, int n, const float *P, int clean) {
   size_t c = 1;
   double error_sum = 0.0, error_acc = 1.0;
   for (int i = 0; i < n; ++i, ++c) {
@@ -474,6 +477,7 @@ static float tdist_loglik(const float *res, int n, const float *P) {
       error_acc = 1.0;
     }
   }
+  if (clean) error_sum += log(error_acc); /* ORC_CLEAN: the last n % 50 residuals count too */
   const float det = P[0] * P[3] - P[1] * P[2];
   return (float)(0.5 * (size_t)n * logf(det) - 0.5 * (5.0 + 2.0) * error_sum);
 }
@@ -486,11 +490,12 @@ float orc_weights_scale_loglik(const float *residuals, int n, const float *prec_
   else
     tdist_weights(residuals, n, prec_in, rcp_mode, w);
   float cov[4], P[4];
-  tdist_scale(residuals, n, w, cov);
+  const int clean = rcp_mode == ORC_RCP_CLEAN;
+  tdist_scale(residuals, n, w, cov, clean);
   inverse2f(cov, P);
   if (scale_out) memcpy(scale_out, cov, sizeof(cov));
   if (prec_out) memcpy(prec_out, P, sizeof(P));
-  const float ll = tdist_loglik(residuals, n, P);
+  const float ll = tdist_loglik(residuals, n, P, clean);
   if (!weights_out) free(w);
   return ll;
 }
@@ -982,9 +987,9 @@ int orc_match(const orc_config *cfg, orc_pyramid *ref, orc_pyramid *cur, const d
         tdist_weights(residuals, n, precision, cfg->rcp_mode, weights);
 
       float cov[4];
-      tdist_scale(residuals, n, weights, cov);
+      tdist_scale(residuals, n, weights, cov, cfg->rcp_mode == ORC_RCP_CLEAN);
       inverse2f(cov, precision); /* :295 */
-      const float ll = tdist_loglik(residuals, n, precision);
+      const float ll = tdist_loglik(residuals, n, precision, cfg->rcp_mode == ORC_RCP_CLEAN);
 
       double xi_initial[6];
       se3_log(&initial, xi_initial);

@@ -27,7 +27,10 @@ extern "C" {
 /* how the projection / weight reciprocal is formed */
 enum {
   ORC_RCP_SSE = 0,  /* _mm_rcp_ps, as the reference (dense_tracking_impl.cpp:192,700): host specific */
-  ORC_RCP_EXACT = 1 /* IEEE division in the same rounding mode: portable, what the HIP path does   */
+  ORC_RCP_EXACT = 1, /* IEEE division in the same rounding mode: portable, what the HIP path does   */
+  ORC_RCP_CLEAN = 2  /* ORC_RCP_EXACT, and additionally the scale estimate uses every residual's own outer product (no Q5)
+                        and the log-likelihood counts the last n % 50 residuals (no Q6): SURVEY.md's "CLEAN" oracle, only
+                        there to report how far the bug-compatible result is from the intended algorithm */
 };
 
 /* dense_tracking.h:71-81 */

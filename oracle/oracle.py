@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libdvo_oracle.so")
 
 MAX_LEVELS = 8
-RCP_SSE, RCP_EXACT = 0, 1
+RCP_SSE, RCP_EXACT, RCP_CLEAN = 0, 1, 2
 TERMINATION = {0: "IterationsExceeded", 1: "IncrementTooSmall", 2: "LogLikelihoodDecreased", 3: "TooFewConstraints", -1: "Unset"}
 
 

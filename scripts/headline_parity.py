@@ -14,7 +14,8 @@ for (w, h, levels) in ((640, 480, 4), (1280, 960, 5)):
         capi.RgbdImagePyramid(Ir, Zr, K, levels), capi.RgbdImagePyramid(Ic, Zc, K, levels))
     pr, pc = orc.Pyramid(Ir, Zr, K, levels), orc.Pyramid(Ic, Zc, K, levels)
     line = [f"{w}x{h}: |log(Tgt^-1 T_gpu)| = {synth.pose_error(Tgt, g.Transformation):.2e}"]
-    for name, mode in (("exact-reciprocal oracle", orc.RCP_EXACT), ("rcpps oracle (this host)", orc.RCP_SSE)):
+    for name, mode in (("exact-reciprocal oracle", orc.RCP_EXACT), ("rcpps oracle (this host)", orc.RCP_SSE),
+                       ("CLEAN oracle (no Q5 / Q6)", orc.RCP_CLEAN)):
         o = orc.match(orc.default_config(first_level=levels - 1, last_level=0, rcp_mode=mode), pr, pc)
         same = all(Lg["TerminationCriterion"] == Lo["termination"] and len(Lg["Iterations"]) == len(Lo["iterations"])
                    for Lg, Lo in zip(g.Levels, o["levels"]))

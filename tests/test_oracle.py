@@ -230,6 +230,29 @@ def test_weights_scale_loglik_against_numpy_restatement(orc, n, unit):
     assert abs(ll - pll) <= 4 * np.spacing(f32(abs(pll)))  # libm log vs numpy log: a few ulp of the float result
 
 
+@pytest.mark.parametrize("n", [7, 50, 51, 203])
+def test_clean_mode_uses_every_residual_and_the_whole_likelihood(orc, n):
+    """ORC_RCP_CLEAN (SURVEY.md's CLEAN oracle): the scale estimate is the plain weighted scatter (no Q5 pairing quirk) and
+    the log-likelihood includes the last n % 50 residuals (no Q6); everything else is the exact-reciprocal mode."""
+    rng = np.random.default_rng(300 + n)
+    res = (rng.normal(size=(n, 2)) * np.array([0.02, 0.05])).astype(f32)
+    P_in = np.array([2000.0, -30.0, -30.0, 400.0], f32)
+    out = {}
+    for mode in (orc.RCP_EXACT, orc.RCP_CLEAN):
+        w, cov, P = np.zeros(n, f32), np.zeros(4, f32), np.zeros(4, f32)
+        ll = orc.lib().orc_weights_scale_loglik(_fp(res), n, _fp(P_in), 0, mode, _fp(w), _fp(cov), _fp(P))
+        out[mode] = (w.copy(), cov.copy(), P.copy(), float(ll))
+    w = out[orc.RCP_CLEAN][0]
+    assert np.array_equal(w, out[orc.RCP_EXACT][0])  # the weights are the same
+    want = (w[:, None, None].astype(np.float64) * res[:, :, None] * res[:, None, :]).sum(0) / (n - 3)
+    assert np.allclose(out[orc.RCP_CLEAN][1].reshape(2, 2), want, rtol=1e-5)
+    assert not np.allclose(out[orc.RCP_EXACT][1].reshape(2, 2), want, rtol=1e-3)  # Q5 is visible at this size
+    P = out[orc.RCP_CLEAN][2].astype(np.float64).reshape(2, 2)
+    q = np.einsum("ni,ij,nj->n", res.astype(np.float64), P, res.astype(np.float64))
+    ll_full = 0.5 * n * np.log(np.linalg.det(P)) - 3.5 * np.log1p(0.2 * q).sum()
+    assert abs(out[orc.RCP_CLEAN][3] - ll_full) <= 2e-4 * abs(ll_full)
+
+
 def test_sse_rcp_mode_is_a_12bit_reciprocal(orc):
     xs = np.linspace(0.5, 7.9, 1000).astype(f32)
     rel = [abs(orc.lib().orc_host_rcp(float(x)) * float(x) - 1.0) for x in xs]
