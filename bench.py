@@ -236,8 +236,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, ref_frame, cur_frames, K, levels, first_level)
         if world == 1 and not args.no_extras:
-            for name, fn in (("parity", lambda: parity(capi, synth, ref_frame, cur_frames[0], K, levels, first_level, device)),
-                             ("stream_copy", lambda: stream_copy(device)),
+            for name, fn in (("stream_copy", lambda: stream_copy(device)),
                              ("ingest", lambda: ingest_timing(capi, synth, cur_frames, K, levels, device)),
                              ("loop_closure_validator", lambda: validator_timing(capi, synth, W, H, device)),
                              ("cpu_baseline_all_cores", lambda: None if args.no_cpu_baseline else
@@ -313,23 +312,6 @@ def traffic_from_profiles():
         return json.load(open(os.path.join(here, "profiles", "r01_traffic.json")))["traffic_bytes_per_launch"]
     except Exception:
         return None
-
-
-def parity(capi, synth, ref_frame, cur_frame, K, levels, first_level, device):
-    """||log(T_oracle^-1 T_gpu)|| of one pair of the workload against the three modes of the CPU restatement (the gate is
-    1e-5 against the exact-reciprocal mode; the rcpps mode is host specific; CLEAN drops the reference's quirks Q5 / Q6)."""
-    from oracle import oracle as orc
-
-    g = capi.DenseTracker(capi.Config(FirstLevel=first_level, LastLevel=0), device=device).match(
-        capi.RgbdImagePyramid(ref_frame[0], ref_frame[1], K, levels, device=device),
-        capi.RgbdImagePyramid(cur_frame[0], cur_frame[1], K, levels, device=device))
-    pr, pc = orc.Pyramid(ref_frame[0], ref_frame[1], K, levels), orc.Pyramid(cur_frame[0], cur_frame[1], K, levels)
-    out = {"tolerance": 1e-5}
-    for name, mode in (("vs_exact_reciprocal_oracle", orc.RCP_EXACT), ("vs_rcpps_oracle_this_host", orc.RCP_SSE),
-                       ("vs_clean_oracle", orc.RCP_CLEAN)):
-        o = orc.match(orc.default_config(first_level=first_level, last_level=0, rcp_mode=mode), pr, pc)
-        out[name] = synth.pose_error(o["T"], g.Transformation)
-    return out
 
 
 def stream_copy(device):
