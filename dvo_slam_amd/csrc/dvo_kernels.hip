@@ -723,8 +723,9 @@ hipError_t launch_tick(const TickArgs &args, int max_blocks, hipStream_t stream,
     else if (t_start && t_stop)
     {
       void *kargs[] = {const_cast<TickArgs *>(&args)};
-      (void)hipExtLaunchKernel(reinterpret_cast<const void *>(&k_tick<1, 1, 4>), grid, dim3(kBlockThreads), kargs, 0, stream,
-                               t_start, t_stop, 0);
+      const hipError_t e = hipExtLaunchKernel(reinterpret_cast<const void *>(&k_tick<1, 1, 4>), grid, dim3(kBlockThreads),
+                                              kargs, 0, stream, t_start, t_stop, 0);
+      if (e != hipSuccess) return e;
     }
     else
       hipLaunchKernelGGL((k_tick<1, 1, 4>), grid, dim3(kBlockThreads), 0, stream, args);
@@ -739,8 +740,9 @@ hipError_t launch_tick_table(const TickItem *items_dev, int n_items, int max_blo
   if (t_start && t_stop)
   {
     void *kargs[] = {&items_dev};
-    (void)hipExtLaunchKernel(reinterpret_cast<const void *>(&k_tick_table<1, 1, 4>), grid, dim3(kBlockThreads), kargs, 0,
-                             stream, t_start, t_stop, 0);
+    const hipError_t e = hipExtLaunchKernel(reinterpret_cast<const void *>(&k_tick_table<1, 1, 4>), grid, dim3(kBlockThreads),
+                                            kargs, 0, stream, t_start, t_stop, 0);
+    if (e != hipSuccess) return e;
   }
   else
     hipLaunchKernelGGL((k_tick_table<1, 1, 4>), grid, dim3(kBlockThreads), 0, stream, items_dev);
