@@ -750,13 +750,16 @@ hipError_t launch_tick_table(const TickItem *items_dev, int n_items, int max_blo
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// finalize: one 1024-thread block per job.  Sums the 87 moments over the blocks in fp64, combines the ordered part of the
+// finalize: one 512-thread block per job.  Sums the 87 moments over the blocks in fp64, combines the ordered part of the
 // records (count, S under both start parities, boundary residual/weight) left to right, locates the log-likelihood
 // cut, sums the log-likelihood partials.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int kFinThreads = 1024;
+#ifndef DVO_FIN_THREADS
+#define DVO_FIN_THREADS 512  // measured 384 / 448 / 512 / 640 / 1024: 512 schedules best next to other streams' k_tick blocks
+#endif
+constexpr int kFinThreads = DVO_FIN_THREADS;
 constexpr int kFinSegThreads = 64;    // wave 0: the ordered part of the records (no block barriers inside)
-constexpr int kFinAccFirst = 256;     // threads [256,1024): 32 row-chunks x 24 groups of 4 columns
+constexpr int kFinAccFirst = 256;     // threads [256, ...): row-chunks x 24 groups of 4 columns
 constexpr int kFinCols = 96;
 constexpr int kFinCol4 = kFinCols / 4;
 constexpr int kFinChunks = (kFinThreads - kFinAccFirst) / kFinCol4;
@@ -875,7 +878,7 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const FinArgs args) {
       for (int i = 0; i < 3; ++i) sh_out.S[i] = 0.0, sh_out.S_odd[i] = 0.0;
       sh_out.first_w = sh_out.last_r0 = sh_out.last_r1 = sh_out.pad_f = 0.0f;
     }
-  } else if (t >= kFinAccFirst) {
+  } else if (t >= kFinAccFirst && (t - kFinAccFirst) / kFinCol4 < kFinChunks) {
     // moments: 16-byte loads (4 columns), rows strided by the 32 chunks, four independent loads in flight per thread
     const int c4 = (t - kFinAccFirst) % kFinCol4, chunk = (t - kFinAccFirst) / kFinCol4;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
