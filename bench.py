@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- frame-pairs/s of the dense RGB-D alignment hot path on MI355X (BASELINE.json metric).
 
-A "step" = one lock-step batch of B independent 640x480 frame pairs (4-level coarse-to-fine Gauss-Newton,
+A "step" = one pass over B independent 640x480 frame pairs (4-level coarse-to-fine Gauss-Newton,
 FirstLevel 3 -> LastLevel 0, reference defaults otherwise) aligned on ONE GPU through the C ABI
-(dvo_amd_match_batch); pyramids of all frames are built beforehand and stay resident in HBM, as
+(dvo_amd_match_many): T host threads, each with its own tracker, work through an equal share of the batch with a fixed
+number of pairs resident at a time.  Pyramids of all frames are built beforehand and stay resident in HBM, as
 LocalTracker::update pre-builds them (dvo_slam/src/local_tracker.cpp:163-169), so the timed region is
 DenseTracker::match only.  With N GPUs every rank aligns its own B pairs (independent units, no data-path
 collective): weak scaling, value = N * B * K / max-over-ranks(time).
