@@ -188,6 +188,30 @@ def test_headline_parity_against_all_oracle_modes(capi, orc, synth, size, capsys
     assert synth.pose_error(Tgt, g.Transformation) < 2e-5
 
 
+@pytest.mark.parametrize("size", [(336, 250, 3), (64, 48, 2), (132, 97, 1), (1008, 500, 3)])
+def test_odd_sizes_match_the_oracle(capi, orc, synth, size):
+    """Widths that are not multiples of 64, odd heights, a level smaller than one wave segment, a single level: planes and
+    residuals bit-exact, poses within the bar (no padding / tail assumptions leak into the result)."""
+    w, h, levels = size
+    (Ir, Zr), (Ic, Zc), Tgt = synth.make_pair(w, h, xi_gt=synth.XI_GT_PAIR * 0.4)
+    K = synth.intrinsics_for(w, h)
+    gr, gc = capi.RgbdImagePyramid(Ir, Zr, K, levels), capi.RgbdImagePyramid(Ic, Zc, K, levels)
+    orr, occ = orc.Pyramid(Ir, Zr, K, levels), orc.Pyramid(Ic, Zc, K, levels)
+    for level in range(levels):
+        for plane in (0, 1, 2, 5):
+            a, b = gc.plane(level, plane), occ.plane(level, plane)
+            assert a.shape == b.shape and np.array_equal(_bits(a)[~np.isnan(b)], _bits(b)[~np.isnan(b)])
+        T = synth.se3_exp(synth.XI_GT_PAIR * 0.3)
+        trk = capi.DenseTracker(capi.Config(FirstLevel=levels - 1, LastLevel=0))
+        got, nv = trk.residuals(gr, gc, level, T)
+        want, n_want = _oracle_residual_image(orc, orr, occ, level, T, got.shape[:2])
+        assert nv == n_want
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        m = ~np.isnan(got)
+        assert np.array_equal(_bits(got[m]), _bits(want[m]))
+    _check_match(capi, orc, synth, gr, gc, orr, occ, dict(FirstLevel=levels - 1, LastLevel=0))
+
+
 def test_match_reference_default_levels(capi, orc, synth, pair640):
     """the reference's default FirstLevel 3 -> LastLevel 1 (dense_tracking_config.cpp:28-29)"""
     _check_match(capi, orc, synth, pair640["gr"], pair640["gc"], pair640["orr"], pair640["occ"], dict())
