@@ -602,12 +602,14 @@ __device__ void loglik_pass(const TickItem &it, const LevelPairDesc &d, const in
     const int steps = ll_rounds * kPxPerLane;
     const DVO_GLOBAL v2f *src = (const DVO_GLOBAL v2f *)((it.flags & kItemLlBuf) ? d.res[1] : d.res[0]) + seg * (kSegPxPerRound * ll_rounds) + lane;
     int run_count = seg_before;
-    // four steps (256 pixels) per trip: one log of a product of up to four terms per lane
+    // four steps (256 pixels) per trip; one log per lane of the product of up to 16 terms (four trips), like the
+    // reference takes one log per 50 residuals (dense_tracking_impl.cpp:415-419): a term is 1 + 0.2 r^T P r >= 1, and
+    // sixteen of them stay far below the double range
+    double prod = 1.0;
     for (int step = 0; step < steps; step += 4) {
       v2f r[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) r[k] = src[(step + k) * kWave];
-      double prod = 1.0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const bool valid = r[k].x == r[k].x;
@@ -621,8 +623,12 @@ __device__ void loglik_pass(const TickItem &it, const LevelPairDesc &d, const in
         }
         run_count += __popcll(b);
       }
-      if (prod != 1.0) total += log(prod);
+      if ((step & 12) == 12) {
+        if (prod != 1.0) total += log(prod);
+        prod = 1.0;
+      }
     }
+    if (prod != 1.0) total += log(prod);
   }
   total = wave_sum_double(total);
   __shared__ double smd[kWavesPerBlock];
