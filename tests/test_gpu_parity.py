@@ -375,6 +375,26 @@ def test_deterministic_and_batch_equals_single(capi, synth, pair640):
         assert raw[i].is_nan == 0 and raw[i].n_levels == 4
 
 
+def test_odometry_over_a_frame_stream_composes_to_ground_truth(capi, synth):
+    """BASELINE config 4's workload (frame t-1 -> frame t along xi(t) = t * xi_step) as one batch: the chained estimates
+    reproduce the trajectory, every pair agrees with ground truth, and chaining 2-frame hops agrees with 1-frame hops."""
+    n, w, h = 10, 640, 480
+    K = synth.intrinsics_for(w, h)
+    poses = synth.stream_poses(n)
+    pyr = [capi.RgbdImagePyramid(*synth.render(w, h, poses[t], frame_id=t), K, 4) for t in range(n)]
+    trk = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0))
+    hops = trk.match_batch(pyr[:-1], pyr[1:], stats=False)
+    acc = np.eye(4)
+    for t, r in enumerate(hops):
+        assert not r.isNaN()
+        assert synth.pose_error(r.Transformation, poses[t + 1] @ np.linalg.inv(poses[t])) < 3e-5
+        acc = r.Transformation @ acc
+    assert synth.pose_error(acc, poses[-1]) < 1e-4  # nine hops, errors do not pile up
+    double = trk.match_batch(pyr[:-2], pyr[2:], stats=False)
+    for t, r in enumerate(double):
+        assert synth.pose_error(r.Transformation, hops[t + 1].Transformation @ hops[t].Transformation) < 6e-5
+
+
 def test_pyramid_from_device_memory(capi, synth, pair640):
     torch = pytest.importorskip("torch")
     (Ir, Zr), (Ic, Zc) = pair640["frames"]
