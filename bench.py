@@ -247,6 +247,7 @@ def main():
             for name, fn in (("stream_copy", lambda: stream_copy(device)),
                              ("ingest", lambda: ingest_timing(capi, synth, cur_frames, K, levels, device)),
                              ("loop_closure_validator", lambda: validator_timing(capi, synth, W, H, device)),
+                             ("dual_match_front_end", lambda: dual_match_timing(capi, ref, curs, levels, first_level, device)),
                              ("cpu_baseline_all_cores", lambda: None if args.no_cpu_baseline else
                               cpu_baseline_threads(args, ref_frame, cur_frames, K, levels, first_level))):
                 try:
@@ -399,6 +400,26 @@ def validator_timing(capi, synth, W, H, device):
             "what": "dvo_amd_validate_proposals: 64 proposals (32 candidates x {identity, relative pose}), stage 1 = 128 "
                     "level-3 alignments (proposals + cross-validation inverses), stage 2 = 64 alignments over levels 3..1, "
                     "evaluation thresholds open so that every proposal reaches stage 2"}
+
+
+def dual_match_timing(capi, keyframe, frames, levels, first_level, device):
+    """SURVEY.md 8f row 3: the two alignments LocalTracker::update runs per frame (keyframe -> frame, last frame -> frame) as
+    one two-pair batch (dvo_amd_track_frame) against two single match() calls one after the other."""
+    trk = capi.DenseTracker(capi.Config(FirstLevel=first_level, LastLevel=1, UseInitialEstimate=True), device=device)
+    eye = np.eye(4)
+    n = 20
+    trk.track_frame(keyframe, frames[0], frames[1], eye)
+    t0 = time.perf_counter()
+    for i in range(n):
+        trk.track_frame(keyframe, frames[i % 4], frames[(i + 1) % 4], eye)
+    fused = (time.perf_counter() - t0) * 1e3 / n
+    t0 = time.perf_counter()
+    for i in range(n):
+        trk.match(keyframe, frames[(i + 1) % 4], eye)
+        trk.match(frames[i % 4], frames[(i + 1) % 4], eye)
+    serial = (time.perf_counter() - t0) * 1e3 / n
+    return {"ms_per_frame_two_pair_batch": fused, "ms_per_frame_two_single_matches": serial,
+            "what": "levels 3..1 (the reference's default LastLevel), keyframe -> frame and last frame -> frame"}
 
 
 def cpu_baseline_threads(args, ref_frame, cur_frames, K, levels, first_level):
