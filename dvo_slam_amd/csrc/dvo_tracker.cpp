@@ -743,7 +743,13 @@ int pick_rounds(long long total_px) {
   // residual pass itself (1 vs 2 rounds: within 4 %).  Longer segments mean fewer per-block records for k_finalize to
   // read, which matters once many pairs are resident.
   const long long waves1 = total_px / kSegPxPerRound;
-  return waves1 >= 65536 ? 4 : waves1 >= 8192 ? 2 : 1;
+  static long long t2 = -1, t4 = -1;
+  if (t2 < 0) {  // DVO_AMD_ROUNDS_AT="waves_for_2,waves_for_4" (tuning)
+    long long a = 8192, b = 65536;
+    if (const char *e = getenv("DVO_AMD_ROUNDS_AT")) (void)sscanf(e, "%lld,%lld", &a, &b);
+    t4 = b, t2 = a;
+  }
+  return waves1 >= t4 ? 4 : waves1 >= t2 ? 2 : 1;
 }
 
 // a pair of events for the next timed launch; the launch itself stamps them (begin / end of that dispatch)
