@@ -83,13 +83,14 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int n_blocks) {
 __device__ __forceinline__ float rcp_toward_zero(float z) {
   const float az = __builtin_fabsf(z);
   if (!(az >= 1.1754944e-38f && az <= 8.5070592e+37f)) return 1.0f / z;  // 0, denormal, huge, inf, NaN: never in bounds
+  // v_rcp_f32 is within 1 ulp, so the truncated quotient is one of r-2 .. r+1.  The sign of the exact residual
+  // 1 - az*c (one fma: exact, since az*c is within 2^-23 of 1) says on which side of 1/az a candidate c lies:
+  // first r itself, then its neighbour on the side the quotient must be.
   const unsigned r = f2u(__builtin_amdgcn_rcpf(az));
-  const float c_m1 = u2f(r - 1), c_0 = u2f(r), c_p1 = u2f(r + 1), c_p2 = u2f(r + 2);
-  const bool ok_m1 = __builtin_fmaf(-az, c_m1, 1.0f) >= 0.0f;
-  const bool ok_0 = __builtin_fmaf(-az, c_0, 1.0f) >= 0.0f;
-  const bool ok_p1 = __builtin_fmaf(-az, c_p1, 1.0f) >= 0.0f;
-  const bool ok_p2 = __builtin_fmaf(-az, c_p2, 1.0f) >= 0.0f;
-  const unsigned pick = ok_p2 ? r + 2 : ok_p1 ? r + 1 : ok_0 ? r : ok_m1 ? r - 1 : r - 2;
+  const bool r_below = __builtin_fmaf(-az, u2f(r), 1.0f) >= 0.0f;  // r <= 1/az
+  const unsigned n = r_below ? r + 1 : r - 1;
+  const bool n_below = __builtin_fmaf(-az, u2f(n), 1.0f) >= 0.0f;
+  const unsigned pick = r_below ? (n_below ? r + 1 : r) : (n_below ? r - 1 : r - 2);
   return __builtin_copysignf(u2f(pick), z);
 }
 
