@@ -384,6 +384,9 @@ struct dvo_amd_context {
   // area and its device copy (uploaded in-stream in front of the launch)
   TickItem *item_host = nullptr, *item_dev = nullptr;  // [kMaxTickStreams][kMaxTableItems]
   int items_per_launch = kMaxItemsPerLaunch;           // DVO_AMD_ITEMS_PER_LAUNCH (<= kMaxTableItems)
+  bool spec_levels = false;                            // DVO_AMD_SPEC_LEVELS=1: start the next level speculatively in the tick of a
+                                                       // level's last likelihood (-2..3 ticks per pair, but a converged level's last
+                                                       // likelihood is rejected about half the time: +3 % residual work; off)
   int phys_block_target = 1 << 30;                     // DVO_AMD_PHYS_BLOCKS=n: fold a launch's residual-pass blocks down to ~n
                                                        // physical blocks that walk several logical ones (measured: slower, off)
   // DVO_AMD_HOST_PROF=1: where the host thread spends its time (printed when the context is destroyed)
@@ -452,6 +455,13 @@ struct Job {
   bool have_a = false, have_b = false;  // a: iteration awaiting its likelihood; b: iteration whose residual pass is in flight
   bool sub_ll = false, sub_res = false;
   IterCtx a, b;
+  // Level transitions: when iteration a is the last of its level whatever its likelihood says (a.cont == false), the first
+  // residual pass of the next level is submitted in the same tick, assuming a is accepted (it almost always is).
+  IterCtx spec_b;
+  bool have_spec = false;
+  double sub_px = 0.0;  // selected pixels of the residual pass submitted in the current tick
+  int buf_flip = 0;   // residual-buffer parity of the current level's iteration 0 (the other one than the previous level's
+  int next_flip = 0;  // last likelihood pass reads, so that both can share a launch)
   // the last two iteration entries of the current level (the final result reads one of them, dense_tracking.cpp:368-373)
   dvo_amd_iteration_stats recent[2];
   int recent_count = 0;
@@ -489,7 +499,7 @@ void begin_iteration(Job &j, IterCtx &it, int k) {
   j.estimate = se3_compose(it.inc, j.estimate);
   it.initial_after = j.initial;
   it.estimate_after = j.estimate;
-  it.buf = k & 1;
+  it.buf = (k & 1) ^ j.buf_flip;
 }
 
 void finish_job(Job &j) {
@@ -555,9 +565,21 @@ void start_level(Job &j) {
   j.last_error = DBL_MAX;
   std::memset(j.precision, 0, sizeof(j.precision));
   se3_log(j.inc, j.x);  // :238 (Q1: re-applies the last applied or rejected increment)
+  j.buf_flip = j.next_flip;
   begin_iteration(j, j.b, 0);
   j.have_a = false;
   j.have_b = true;
+}
+
+// Iteration 0 of the next level as start_level() will set it up if iteration a's likelihood is accepted.  Works on a copy:
+// nothing of the pair's state or result is touched.  (An accepted likelihood leaves initial / estimate / inc as they are,
+// dense_tracking.cpp:312-357; the increment itself only enters the termination statistics of the finished level.)
+void speculate_next_level(const Job &j, IterCtx &b_out) {
+  Job c = j;
+  c.level = j.level - 1;
+  se3_log(c.inc, c.x);
+  c.buf_flip = j.a.buf ^ 1;
+  begin_iteration(c, b_out, 0);
 }
 
 // K * T[0:3,0:4] in float, evaluated like Eigen's coefficient-based 3x3 * 3x4 product (dense_tracking_impl.cpp:142-152)
@@ -656,6 +678,8 @@ void process_loglik(Job &j, const FinOut *outs) {
   j.error = -(double)ll;
   const bool accept = j.error < j.last_error;  // :312
   if (!accept) {
+    j.have_spec = false;  // a speculative start of the next level assumed acceptance: discarded
+    j.next_flip = a.buf ^ 1;
     // :314-322: roll back iteration a (and the speculative iteration b, if any)
     j.initial = a.initial_before;
     j.estimate = a.estimate_before;
@@ -672,7 +696,17 @@ void process_loglik(Job &j, const FinOut *outs) {
   std::memcpy(j.x, a.x_new, sizeof(j.x));
   j.iteration = a.k + 1;
   if (!a.cont) {
+    const bool spec = j.have_spec;
+    const IterCtx spec_b = j.spec_b;
+    j.have_spec = false;
+    j.next_flip = a.buf ^ 1;
     end_level(j);
+    if (spec && !j.done && j.have_b) {
+      // the next level's first residual pass ran in this tick with exactly the state start_level() has just set up
+      j.b.rounds = spec_b.rounds, j.b.n_blocks = spec_b.n_blocks;
+      IterCtx b = j.b;
+      process_residual(j, b, o);
+    }
     return;
   }
   // iteration b's residual pass ran in the same tick
@@ -845,8 +879,16 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
   const double t_begin = ctx->host_prof ? now_ns() : 0.0;
   grp.in_flight = false;
   long long total_px = 0;
-  for (size_t ji = grp.lo; ji < grp.hi; ++ji)
-    if (!jobs[ji].done && jobs[ji].have_b) total_px += jobs[ji].ref->lv[jobs[ji].level].n;
+  const bool speculate_levels = ctx->spec_levels;
+  auto wants_spec = [&](const Job &j) {
+    return speculate_levels && j.have_a && !j.have_b && !j.a.cont && j.level > j.cfg->last_level;
+  };
+  for (size_t ji = grp.lo; ji < grp.hi; ++ji) {
+    const Job &j = jobs[ji];
+    if (j.done) continue;
+    if (j.have_b) total_px += j.ref->lv[j.level].n;
+    if (wants_spec(j)) total_px += j.ref->lv[j.level - 1].n;
+  }
   const int rounds_now = pick_rounds(total_px);
   const unsigned seq = ++ctx->tick_seq;
   grp.seq = seq;
@@ -893,8 +935,32 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
       f.n_blocks = w.res_blocks;
       f.seg_prefix_out = j.slot->seg_prefix[j.b.buf];
       j.sub_res = true;
+      j.sub_px = (double)j.ref->selections[j.sel].count[j.level];
       j.result->n_residual_passes++;
-      j.alg_px += (double)j.ref->selections[j.sel].count[j.level];
+      j.alg_px += j.sub_px;
+    } else if (wants_spec(j)) {
+      // iteration a ends its level whatever its likelihood says: start the next level in this tick, assuming acceptance
+      const int nl = j.level - 1;
+      speculate_next_level(j, j.spec_b);
+      j.spec_b.rounds = rounds_now;
+      while (j.spec_b.rounds < kMaxRounds && blocks_for(j.ref->lv[nl].n, j.spec_b.rounds) > 2048) j.spec_b.rounds *= 2;
+      j.spec_b.n_blocks = blocks_for(j.ref->lv[nl].n, j.spec_b.rounds);
+      w.ref = j.ref->selections[j.sel].ref_desc + nl;  // the likelihood pass only uses the slot's buffers
+      w.cur = j.cur->cur_desc + nl;
+      w.res_blocks = (uint16_t)j.spec_b.n_blocks;
+      w.res_phys = w.res_blocks;
+      res_rounds = j.spec_b.rounds;
+      if (j.spec_b.buf) w.flags |= kItemResBuf;
+      w.flags |= kItemUnitWeights;
+      make_kt(j.cur->lv[nl], j.spec_b.estimate_after, w.kt);
+      f.records = j.slot->records;
+      f.n_blocks = w.res_blocks;
+      f.seg_prefix_out = j.slot->seg_prefix[j.spec_b.buf];
+      j.have_spec = true;
+      j.sub_res = true;
+      j.sub_px = (double)j.ref->selections[j.sel].count[nl];
+      j.result->n_residual_passes++;
+      j.alg_px += j.sub_px;
     }
     // the likelihood of iteration k and the weights of iteration k+1 both use the precision of iteration k (a's); without a
     // pending likelihood the weights use the job's current precision (unused at the first iteration of a level)
@@ -955,7 +1021,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
       for (size_t ji = grp.lo, k = 0; ji < grp.hi; ++ji) {
         const Job &j = jobs[ji];
         if (j.done || !(j.sub_ll || j.sub_res)) continue;
-        if (k >= first && k < first + (size_t)n_here && j.sub_res) px += (double)j.ref->selections[j.sel].count[j.level];
+        if (k >= first && k < first + (size_t)n_here && j.sub_res) px += j.sub_px;
         ++k;
       }
       const double rec[6] = {0.0, (double)n_here, rb, lb, (double)max_blocks, px};
@@ -1266,6 +1332,7 @@ int dvo_amd_context_create(int device, const dvo_amd_config *cfg, dvo_amd_contex
   ctx->fin_stamps = fs && fs[0] == '1';
   const char *hp = getenv("DVO_AMD_HOST_PROF");
   ctx->host_prof = hp && hp[0] == '1';
+  if (const char *sl = getenv("DVO_AMD_SPEC_LEVELS")) ctx->spec_levels = sl[0] == '1';
   if (const char *pb = getenv("DVO_AMD_PHYS_BLOCKS")) {
     const int v = atoi(pb);
     if (v >= 64) ctx->phys_block_target = v;

@@ -395,6 +395,28 @@ def test_odometry_over_a_frame_stream_composes_to_ground_truth(capi, synth):
         assert synth.pose_error(r.Transformation, hops[t + 1].Transformation @ hops[t].Transformation) < 6e-5
 
 
+def test_speculative_level_start_gives_the_same_results(capi, synth, pair640, monkeypatch):
+    """DVO_AMD_SPEC_LEVELS=1 (next level started in the tick of a level's last likelihood): fewer ticks, identical
+    iteration paths and poses (the option is read when a tracker is created)."""
+    cfg = capi.Config(FirstLevel=3, LastLevel=0)
+    plain = capi.DenseTracker(cfg)
+    monkeypatch.setenv("DVO_AMD_SPEC_LEVELS", "1")
+    spec = capi.DenseTracker(cfg)
+    monkeypatch.delenv("DVO_AMD_SPEC_LEVELS")
+    fewer = 0
+    for ref, cur in ((pair640["gr"], pair640["gc"]), (pair640["gc"], pair640["gr"]), (pair640["gr"], pair640["gr"])):
+        a, b = plain.match(ref, cur), spec.match(ref, cur)
+        assert np.array_equal(a.Transformation, b.Transformation) and np.array_equal(a.Information, b.Information)
+        assert [(L["TerminationCriterion"], len(L["Iterations"])) for L in a.Levels] == \
+               [(L["TerminationCriterion"], len(L["Iterations"])) for L in b.Levels]
+        assert b.n_ticks <= a.n_ticks
+        fewer += a.n_ticks - b.n_ticks
+    assert fewer > 0
+    batch = spec.match_batch([pair640["gr"]] * 50, [pair640["gc"]] * 50, stats=False, in_flight=40)
+    ref = plain.match(pair640["gr"], pair640["gc"])
+    assert all(synth.pose_error(ref.Transformation, o.Transformation) <= POSE_TOL for o in batch)
+
+
 def test_pyramid_from_device_memory(capi, synth, pair640):
     torch = pytest.importorskip("torch")
     (Ir, Zr), (Ic, Zc) = pair640["frames"]
