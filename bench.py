@@ -78,6 +78,7 @@ def main():
     if capi.lib().dvo_amd_device_count() < 1:
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     device = local_rank
+    numa = pin_to_gpu_numa_node(device)
     W, H = args.width, args.height
     levels = 5 if W >= 1280 else 4
     first_level = levels - 1
@@ -208,6 +209,7 @@ def main():
                             f"and resident in HBM",
                 "pairs_per_step_per_gpu": B,
                 "host_threads_per_gpu": T,
+                "host_threads_pinned_to_numa_node": numa,
                 "pairs_in_flight_per_tracker": args.in_flight,
                 "sharding": "independent pairs per rank, no collective on the data path",
             },
@@ -310,6 +312,30 @@ def tile_shard_bench(args, capi, synth, sharding, dist, rank, world, device, ref
         }), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def pin_to_gpu_numa_node(device):
+    """Keep this rank's host threads (they poll pinned memory the GPU writes) on the CPU socket the GPU hangs off.  Best
+    effort: any failure, or an affinity mask that does not reach that node, leaves the process as it is."""
+    try:
+        import torch
+
+        p = torch.cuda.get_device_properties(device)
+        bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        allowed = os.sched_getaffinity(0) & cpus
+        if len(allowed) >= 8:
+            os.sched_setaffinity(0, allowed)
+            return node
+    except Exception:
+        pass
+    return None
 
 
 def traffic_from_profiles():
