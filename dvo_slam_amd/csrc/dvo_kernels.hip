@@ -717,25 +717,20 @@ hipError_t launch_tick(const TickArgs &args, int max_blocks, hipStream_t stream,
   }
   if (args.n_items <= 0 || max_blocks <= 0) return hipSuccess;
   dim3 grid((unsigned)((max_blocks + 7) & ~7), (unsigned)args.n_items, 1);
-  if (g_acc_mode == 0) {
-    if (g_reduce_mode == 0)
-      hipLaunchKernelGGL((k_tick<0, 0, 2>), grid, dim3(kBlockThreads), 0, stream, args);
-    else
-      hipLaunchKernelGGL((k_tick<1, 0, 2>), grid, dim3(kBlockThreads), 0, stream, args);
-  } else if (g_occ == 5) {
-    hipLaunchKernelGGL((k_tick<1, 1, 5>), grid, dim3(kBlockThreads), 0, stream, args);
+  void (*kernel)(const TickArgs) = k_tick<1, 1, 4>;
+  if (g_acc_mode == 0)
+    kernel = g_reduce_mode == 0 ? k_tick<0, 0, 2> : k_tick<1, 0, 2>;
+  else if (g_occ == 5)
+    kernel = k_tick<1, 1, 5>;
+  else if (g_reduce_mode == 0)
+    kernel = k_tick<0, 1, 4>;
+  if (t_start && t_stop) {
+    void *kargs[] = {const_cast<TickArgs *>(&args)};
+    const hipError_t e = hipExtLaunchKernel(reinterpret_cast<const void *>(kernel), grid, dim3(kBlockThreads), kargs, 0, stream,
+                                            t_start, t_stop, 0);
+    if (e != hipSuccess) return e;
   } else {
-    if (g_reduce_mode == 0)
-      hipLaunchKernelGGL((k_tick<0, 1, 4>), grid, dim3(kBlockThreads), 0, stream, args);
-    else if (t_start && t_stop)
-    {
-      void *kargs[] = {const_cast<TickArgs *>(&args)};
-      const hipError_t e = hipExtLaunchKernel(reinterpret_cast<const void *>(&k_tick<1, 1, 4>), grid, dim3(kBlockThreads),
-                                              kargs, 0, stream, t_start, t_stop, 0);
-      if (e != hipSuccess) return e;
-    }
-    else
-      hipLaunchKernelGGL((k_tick<1, 1, 4>), grid, dim3(kBlockThreads), 0, stream, args);
+    hipLaunchKernelGGL(kernel, grid, dim3(kBlockThreads), 0, stream, args);
   }
   return hipGetLastError();
 }
