@@ -213,7 +213,7 @@ typedef float v4acc __attribute__((ext_vector_type(4)));
 
 // Timing-only ablation builds (scripts/ablate.sh: -DDVO_ABLATE=<mask>); never defined in the shipped library.
 // 1: no LDS staging / MFMA   2: no gather loads   4: no rank / pair-sum logic   8: no residual spill store
-// 16: no pixel steps at all (prologue + epilogue only)
+// 16: no pixel steps at all (prologue + epilogue only)   32: no epilogue (reductions, block record)
 #ifndef DVO_ABLATE
 #define DVO_ABLATE 0
 #endif
@@ -485,6 +485,10 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
     do_step(steps - 1, 1, false);
   }
 
+  if (DVO_ABLATE & 32) {  // (ablation 32: no epilogue -- keep the accumulators alive, write nothing)
+    DVO_KEEP(S0[0] + S1[0] + first_w + gram_a[0] + gram_b[0] + carry_r0 + (float)run_count);
+    return;
+  }
   if (ACC == 1 && !(DVO_ABLATE & 1) && steps > 0) gram_from_stage(1);  // the last step (odd index) staged into buffer 1
 
   // ---- wave reduction, then the four waves of the block through LDS
