@@ -417,6 +417,27 @@ def test_speculative_level_start_gives_the_same_results(capi, synth, pair640, mo
     assert all(synth.pose_error(ref.Transformation, o.Transformation) <= POSE_TOL for o in batch)
 
 
+def test_item_table_launches_give_the_same_results(capi, synth, pair640, monkeypatch):
+    """DVO_AMD_ITEMS_PER_LAUNCH > 36: the work items of a tick go through a device-resident table uploaded in-stream instead
+    of the kernel arguments (up to 288 pairs per launch)."""
+    monkeypatch.setenv("DVO_AMD_ITEMS_PER_LAUNCH", "100")
+    table = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0))
+    monkeypatch.delenv("DVO_AMD_ITEMS_PER_LAUNCH")
+    plain = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0))
+    n = 230  # three launches of <= 100 pairs per tick, then a shrinking tail
+    refs = [pair640["gr"] if i % 2 else pair640["gc"] for i in range(n)]
+    curs = [pair640["gc"] if i % 2 else pair640["gr"] for i in range(n)]
+    out = table.match_batch(refs, curs, stats=False, raw=True)
+    fwd, bwd = plain.match(pair640["gr"], pair640["gc"]), plain.match(pair640["gc"], pair640["gr"])
+    for i in range(n):
+        T = np.array(out[i].transformation[:]).reshape(4, 4).T
+        assert synth.pose_error((fwd if i % 2 else bwd).Transformation, T) <= POSE_TOL
+    rolling = table.match_batch(refs, curs, stats=False, in_flight=150, raw=True)  # two groups of 75, both table launches
+    for i in range(n):
+        T = np.array(rolling[i].transformation[:]).reshape(4, 4).T
+        assert synth.pose_error((fwd if i % 2 else bwd).Transformation, T) <= POSE_TOL
+
+
 def test_pyramid_from_device_memory(capi, synth, pair640):
     torch = pytest.importorskip("torch")
     (Ir, Zr), (Ic, Zc) = pair640["frames"]
