@@ -843,6 +843,9 @@ int wait_tick(dvo_amd_context *ctx, const std::vector<Job> &jobs, size_t lo, siz
     const volatile unsigned *p = &ctx->out_host[j.slot - ctx->slots.data()].seq;
     unsigned long long spins = 0;
     while (__atomic_load_n(p, __ATOMIC_ACQUIRE) != seq) {
+#if defined(__x86_64__) || defined(__i386__)
+      __builtin_ia32_pause();  // be polite to the sibling hardware thread while spinning
+#endif
       if ((++spins & 0xFFFFF) == 0) {  // every ~1M polls make sure the streams are still alive
         bool all_idle = true;
         for (size_t si = 0; si <= ctx->extra_streams.size(); ++si) {
