@@ -46,6 +46,54 @@ def test_constraints_adaptor_compiles_as_plain_cxx11():
     assert res.returncode == 0, res.stderr
 
 
+CEXE = os.path.join(ROOT, "examples", "_build", "c_abi_example")
+
+
+def _compile_c():
+    from dvo_slam_amd import _build
+
+    _build.build()
+    os.makedirs(os.path.dirname(CEXE), exist_ok=True)
+    libdir = os.path.join(ROOT, "dvo_slam_amd")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Wpedantic", "-Werror", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "c_abi_example.c"), "-o", CEXE, "-L" + libdir, "-ldvo_amd",
+           "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    return CEXE
+
+
+def test_c_abi_header_is_plain_c99():
+    """include/dvo_amd.h from a C translation unit (no C++ anywhere): the binding a C host would write."""
+    assert os.path.exists(_compile_c())
+
+
+@pytest.mark.gpu
+def test_c_caller_with_raw_frames_matches_python_binding(tmp_path, synth):
+    from dvo_slam_amd import capi
+
+    exe = CEXE if os.path.exists(CEXE) else _compile_c()
+    w, h = 640, 480
+    (Ir, Zr), (Ic, Zc), Tgt = synth.make_pair(w, h)
+    K = synth.intrinsics_for(w, h)
+    raw_r, raw_c = synth.to_raw(Ir, Zr), synth.to_raw(Ic, Zc)
+    paths = []
+    for name, arr in (("rb", raw_r[0]), ("rz", raw_r[1]), ("cb", raw_c[0]), ("cz", raw_c[1])):
+        p = tmp_path / (name + ".raw")
+        np.ascontiguousarray(arr).tofile(p)
+        paths.append(str(p))
+    res = subprocess.run([exe, str(w), str(h)] + [repr(float(k)) for k in K] + paths, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    lines = res.stdout.strip().splitlines()
+    assert lines[0].startswith("isnan 0")
+    T = np.array([[float(v) for v in ln.split()] for ln in lines[1:5]])
+    trk = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0))
+    ref = trk.match(capi.RgbdImagePyramid.from_raw(*raw_r, K, 4), capi.RgbdImagePyramid.from_raw(*raw_c, K, 4))
+    assert synth.pose_error(ref.Transformation, T) <= 1e-9  # same library, same inputs
+    assert synth.pose_error(Tgt, T) < 2e-3  # 8-bit / 0.2 mm quantisation of the raw frames
+    assert lines[5].startswith("1305031102.175303936 ") and len(lines[5].split()) == 8
+
+
 @pytest.mark.gpu
 def test_adaptor_matches_python_binding(tmp_path, synth):
     from dvo_slam_amd import capi
