@@ -35,6 +35,9 @@ def parse():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--distinct", type=int, default=8, help="distinct current frames cycled through the batch")
+    ap.add_argument("--distinct-refs", type=int, default=1,
+                    help="distinct reference frames (default: one keyframe against many frames, BASELINE config 5; more of "
+                         "them push the working set beyond the 256 MiB Infinity Cache)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -113,7 +116,11 @@ def main():
     trackers = [capi.DenseTracker(capi.Config(FirstLevel=first_level, LastLevel=0), device=device) for _ in range(T)]
     trk = trackers[0]
     B = args.batch
-    refs = [ref] * B
+    ref_pyrs = [ref]
+    for i in range(1, max(1, args.distinct_refs)):
+        fr = synth.render(W, H, synth.se3_exp(synth.XI_GT_PAIR * 0.05 * i), frame_id=1000 + 2 * rank + i)
+        ref_pyrs.append(capi.RgbdImagePyramid(fr[0], fr[1], K, levels, device=device))
+    refs = [ref_pyrs[i % len(ref_pyrs)] for i in range(B)]
     curb = [curs[i % len(curs)] for i in range(B)]
     shares = sharding.split_for_threads(list(range(B)), T)
 
@@ -204,7 +211,7 @@ def main():
                 "workload": f"synthetic {W}x{H} RGB-D pairs (analytic room corner, seed 20131103), {levels}-level "
                             f"coarse-to-fine Gauss-Newton (FirstLevel {first_level} -> LastLevel 0, MaxIter 100, "
                             f"Precision 5e-7, Mu 0), {B} independent pairs per step per GPU ({args.distinct} distinct current "
-                            f"frames against one keyframe), worked through by {T} host threads (one tracker / HIP stream "
+                            f"frames against {len(ref_pyrs)} keyframe(s)), worked through by {T} host threads (one tracker / HIP stream "
                             f"each) with at most {args.in_flight or 'all'} pairs resident per tracker, pyramids pre-built "
                             f"and resident in HBM",
                 "pairs_per_step_per_gpu": B,
