@@ -1,0 +1,20 @@
+# Builds the C-ABI library without Python (the same command dvo_slam_amd/_build.py runs) and the oracle (test infrastructure).
+HIPCC ?= /opt/rocm/bin/hipcc
+SRC   := dvo_slam_amd/csrc
+LIB   := dvo_slam_amd/libdvo_amd.so
+FLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wall -Wno-unused-function
+
+all: $(LIB)
+
+$(LIB): $(SRC)/dvo_kernels.hip $(SRC)/dvo_tracker.cpp $(SRC)/dvo_validator.cpp $(SRC)/dvo_frontend.cpp $(SRC)/dvo_tum.cpp \
+        $(SRC)/dvo_types.h $(SRC)/se3.h include/dvo_amd.h
+	$(HIPCC) $(FLAGS) -x hip $(SRC)/dvo_kernels.hip $(SRC)/dvo_tracker.cpp $(SRC)/dvo_validator.cpp $(SRC)/dvo_frontend.cpp \
+	    $(SRC)/dvo_tum.cpp -lz -o $@
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -f $(LIB)
+
+.PHONY: all oracle clean
