@@ -28,27 +28,33 @@ ALG_BYTES_PER_POINT = 56.0
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="ranks = GPUs of this node; N > 1 without a torchrun environment makes this process spawn the N ranks "
+                         "itself (python -m torch.distributed.run ... bench.py <same arguments>)")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1152, help="frame pairs aligned per step per GPU")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--distinct", type=int, default=8, help="distinct current frames cycled through the batch")
-    ap.add_argument("--distinct-refs", type=int, default=1,
-                    help="distinct reference frames (default: one keyframe against many frames, BASELINE config 5; more of "
-                         "them push the working set beyond the 256 MiB Infinity Cache)")
+    ap.add_argument("--distinct", type=int, default=96, help="distinct current frames")
+    ap.add_argument("--distinct-refs", type=int, default=12,
+                    help="distinct keyframes.  Pair i of a step = (keyframe i %% R, frame (i // R) %% C): with the defaults "
+                         "(96 x 12 = 1152) every pair of a step is a different combination and the 108 pyramids (2.1 GB) "
+                         "are far beyond the 256 MiB Infinity Cache")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a one-GPU box: every rank uses GPU 0 and the ranks synchronise over gloo "
                          "(exercises the N > 1 code path; the figure is meaningless)")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="no GPU work at all: ranks rendezvous over gloo, 'align' their share with a stand-in sleep and print "
+                         "the line (tests/test_distributed.py checks the spawn / aggregate / one-line plumbing on the CPU)")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the informational side measurements (STREAM copy, frame ingest, loop-closure validator, "
-                         "all-core CPU baseline); rank 0 at N=1 only")
+                    help="skip the informational side measurements (cache-resident variant, STREAM copy, frame ingest, "
+                         "loop-closure validator, all-core CPU baseline); rank 0 at N=1 only")
     ap.add_argument("--tile-shard", action="store_true",
                     help="BASELINE config 4 instead of the default: ONE pair at a time, every level tile-sharded over the "
-                         "N GPUs with a per-iteration RCCL all-gather of the band records (strong scaling, expected to be "
+                         "N GPUs with a per-iteration exchange of the band records (strong scaling, expected to be "
                          "slower than 1 GPU at 640x480: a tick is ~26 us, so is a small-message all-gather)")
     ap.add_argument("--prime", type=int, default=2,
                     help="untimed priming steps run as part of set-up before the W warm-up steps: the first calls grow "
@@ -57,11 +63,71 @@ def parse():
                     help="pairs resident per tracker at a time (0 = the whole share in lock step)")
     ap.add_argument("--threads", type=int, default=8,
                     help="host threads per GPU, each with its own tracker (HIP stream) and an equal share of the batch")
+    ap.add_argument("--no-stats", action="store_true",
+                    help="drop the per-iteration statistics (Result.Statistics) in the timed region; by default they are "
+                         "delivered, as the reference's callers read them (keyframe_tracker.cpp:167, "
+                         "constraint_proposal_voter.cpp:128)")
     return ap.parse_args()
+
+
+def maybe_spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks as fresh child processes (one per
+    GPU) BEFORE this process touches the GPU, forward their output (rank 0 prints the one JSON line) and exit with their
+    code.  The reference deals its proposals over TBB workers the same way (keyframe_graph.cpp:576-593)."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def plumbing_only(args):
+    """The N-rank plumbing without a GPU: rendezvous (gloo), barrier, stand-in work, MAX / SUM aggregation, one line."""
+    from dvo_slam_amd import sharding
+
+    rank, _, world = sharding.rank_info()
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: F811
+
+        dist.init_process_group(backend="gloo")
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.05 * (1 + rank))  # the straggler sets the time
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    elapsed, pairs = sharding.aggregate(elapsed, args.batch * args.steps, dist, None if dist is None else "cpu")
+    if rank == 0:
+        print(json.dumps({"metric": "frame-pairs/s (640x480, 4-level GN align)", "value": pairs / elapsed,
+                          "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "none (plumbing rehearsal: no alignment ran)",
+                          "config": {"workload": "plumbing only", "pairs_total": pairs}}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def pair_index(i, n_refs, n_curs):
+    """pair i of a step -> (keyframe, frame): all n_refs * n_curs combinations before any repeats"""
+    return i % n_refs, (i // n_refs) % n_curs
 
 
 def main():
     args = parse()
+    maybe_spawn_ranks(args)
+    if args.plumbing_only:
+        return plumbing_only(args)
     from dvo_slam_amd import sharding
 
     rank, local_rank, world = sharding.rank_info()
@@ -86,14 +152,16 @@ def main():
     levels = 5 if W >= 1280 else 4
     first_level = levels - 1
     K = synth.intrinsics_for(W, H)
+    n_curs, n_refs = max(1, args.distinct), max(1, args.distinct_refs)
 
-    # ---- synthetic frames: one reference + `distinct` current frames at different poses (seeded, rank-dependent)
+    # ---- synthetic frames (seeded, rank-dependent): `distinct` current frames and `distinct-refs` keyframes at hashed poses
+    def cur_pose(i):
+        return synth.se3_exp(synth.XI_GT_PAIR * (0.5 + 0.9 * ((i * 7) % 13) / 13.0) * (1 if i % 2 == 0 else -1)
+                             + synth.XI_GT_PAIR[::-1] * 0.03 * ((i * 5) % 11 - 5))
+
     t0 = time.perf_counter()
     ref_frame = synth.render(W, H, None, frame_id=2 * rank)
-    cur_frames = []
-    for i in range(args.distinct):
-        xi = synth.XI_GT_PAIR * (0.6 + 0.1 * i) * (1 if i % 2 == 0 else -1)
-        cur_frames.append(synth.render(W, H, synth.se3_exp(xi), frame_id=2 * rank + 1 + 2 * i))
+    cur_frames = [synth.render(W, H, cur_pose(i), frame_id=2 * rank + 1 + 2 * i) for i in range(n_curs)]
     t_render = time.perf_counter() - t0
 
     # ---- pyramids (prep): built once, resident in HBM
@@ -101,11 +169,11 @@ def main():
     ref = capi.RgbdImagePyramid(ref_frame[0], ref_frame[1], K, levels, device=device)
     curs = [capi.RgbdImagePyramid(f[0], f[1], K, levels, device=device) for f in cur_frames]
     prep_first_ms = (time.perf_counter() - t0) * 1e3 / (1 + len(curs))  # includes the one-off slab allocations
-    # steady state (slabs come from the pool): build the same frames again and drop them
+    # steady state (slabs come from the pool): build some of the same frames again and drop them
     t0 = time.perf_counter()
-    for f in cur_frames:
+    for f in cur_frames[:8]:
         capi.RgbdImagePyramid(f[0], f[1], K, levels, device=device)
-    prep_ms = (time.perf_counter() - t0) * 1e3 / len(cur_frames)
+    prep_ms = (time.perf_counter() - t0) * 1e3 / len(cur_frames[:8])
     if args.tile_shard:
         return tile_shard_bench(args, capi, synth, sharding, dist, rank, world, device, ref_frame, cur_frames, K, levels,
                                 first_level)
@@ -113,29 +181,40 @@ def main():
     import threading
 
     T = max(1, min(args.threads, args.batch))
-    trackers = [capi.DenseTracker(capi.Config(FirstLevel=first_level, LastLevel=0), device=device) for _ in range(T)]
+    cfg = capi.Config(FirstLevel=first_level, LastLevel=0)
+    trackers = [capi.DenseTracker(cfg, device=device) for _ in range(T)]
     trk = trackers[0]
     B = args.batch
     ref_pyrs = [ref]
-    for i in range(1, max(1, args.distinct_refs)):
+    for i in range(1, n_refs):
         fr = synth.render(W, H, synth.se3_exp(synth.XI_GT_PAIR * 0.05 * i), frame_id=1000 + 2 * rank + i)
         ref_pyrs.append(capi.RgbdImagePyramid(fr[0], fr[1], K, levels, device=device))
-    refs = [ref_pyrs[i % len(ref_pyrs)] for i in range(B)]
-    curb = [curs[i % len(curs)] for i in range(B)]
+    n_pyramids = len(ref_pyrs) + len(curs)
+    pyramid_bytes = n_pyramids * 48.0 * sum((W >> l) * (H >> l) for l in range(levels))
+    idx = [pair_index(i, n_refs, n_curs) for i in range(B)]
+    refs = [ref_pyrs[r] for r, _ in idx]
+    curb = [curs[c] for _, c in idx]
+    distinct_pairs = len(set(idx))
     shares = sharding.split_for_threads(list(range(B)), T)
+    with_stats = not args.no_stats
+    # result structs (+ per-iteration statistics arrays) are allocated once per host thread and refilled every step
+    result_bufs = [trackers[t].alloc_results(len(shares[t])) if with_stats else None for t in range(T)]
 
-    def run_steps(n_steps, collect):
+    def run_steps(n_steps, collect, r_list=None, c_list=None, stats=with_stats):
         """n_steps lock-step batches of B pairs on this GPU; with T > 1 every thread drives its own stream"""
+        r_list, c_list = r_list or refs, c_list or curb
+
         def worker(t):
-            idx = shares[t]
-            r, c = [refs[i] for i in idx], [curb[i] for i in idx]
-            for s in range(n_steps):
+            ix = shares[t]
+            r, c = [r_list[i] for i in ix], [c_list[i] for i in ix]
+            for s_ in range(n_steps):
                 ts = time.perf_counter()
-                out = trackers[t].match_batch(r, c, stats=False, in_flight=args.in_flight, raw=True)
+                out = trackers[t].match_batch(r, c, stats=False, in_flight=args.in_flight, raw=True,
+                                              results=result_bufs[t] if stats else None)
                 collect.append((sum(o.alg_bytes for o in out), sum(o.n_residual_passes for o in out),
-                                sum(o.is_nan for o in out)))
+                                sum(o.is_nan for o in out), sum(o.n_iterations for o in out)))
                 if os.environ.get("DVO_BENCH_DEBUG"):
-                    print(f"thread {t} step {s}: {(time.perf_counter() - ts) * 1e3:.2f} ms", file=sys.stderr, flush=True)
+                    print(f"thread {t} step {s_}: {(time.perf_counter() - ts) * 1e3:.2f} ms", file=sys.stderr, flush=True)
         if T == 1:
             worker(0)
         else:
@@ -174,16 +253,19 @@ def main():
     elapsed = time.perf_counter() - t0
     alg_bytes = sum(c[0] for c in col)
     passes = sum(c[1] for c in col)
+    iterations_delivered = sum(c[3] for c in col)
     if sum(c[2] for c in col):
         raise SystemExit("bench.py: a pair of the timed region came back NaN")
     if T == 1:
         k_ms, k_launches = trk.kernel_timing(False)
+        log = trk.tick_log()
     else:
         # one host thread's share of the batch, same residency as in the timed region, on one stream
         trk.kernel_timing(True, reset=True)
         idx0 = shares[0]
         out = trk.match_batch([refs[i] for i in idx0], [curb[i] for i in idx0], stats=False, in_flight=args.in_flight)
         k_ms, k_launches = trk.kernel_timing(False)
+        log = trk.tick_log()
         alg_bytes_k = sum(o.alg_bytes for o in out)
     # MAX over ranks of the elapsed time, SUM over ranks of the pairs aligned
     elapsed, pairs = sharding.aggregate(elapsed, B * args.steps, dist,
@@ -210,16 +292,24 @@ def main():
             "config": {
                 "workload": f"synthetic {W}x{H} RGB-D pairs (analytic room corner, seed 20131103), {levels}-level "
                             f"coarse-to-fine Gauss-Newton (FirstLevel {first_level} -> LastLevel 0, MaxIter 100, "
-                            f"Precision 5e-7, Mu 0), {B} independent pairs per step per GPU ({args.distinct} distinct current "
-                            f"frames against {len(ref_pyrs)} keyframe(s)), worked through by {T} host threads (one tracker / HIP stream "
-                            f"each) with at most {args.in_flight or 'all'} pairs resident per tracker, pyramids pre-built "
-                            f"and resident in HBM",
+                            f"Precision 5e-7, Mu 0), {B} independent pairs per step per GPU = {distinct_pairs} distinct "
+                            f"(keyframe, frame) combinations of {len(ref_pyrs)} keyframes x {len(curs)} frames "
+                            f"({n_pyramids} pyramids, {pyramid_bytes / 2**20:.0f} MiB resident: "
+                            f"{'beyond' if pyramid_bytes > 256 * 2**20 else 'inside'} the 256 MiB Infinity Cache), worked "
+                            f"through by {T} host threads (one tracker / HIP stream each) with at most "
+                            f"{args.in_flight or 'all'} pairs resident per tracker, pyramids pre-built and resident in HBM, "
+                            f"per-iteration statistics {'delivered' if with_stats else 'dropped'}",
                 "pairs_per_step_per_gpu": B,
+                "distinct_pairs_per_step": distinct_pairs,
+                "pyramids_resident": n_pyramids,
+                "pyramid_working_set_mib": pyramid_bytes / 2**20,
                 "host_threads_per_gpu": T,
                 "host_threads_pinned_to_numa_node": numa,
                 "pairs_in_flight_per_tracker": args.in_flight,
+                "iteration_statistics": "delivered" if with_stats else "dropped",
                 "sharding": "independent pairs per rank, no collective on the data path",
             },
+            "iterations_per_pair": iterations_delivered / max(1, B * args.steps),
             "single_pair_latency_ms": single_ms,
             "prep_ms_per_frame": prep_ms,
             "prep_ms_per_frame_first_use": prep_first_ms,
@@ -230,20 +320,25 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                "achieved_is": "ALGORITHMIC bytes (56 B per selected reference pixel per residual pass, SURVEY.md 8d) / k_tick "
+                               "launch duration; an upper-level view, not the bytes HBM actually moved: see `traffic` and `issue`",
                 "traffic": traffic_from_profiles(),
+                "traffic_source": traffic_source(),
                 "kernel": "k_tick (fused warp+residual+weights+normal equations, with the log-likelihood items of the tick)",
                 "launches": int(k_launches),
                 "avg_launch_us": (k_ms * 1e3 / k_launches) if k_launches else None,
                 "alg_bytes_per_launch": (alg_bytes_k / k_launches) if k_launches else None,
                 "measured": "HIP events stamped by the dispatch itself (hipExtLaunchKernel start / stop) on the launching "
-                            "stream, " + ("inside the timed region" if T == 1 else
-                            "single-stream pass over one host thread's share of the batch, same pairs in flight, right after the timed "
-                            "region (which used %d streams at once)" % T),
+                            "stream, every launch alone on the GPU, " + ("inside the timed region" if T == 1 else
+                            "in a single-stream pass over one host thread's share of the batch, same pairs in flight, right after "
+                            "the timed region (which ran %d streams at once: its launches overlap, so the per-launch figure "
+                            "here is not the concurrent rate)" % T),
                 "residual_passes": int(passes),
+                "issue": issue_roofline(log, k_ms),
             },
         }
         try:
-            ms_i, ab_i, nl_i = trk.bench_residual_pass(ref, curs[0], 0, synth.se3_exp(synth.XI_GT_PAIR * 0.6), 36, 0, reps=20)
+            ms_i, ab_i, nl_i = trk.bench_residual_pass(ref, curs[0], 0, cur_pose(0), 36, 0, reps=20)
             line["roofline_isolated_kernel"] = {
                 "what": "the residual pass alone: level 0, 36 pairs in one launch (one launch's worth of resident pairs)",
                 "achieved": ab_i / ms_i / 1e6, "unit": "GB/s", "frac": ab_i / ms_i / 1e6 / HBM_PEAK_GBS,
@@ -251,14 +346,28 @@ def main():
         except Exception as exc:  # pragma: no cover
             line["roofline_isolated_kernel"] = {"error": str(exc)}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args, ref_frame, cur_frames, K, levels, first_level)
+            line["cpu_baseline"] = cpu_baseline(args, ref_frame, cur_frames[:8], K, levels, first_level)
         if world == 1 and not args.no_extras:
-            for name, fn in (("stream_copy", lambda: stream_copy(device)),
+            def cache_resident():
+                # round 1's workload for comparison: 8 distinct frames against ONE keyframe (9 pyramids, 180 MB: inside the
+                # Infinity Cache, each distinct pair ~4x in every launch, identical reads that L2 dedups)
+                r_l, c_l = [ref] * B, [curs[i % 8] for i in range(B)]
+                run_steps(1, [], r_l, c_l)
+                t0 = time.perf_counter()
+                n = max(2, args.steps // 2)
+                run_steps(n, [], r_l, c_l)
+                dt = time.perf_counter() - t0
+                return {"value": B * n / dt, "unit": "frame-pairs/s", "steps": n,
+                        "what": "the same batch size with 8 distinct frames against 1 keyframe (9 pyramids inside the "
+                                "Infinity Cache, pairs repeated 144x per step): round 1's default workload"}
+            for name, fn in (("cache_resident_workload", cache_resident),
+                             ("no_stats_variant", lambda: stats_variant(run_steps, B, args, with_stats)),
+                             ("stream_copy", lambda: stream_copy(device)),
                              ("ingest", lambda: ingest_timing(capi, synth, cur_frames, K, levels, device)),
                              ("loop_closure_validator", lambda: validator_timing(capi, synth, W, H, device)),
                              ("dual_match_front_end", lambda: dual_match_timing(capi, ref, curs, levels, first_level, device)),
                              ("cpu_baseline_all_cores", lambda: None if args.no_cpu_baseline else
-                              cpu_baseline_threads(args, ref_frame, cur_frames, K, levels, first_level))):
+                              cpu_baseline_threads(args, ref_frame, cur_frames[:8], K, levels, first_level))):
                 try:
                     line[name] = fn()
                 except Exception as exc:  # pragma: no cover - side measurements never fail the bench line
@@ -266,6 +375,43 @@ def main():
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def stats_variant(run_steps, B, args, with_stats):
+    """the timed workload once more with the per-iteration statistics toggled: what delivering them costs"""
+    n = max(2, args.steps // 2)
+    run_steps(1, [], stats=not with_stats)
+    t0 = time.perf_counter()
+    run_steps(n, [], stats=not with_stats)
+    dt = time.perf_counter() - t0
+    return {"value": B * n / dt, "unit": "frame-pairs/s", "steps": n,
+            "iteration_statistics": "dropped" if with_stats else "delivered"}
+
+
+SIMDS = 256 * 4
+PEAK_CLOCK_HZ = 2.4e9
+VALU_ISSUE_CYCLES = 4   # one fp32 VALU wave instruction holds its SIMD for 4 cycles (measured: profiles/r02_issue.json)
+MFMA_ISSUE_CYCLES = 32  # v_mfma_f32_16x16x4_f32 (MI355X_MICROARCH.md); 8 for v_mfma_f32_4x4x1_16B_f32
+
+
+def issue_roofline(log, k_ms):
+    """The bound k_tick actually sits on: VALU + MFMA issue cycles.  Instructions per 64-pixel wave step come from the
+    committed PMC pass of the kernel (profiles/r02_issue.json: SQ_INSTS_VALU / SQ_INSTS_MFMA per step of the residual and of
+    the likelihood pass); the steps are this run's (tick log); peak = every SIMD issuing every cycle at the 2.4 GHz peak clock."""
+    try:
+        here = os.path.dirname(os.path.abspath(__file__))
+        c = json.load(open(os.path.join(here, "profiles", "r02_issue.json")))
+        res_steps, ll_steps = float(log[:, 6].sum()), float(log[:, 7].sum())
+        mfma_cyc = c.get("mfma_issue_cycles", MFMA_ISSUE_CYCLES)
+        cyc = (res_steps * (c["valu_per_res_step"] * VALU_ISSUE_CYCLES + c["mfma_per_res_step"] * mfma_cyc)
+               + ll_steps * c["valu_per_ll_step"] * VALU_ISSUE_CYCLES)
+        peak = SIMDS * PEAK_CLOCK_HZ * k_ms * 1e-3
+        return {"bound": "VALU+MFMA issue", "valu_per_res_step": c["valu_per_res_step"], "mfma_per_res_step": c["mfma_per_res_step"],
+                "valu_per_ll_step": c["valu_per_ll_step"], "valu_issue_cycles": VALU_ISSUE_CYCLES, "mfma_issue_cycles": mfma_cyc,
+                "res_steps": res_steps, "ll_steps": ll_steps, "issue_cycles": cyc, "peak_cycles": peak, "frac": cyc / peak,
+                "source": c.get("source")}
+    except Exception as exc:
+        return {"error": repr(exc)}
 
 
 def tile_shard_bench(args, capi, synth, sharding, dist, rank, world, device, ref_frame, cur_frames, K, levels, first_level):
@@ -345,13 +491,26 @@ def pin_to_gpu_numa_node(device):
     return None
 
 
+TRAFFIC_FILE = "r02_traffic.json"
+
+
 def traffic_from_profiles():
-    """HBM-side bytes per k_tick launch from the committed PMC passes (profiles/r01_traffic.json: rocprofv3 --pmc FETCH_SIZE
-    and WRITE_SIZE in separate runs of this command, gfx950 correction applied); counters cannot be read from inside the
-    bench, so this is the figure of the profiled run, not of this one."""
+    """HBM-side bytes per k_tick launch from the committed PMC passes (profiles/r02_traffic.json: rocprofv3 --pmc FETCH_SIZE
+    and WRITE_SIZE in separate runs of the default command, gfx950 correction applied); counters cannot be read from inside
+    the bench, so this is the figure of the profiled run (see traffic_source), not of this one."""
     try:
         here = os.path.dirname(os.path.abspath(__file__))
-        return json.load(open(os.path.join(here, "profiles", "r01_traffic.json")))["traffic_bytes_per_launch"]
+        return json.load(open(os.path.join(here, "profiles", TRAFFIC_FILE)))["traffic_bytes_per_launch"]
+    except Exception:
+        return None
+
+
+def traffic_source():
+    try:
+        here = os.path.dirname(os.path.abspath(__file__))
+        d = json.load(open(os.path.join(here, "profiles", TRAFFIC_FILE)))
+        return {"file": "profiles/" + TRAFFIC_FILE, "command": d.get("command"), "alg_bytes_per_launch_of_that_run":
+                d.get("alg_bytes_per_launch"), "pairs_per_s_under_pmc": d.get("bench_value_under_pmc")}
     except Exception:
         return None
 
@@ -462,6 +621,7 @@ def cpu_baseline_threads(args, ref_frame, cur_frames, K, levels, first_level):
 
     from oracle import oracle as orc
 
+    orc.select_build("native")  # -O3 -march=native, the reference's flags (dvo_core/CMakeLists.txt:38-40)
     n_threads = min(os.cpu_count() or 1, 64)
     try:
         n_threads = min(n_threads, len(os.sched_getaffinity(0)))
@@ -487,6 +647,8 @@ def cpu_baseline_threads(args, ref_frame, cur_frames, K, levels, first_level):
     for x in th:
         x.join()
     dt = time.perf_counter() - t0
+    del pr, pcs
+    orc.select_build("parity")
     return {"value": sum(counts) / dt, "unit": "frame-pairs/s", "cores": n_threads, "kind": "port",
             "sample": f"{sum(counts)} match() calls in {dt:.1f} s, {n_threads} threads, one oracle tracker each, shared pyramids"}
 
@@ -496,6 +658,7 @@ def cpu_baseline(args, ref_frame, cur_frames, K, levels, first_level):
     on this host over a bounded sample of the same pairs; match() only, pyramids pre-built."""
     from oracle import oracle as orc
 
+    orc.select_build("native")  # -O3 -march=native, the reference's flags (dvo_core/CMakeLists.txt:38-40)
     pr = orc.Pyramid(ref_frame[0], ref_frame[1], K, levels)
     pcs = [orc.Pyramid(f[0], f[1], K, levels) for f in cur_frames]
     cfg = orc.default_config(first_level=first_level, last_level=0, rcp_mode=orc.RCP_SSE)
@@ -514,9 +677,13 @@ def cpu_baseline(args, ref_frame, cur_frames, K, levels, first_level):
                 break
     except OSError:
         pass
+    n_pairs = len(pcs)
+    del pr, pcs
+    orc.select_build("parity")
     return {"value": n / dt, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
-            "sample": f"{n} match() calls over the same {len(pcs)} synthetic pairs in {dt:.1f} s, single thread, "
-                      f"oracle/dvo_oracle.c (restated reference SSE path, -O3 -msse3), pyramids pre-built",
+            "sample": f"{n} match() calls over {n_pairs} of the synthetic pairs in {dt:.1f} s, single thread, "
+                      f"oracle/dvo_oracle.c (restated reference SSE path with _mm_rcp_ps) built with the reference's flags "
+                      f"-O3 -march=native -msse3 on this host, pyramids pre-built",
             "host_cpu": model, "host_cores": os.cpu_count()}
 
 

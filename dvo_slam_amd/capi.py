@@ -31,7 +31,7 @@ EXPORTS = [
     "dvo_amd_match_sharded", "dvo_amd_match_banded", "dvo_amd_debug_combine_bands", "dvo_amd_pyramid_create_raw",
     "dvo_amd_default_validator_stages", "dvo_amd_proposals_for_candidates", "dvo_amd_validate_proposals",
     "dvo_amd_track_frame", "dvo_amd_png_info", "dvo_amd_png_read_bgr8", "dvo_amd_png_read_gray16",
-    "dvo_amd_format_trajectory_line", "dvo_amd_debug_tick_log",
+    "dvo_amd_format_trajectory_line", "dvo_amd_debug_tick_log", "dvo_amd_debug_iteration",
 ]
 
 
@@ -66,6 +66,13 @@ class CFrameCriteria(C.Structure):
                 ("keyframe_translation_norm", C.c_double), ("keyframe_constraint_ratio", C.c_double),
                 ("odometry_neg_loglik", C.c_double), ("keyframe_neg_loglik", C.c_double),
                 ("odometry_condition_number", C.c_double), ("keyframe_condition_number", C.c_double)]
+
+
+class CIterationProbe(C.Structure):
+    _fields_ = [("valid_constraints", C.c_int), ("reserved", C.c_int), ("scale_sums", C.c_double * 3),
+                ("scale", C.c_float * 4), ("precision", C.c_float * 4), ("moments", C.c_double * 87),
+                ("information", C.c_double * 36), ("rhs", C.c_double * 6), ("loglik_sum", C.c_double),
+                ("loglik", C.c_float), ("reserved_f", C.c_float)]
 
 
 class DvoAmdError(RuntimeError):
@@ -136,6 +143,7 @@ def lib():
     L.dvo_amd_match_many.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), dp, C.POINTER(CResult), C.c_int]
     L.dvo_amd_residuals.argtypes = [vp, vp, vp, C.c_int, fp, fp, C.POINTER(C.c_int)]
     L.dvo_amd_error_image.argtypes = [vp, vp, vp, dp, C.c_int, fp]
+    L.dvo_amd_debug_iteration.argtypes = [vp, vp, vp, C.c_int, fp, fp, C.POINTER(CIterationProbe)]
     L.dvo_amd_kernel_timing.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_longlong), C.c_int]
     L.dvo_amd_bench_residual_pass.argtypes = [vp, vp, vp, C.c_int, fp, C.c_int, C.c_int, C.c_int, dp, dp,
                                               C.POINTER(C.c_int)]
@@ -372,13 +380,21 @@ class DenseTracker:
         _check(lib().dvo_amd_match(self._h, reference._h, current._h, T0, C.byref(res[0])), "dvo_amd_match")
         return Result(res[0], its[0])
 
-    def match_batch(self, references, currents, T_inits=None, stats: bool = True, in_flight: int = 0, raw: bool = False):
+    def alloc_results(self, n):
+        """(result structs, per-iteration statistics arrays) for n pairs, reusable across match_batch(results=...) calls"""
+        return self._alloc_results(n)
+
+    def match_batch(self, references, currents, T_inits=None, stats: bool = True, in_flight: int = 0, raw: bool = False,
+                    results=None):
         """n independent match() calls on this tracker's GPU.  in_flight = 0: all advanced in lock step; otherwise at most
         in_flight pairs are resident and a finished pair hands its slot to the next one.  raw=True returns the array of C
-        result structs as the library filled them (no per-pair Python objects: for throughput loops)."""
+        result structs as the library filled them (no per-pair Python objects: for throughput loops).  results: a pair from
+        alloc_results(n) to fill (per-iteration statistics included) instead of allocating new ones."""
         n = len(references)
         assert len(currents) == n
-        if stats:
+        if results is not None:
+            res, its = results
+        elif stats:
             res, its = self._alloc_results(n)
         else:
             res, its = (CResult * n)(), [None] * n
@@ -447,6 +463,20 @@ class DenseTracker:
                "dvo_amd_residuals")
         return out, n.value
 
+    def iteration_probe(self, reference: RgbdImagePyramid, current: RgbdImagePyramid, level: int, T, precision_in=None):
+        """One Gauss-Newton iteration body at the fixed pose T (dense_tracking.cpp:271-347 minus accept test and solve)
+        through the kernels and host arithmetic match() uses: unit weights when precision_in is None, else t-distribution
+        weights from the 2x2 precision_in.  Returns dict(n, scale, precision, ll, A, b, moments, scale_sums)."""
+        Tf = np.ascontiguousarray(np.asarray(T, dtype=np.float64).astype(np.float32).T)
+        pin = None if precision_in is None else np.ascontiguousarray(np.asarray(precision_in, np.float32).T).ravel()
+        pr = CIterationProbe()
+        _check(lib().dvo_amd_debug_iteration(self._h, reference._h, current._h, level, _fp(Tf),
+                                             None if pin is None else _fp(pin), C.byref(pr)), "dvo_amd_debug_iteration")
+        return {"n": pr.valid_constraints, "scale": np.array(pr.scale[:], np.float32).reshape(2, 2).T.copy(),
+                "precision": np.array(pr.precision[:], np.float32).reshape(2, 2).T.copy(), "ll": float(pr.loglik),
+                "A": np.array(pr.information[:]).reshape(6, 6).T.copy(), "b": np.array(pr.rhs[:]),
+                "moments": np.array(pr.moments[:]), "scale_sums": np.array(pr.scale_sums[:]), "ll_sum": pr.loglik_sum}
+
     def computeIntensityErrorImage(self, reference, current, T, level: int = 0) -> np.ndarray:
         w, h, _ = reference.level_info(level)
         out = np.empty((h, w), np.float32)
@@ -464,12 +494,13 @@ class DenseTracker:
         return ms.value, ab.value, nl.value
 
     def tick_log(self) -> np.ndarray:
-        """Per-launch log of the timed k_tick launches: rows {ms, items, residual blocks, likelihood blocks, grid.x, px}."""
+        """Per-launch log of the timed k_tick launches: rows {ms, items, residual blocks, likelihood blocks, grid.x, px,
+        64-pixel wave steps of the residual items, 64-pixel wave steps of the likelihood items}."""
         n = C.c_int()
         L = lib()
         L.dvo_amd_debug_tick_log.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]
         _check(L.dvo_amd_debug_tick_log(self._h, None, 0, C.byref(n)), "tick_log")
-        out = np.zeros((max(n.value, 1), 6))
+        out = np.zeros((max(n.value, 1), 8))
         _check(L.dvo_amd_debug_tick_log(self._h, out.ctypes.data_as(C.POINTER(C.c_double)), n.value, C.byref(n)), "tick_log")
         return out[: n.value]
 

@@ -47,6 +47,7 @@ int fail_hip(const char *what, hipError_t e) {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+constexpr size_t kTickLogFields = 8;  // doubles per logged launch (dvo_amd_debug_tick_log)
 constexpr int kMaxTickStreams = 8;  // streams a context spreads the launches / pair groups of its ticks over
 
 // ---- per-device shared state: a prep stream and a pool of pyramid slabs ------------------------------------------
@@ -407,7 +408,7 @@ struct dvo_amd_context {
   bool timing = false;
   double timing_ms = 0.0;
   long long timing_launches = 0;
-  std::vector<double> tick_log;  // timing mode: per launch {ms, items, residual blocks, likelihood blocks, grid.x, selected px}
+  std::vector<double> tick_log;  // timing mode: per launch kTickLogFields doubles, see dvo_amd_debug_tick_log
   std::vector<double> tick_log_pending;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   size_t events_used = 0;
@@ -599,6 +600,40 @@ int blocks_for(int n, int rounds) {
   return (n + px_per_block - 1) / px_per_block;
 }
 
+// computeScaleSse's 1/(n-2-1) and the 2x2 inverse (dense_tracking.cpp:295); S holds the unscaled pair sums
+void scale_and_precision(const FinOut &o, int n, float cov[4], float P[4]) {
+  const float scale = 1.0f / (float)(size_t)(n - 2 - 1);
+  cov[0] = (float)(o.S[0] * (double)scale);
+  cov[1] = cov[2] = (float)(o.S[1] * (double)scale);
+  cov[3] = (float)(o.S[2] * (double)scale);
+  inverse2x2f(cov, P);
+}
+
+// A = sum w J^T P J, b = -sum w J^T P r from the P-free moments; + Mu terms (dense_tracking.cpp:341-346)
+void system_from_moments(const FinOut &o, const float P[4], double mu, const double xi_initial[6], double A[36], double b[6]) {
+  const double p00 = P[0], p10 = P[1], p01 = P[2], p11 = P[3];
+  const double pab = 0.5 * (p01 + p10);
+  int t = 0;
+  for (int r = 0; r < 6; ++r)
+    for (int c = r; c < 6; ++c, ++t) {
+      const double v = p00 * o.acc[kAccAA + t] + pab * o.acc[kAccAB + t] + p11 * o.acc[kAccBB + t];
+      A[c * 6 + r] = v;
+      A[r * 6 + c] = v;
+    }
+  for (int i = 0; i < 6; ++i) {
+    A[i * 6 + i] += mu;
+    const double bi = -(p00 * o.acc[kAccAR0 + i] + p10 * o.acc[kAccBR0 + i] + p01 * o.acc[kAccAR1 + i] +
+                        p11 * o.acc[kAccBR1 + i]);
+    b[i] = bi + mu * xi_initial[i];
+  }
+}
+
+// computeCompleteDataLogLikelihood's last line, dense_tracking_impl.cpp:424
+float loglik_from_sum(int n, const float P[4], double ll_sum) {
+  const float det = P[0] * P[3] - P[1] * P[2];
+  return (float)(0.5 * (double)(size_t)n * (double)std::log(det) - 0.5 * (5.0 + 2.0) * ll_sum);
+}
+
 // the residual pass of iteration `it` came back: dense_tracking.cpp:273-347 minus the likelihood test
 void process_residual(Job &j, IterCtx &it, const FinOut &o) {
   dvo_amd_iteration_stats *e = stats_push(j);
@@ -615,12 +650,7 @@ void process_residual(Job &j, IterCtx &it, const FinOut &o) {
     end_level(j);
     return;
   }
-  // computeScaleSse's 1/(n-2-1) and the 2x2 inverse (:295); S holds the unscaled pair sums
-  const float scale = 1.0f / (float)(size_t)(it.n - 2 - 1);
-  it.cov[0] = (float)(o.S[0] * (double)scale);
-  it.cov[1] = it.cov[2] = (float)(o.S[1] * (double)scale);
-  it.cov[3] = (float)(o.S[2] * (double)scale);
-  inverse2x2f(it.cov, it.P);
+  scale_and_precision(o, it.n, it.cov, it.P);
   std::memcpy(j.precision, it.P, sizeof(it.P));
 
   double xi_initial[6];
@@ -629,22 +659,7 @@ void process_residual(Job &j, IterCtx &it, const FinOut &o) {
   for (int i = 0; i < 6; ++i) sq += xi_initial[i] * xi_initial[i];
   it.prior = j.cfg->mu * sq;  // :302
 
-  // A = sum w J^T P J, b = -sum w J^T P r from the P-free moments; + Mu terms (:345-346)
-  const double p00 = it.P[0], p10 = it.P[1], p01 = it.P[2], p11 = it.P[3];
-  const double pab = 0.5 * (p01 + p10);
-  int t = 0;
-  for (int r = 0; r < 6; ++r)
-    for (int c = r; c < 6; ++c, ++t) {
-      const double v = p00 * o.acc[kAccAA + t] + pab * o.acc[kAccAB + t] + p11 * o.acc[kAccBB + t];
-      it.A[c * 6 + r] = v;
-      it.A[r * 6 + c] = v;
-    }
-  for (int i = 0; i < 6; ++i) {
-    it.A[i * 6 + i] += j.cfg->mu;
-    const double bi = -(p00 * o.acc[kAccAR0 + i] + p10 * o.acc[kAccBR0 + i] + p01 * o.acc[kAccAR1 + i] +
-                        p11 * o.acc[kAccBR1 + i]);
-    it.b[i] = bi + j.cfg->mu * xi_initial[i];
-  }
+  system_from_moments(o, it.P, j.cfg->mu, xi_initial, it.A, it.b);
   solve_ldlt6(it.A, it.b, it.x_new);  // :347
   it.cont = inf_norm6(it.x_new) > j.cfg->precision && !(it.k + 1 >= j.cfg->max_iterations_per_level);
 
@@ -666,9 +681,7 @@ void process_residual(Job &j, IterCtx &it, const FinOut &o) {
 void process_loglik(Job &j, const FinOut *outs) {
   IterCtx &a = j.a;
   const FinOut &o = outs[0];
-  const float det = a.P[0] * a.P[3] - a.P[1] * a.P[2];
-  // computeCompleteDataLogLikelihood, dense_tracking_impl.cpp:424
-  const float ll = (float)(0.5 * (double)(size_t)a.n * (double)std::log(det) - 0.5 * (5.0 + 2.0) * o.ll_sum);
+  const float ll = loglik_from_sum(a.n, a.P, o.ll_sum);
   dvo_amd_iteration_stats *e = &j.recent[j.recent_count - 1];
   e->tdist_loglik = -(double)ll;
   e->tdist_mean[0] = e->tdist_mean[1] = 0.0;
@@ -820,9 +833,9 @@ int timing_collect(dvo_amd_context *ctx) {
     HIP_TRY(hipEventElapsedTime(&ms, ctx->events[i].first, ctx->events[i].second));
     ctx->timing_ms += ms;
     ctx->timing_launches++;
-    if (6 * i + 5 < ctx->tick_log_pending.size() && ctx->tick_log.size() < 6 * 65536) {
+    if (kTickLogFields * (i + 1) <= ctx->tick_log_pending.size() && ctx->tick_log.size() < (size_t)kTickLogFields * 65536) {
       ctx->tick_log.push_back((double)ms);
-      for (int k = 1; k < 6; ++k) ctx->tick_log.push_back(ctx->tick_log_pending[6 * i + k]);
+      for (size_t k = 1; k < kTickLogFields; ++k) ctx->tick_log.push_back(ctx->tick_log_pending[kTickLogFields * i + k]);
     }
   }
   ctx->tick_log_pending.clear();
@@ -1019,16 +1032,20 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
     if (ctx->timing) {
       int rc = timing_begin(ctx, &ev);
       if (rc) return rc;
-      double rb = 0, lb = 0, px = 0;
-      for (int i = 0; i < n_here; ++i) rb += stage[i].res_blocks, lb += stage[i].ll_blocks;
+      double rb = 0, lb = 0, px = 0, res_steps = 0, ll_steps = 0;
+      for (int i = 0; i < n_here; ++i) {
+        rb += stage[i].res_blocks, lb += stage[i].ll_blocks;
+        res_steps += (double)stage[i].res_blocks * kWavesPerBlock * kPxPerLane * item_res_rounds(stage[i]);
+        ll_steps += (double)stage[i].ll_blocks * kWavesPerBlock * kPxPerLane * item_ll_rounds(stage[i]);
+      }
       for (size_t ji = grp.lo, k = 0; ji < grp.hi; ++ji) {
         const Job &j = jobs[ji];
         if (j.done || !(j.sub_ll || j.sub_res)) continue;
         if (k >= first && k < first + (size_t)n_here && j.sub_res) px += j.sub_px;
         ++k;
       }
-      const double rec[6] = {0.0, (double)n_here, rb, lb, (double)max_blocks, px};
-      ctx->tick_log_pending.insert(ctx->tick_log_pending.end(), rec, rec + 6);
+      const double rec[kTickLogFields] = {0.0, (double)n_here, rb, lb, (double)max_blocks, px, res_steps, ll_steps};
+      ctx->tick_log_pending.insert(ctx->tick_log_pending.end(), rec, rec + kTickLogFields);
     }
     hipEvent_t t0 = ctx->timing ? ctx->events[ev].first : nullptr, t1 = ctx->timing ? ctx->events[ev].second : nullptr;
     hipError_t e = use_table ? launch_tick_table(ctx->item_dev + stream_slot * kMaxTableItems, n_here, max_blocks, st, t0, t1)
@@ -1679,59 +1696,126 @@ int dvo_amd_match(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyra
   return dvo_amd_match_batch(ctx, 1, r, c, T_init, result);
 }
 
-int dvo_amd_residuals(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, int level, const float *T,
-                      float *residuals, int *n_valid) {
-  if (!ctx || !reference || !current || !T || level < 0) return DVO_AMD_ERR_INVALID_ARGUMENT;
-  if (level >= reference->n_levels || level >= current->n_levels) return DVO_AMD_ERR_TOO_FEW_LEVELS;
-  if (reference->device != ctx->device || current->device != ctx->device) return DVO_AMD_ERR_DEVICE_MISMATCH;
+namespace {
+// One k_tick + k_finalize over slot 0 outside the match driver (the stage-wise parity entries): optionally the residual pass
+// at the float transform T (into residual buffer 0) and / or the log-likelihood pass over residual buffer 0.
+int single_tick(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, int level, int sel, const float *T,
+                const float P[4], bool unit_weights, bool residual_pass, bool loglik_pass, int ll_cut_rank) {
   const LevelData &R = reference->lv[level];
   const LevelData &C = current->lv[level];
-  if (R.w != C.w || R.h != C.h) return DVO_AMD_ERR_INVALID_ARGUMENT;
-  HIP_TRY(hipSetDevice(ctx->device));
-  int sel = 0;
-  int rc = pyramid_selection(reference, ctx->cfg.intensity_derivative_threshold, ctx->cfg.depth_derivative_threshold, &sel);
-  if (rc) return rc;
-  rc = ensure_slots(ctx, 1, R.n_pad);
-  if (rc) return rc;
   JobSlot &s = ctx->slots[0];
   TickArgs ta;
   std::memset(&ta, 0, sizeof(ta));
   ta.n_items = 1;
   TickItem &w = ta.items[0];
-  w.ref = reference->selections[sel].ref_desc + level;
+  {
+    std::lock_guard<std::mutex> lk(reference->mu);
+    w.ref = reference->selections[(size_t)sel].ref_desc + level;
+  }
   w.cur = current->cur_desc + level;
   w.slot = ctx->slot_desc;
-  int res_rounds = 1;
-  while (res_rounds < kMaxRounds && blocks_for(R.n, res_rounds) > 2048) res_rounds *= 2;
-  item_set_rounds(w, res_rounds, 1);
-  w.res_blocks = (uint16_t)blocks_for(R.n, res_rounds);
-  w.res_phys = w.res_blocks;
-  w.flags = kItemUnitWeights;
-  const float K[9] = {C.fx, 0.0f, C.ox, 0.0f, C.fy, C.oy, 0.0f, 0.0f, 1.0f};
-  for (int i = 0; i < 3; ++i)
-    for (int c = 0; c < 4; ++c)
-      w.kt[i * 4 + c] = (K[i * 3 + 0] * T[c * 4 + 0] + K[i * 3 + 1] * T[c * 4 + 1]) + K[i * 3 + 2] * T[c * 4 + 2];
-  hipError_t e = launch_tick(ta, w.res_blocks, ctx->stream);
-  if (e != hipSuccess) return fail_hip("launch_tick", e);
+  int rounds = 1;
+  while (rounds < kMaxRounds && blocks_for(R.n, rounds) > 2048) rounds *= 2;
+  item_set_rounds(w, rounds, rounds);
+  const int nb = blocks_for(R.n, rounds);
+  if (unit_weights) w.flags |= kItemUnitWeights;
+  if (P) std::memcpy(w.P, P, sizeof(w.P));
   FinArgs fa;
+  std::memset(&fa, 0, sizeof(fa));
   fa.n_items = 1;
-  fa.items[0].records = s.records;
-  fa.items[0].n_blocks = w.res_blocks;
-  fa.items[0].n_ll_blocks = 0;
-  fa.items[0].ll_partials = s.ll_partials;
-  fa.items[0].seg_prefix_out = s.seg_prefix[0];
-  fa.items[0].block_first = 0, fa.items[0].ll_first = 0;
-  fa.items[0].out = s.out;
-  fa.items[0].out_dev = nullptr;
+  FinItem &f = fa.items[0];
+  f.ll_partials = s.ll_partials;
+  f.seg_prefix_out = s.seg_prefix[0];
+  f.out = s.out;
+  f.out_dev = nullptr;
   fa.ticket = ctx->tickets;
-  fa.items[0].seq = ++ctx->tick_seq;
-  fa.items[0].pad = 0;
+  f.seq = ++ctx->tick_seq;
+  if (residual_pass) {
+    w.res_blocks = (uint16_t)nb;
+    w.res_phys = w.res_blocks;
+    const float K[9] = {C.fx, 0.0f, C.ox, 0.0f, C.fy, C.oy, 0.0f, 0.0f, 1.0f};
+    for (int i = 0; i < 3; ++i)
+      for (int c = 0; c < 4; ++c)
+        w.kt[i * 4 + c] = (K[i * 3 + 0] * T[c * 4 + 0] + K[i * 3 + 1] * T[c * 4 + 1]) + K[i * 3 + 2] * T[c * 4 + 2];
+    f.records = s.records;
+    f.n_blocks = nb;
+  }
+  if (loglik_pass) {
+    w.ll_blocks = (uint16_t)nb;
+    w.ll_cut_rank = ll_cut_rank;
+    f.n_ll_blocks = nb;
+  }
+  hipError_t e = launch_tick(ta, (int)w.res_blocks + (int)w.ll_blocks, ctx->stream);
+  if (e != hipSuccess) return fail_hip("launch_tick", e);
   e = launch_finalize(fa, ctx->stream);
   if (e != hipSuccess) return fail_hip("launch_finalize", e);
+  return DVO_AMD_OK;
+}
+
+int check_level_pair(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, int level) {
+  if (level >= reference->n_levels || level >= current->n_levels) return DVO_AMD_ERR_TOO_FEW_LEVELS;
+  if (reference->device != ctx->device || current->device != ctx->device) return DVO_AMD_ERR_DEVICE_MISMATCH;
+  if (reference->lv[level].w != current->lv[level].w || reference->lv[level].h != current->lv[level].h)
+    return DVO_AMD_ERR_INVALID_ARGUMENT;
+  return DVO_AMD_OK;
+}
+}  // namespace
+
+int dvo_amd_residuals(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, int level, const float *T,
+                      float *residuals, int *n_valid) {
+  if (!ctx || !reference || !current || !T || level < 0) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  int rc = check_level_pair(ctx, reference, current, level);
+  if (rc) return rc;
+  const LevelData &R = reference->lv[level];
+  HIP_TRY(hipSetDevice(ctx->device));
+  int sel = 0;
+  rc = pyramid_selection(reference, ctx->cfg.intensity_derivative_threshold, ctx->cfg.depth_derivative_threshold, &sel);
+  if (rc) return rc;
+  rc = ensure_slots(ctx, 1, R.n_pad);
+  if (rc) return rc;
+  rc = single_tick(ctx, reference, current, level, sel, T, nullptr, true, true, false, 0);
+  if (rc) return rc;
   if (residuals)
-    HIP_TRY(hipMemcpyAsync(residuals, s.res[0], sizeof(float2) * R.n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(residuals, ctx->slots[0].res[0], sizeof(float2) * R.n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   if (n_valid) *n_valid = ctx->out_host[0].valid;
+  return DVO_AMD_OK;
+}
+
+int dvo_amd_debug_iteration(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, int level,
+                            const float *T, const float *precision_in, dvo_amd_iteration_probe *out) {
+  if (!ctx || !reference || !current || !T || !out || level < 0) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  int rc = check_level_pair(ctx, reference, current, level);
+  if (rc) return rc;
+  const LevelData &R = reference->lv[level];
+  HIP_TRY(hipSetDevice(ctx->device));
+  int sel = 0;
+  rc = pyramid_selection(reference, ctx->cfg.intensity_derivative_threshold, ctx->cfg.depth_derivative_threshold, &sel);
+  if (rc) return rc;
+  rc = ensure_slots(ctx, 1, R.n_pad);
+  if (rc) return rc;
+  std::memset(out, 0, sizeof(*out));
+  // tick 1: residuals, weights (unit, or from precision_in), pair-quirk scale sums, the 87 moments
+  rc = single_tick(ctx, reference, current, level, sel, T, precision_in, precision_in == nullptr, true, false, 0);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const FinOut o = ctx->out_host[0];
+  out->valid_constraints = o.valid;
+  for (int i = 0; i < 3; ++i) out->scale_sums[i] = o.S[i];
+  for (int i = 0; i < kNumAcc; ++i) out->moments[i] = o.acc[i];
+  if (o.valid < 6) return DVO_AMD_OK;  // dense_tracking.cpp:276-284
+  float cov[4], P[4];
+  scale_and_precision(o, o.valid, cov, P);
+  std::memcpy(out->scale, cov, sizeof(cov));
+  std::memcpy(out->precision, P, sizeof(P));
+  const double zero6[6] = {0, 0, 0, 0, 0, 0};
+  system_from_moments(o, P, 0.0, zero6, out->information, out->rhs);
+  // tick 2: the log-likelihood of the same residuals under the new precision, cut at 50 * floor(V / 50) (Q6)
+  rc = single_tick(ctx, reference, current, level, sel, T, P, false, false, true, 50 * (o.valid / 50));
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  out->loglik_sum = ctx->out_host[0].ll_sum;
+  out->loglik = loglik_from_sum(o.valid, P, out->loglik_sum);
   return DVO_AMD_OK;
 }
 
@@ -1833,10 +1917,10 @@ void dvo_amd_solve6(const double *A, const double *b, double *x) { solve_ldlt6(A
 
 int dvo_amd_debug_tick_log(dvo_amd_context *ctx, double *out, int capacity_records, int *n_records) {
   if (!ctx || !n_records) return DVO_AMD_ERR_INVALID_ARGUMENT;
-  const int n = (int)(ctx->tick_log.size() / 6);
+  const int n = (int)(ctx->tick_log.size() / kTickLogFields);
   *n_records = n;
   if (out) {
-    for (int i = 0; i < std::min(n, capacity_records) * 6; ++i) out[i] = ctx->tick_log[(size_t)i];
+    for (int i = 0; i < std::min(n, capacity_records) * (int)kTickLogFields; ++i) out[i] = ctx->tick_log[(size_t)i];
     ctx->tick_log.clear();
   }
   return DVO_AMD_OK;

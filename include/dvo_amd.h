@@ -324,6 +324,27 @@ int dvo_amd_format_trajectory_line(double timestamp, const double *T, char *buf,
  * selected or its warp is invalid.  Used by the parity tests and by dvo_amd_error_image. */
 int dvo_amd_residuals(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, int level,
                       const float *T, float *residuals, int *n_valid);
+/* Stage-wise probe of ONE Gauss-Newton iteration body at a fixed pose (dense_tracking.cpp:271-347 without the accept test and
+ * the solve): computeResidualsSse, computeWeightsSse (unit weights when precision_in is NULL = first iteration of a level,
+ * else the t-distribution weights of the column-major 2x2 precision_in), computeScaleSse + inverse, the normal equations
+ * (Mu = 0) and computeCompleteDataLogLikelihood, through exactly the kernels and host arithmetic dvo_amd_match uses (two
+ * ticks).  Exists so that the parity tests can compare the weighted stages (iterations k >= 1) with their CPU checker directly
+ * instead of only through the final pose. */
+typedef struct {
+  int valid_constraints;
+  int reserved;
+  double scale_sums[3];   /* unscaled pair sums (xx, xy, yy) of computeScaleSse incl. the Q5 pairing */
+  float scale[4];         /* column-major 2x2: sums / (V - 3) */
+  float precision[4];     /* its inverse (Eigen Matrix2f::inverse) */
+  double moments[87];     /* the P-free sums (layout: dvo_types.h kAcc*) */
+  double information[36]; /* A = sum w J^T P J, column-major 6x6 */
+  double rhs[6];          /* b = -sum w J^T P r */
+  double loglik_sum;      /* sum of log(1 + 0.2 r^T P r) over the first 50 floor(V/50) valid residuals (Q6) */
+  float loglik;           /* what computeCompleteDataLogLikelihood returns */
+  float reserved_f;
+} dvo_amd_iteration_probe;
+int dvo_amd_debug_iteration(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, int level,
+                            const float *T, const float *precision_in, dvo_amd_iteration_probe *out);
 /* DenseTracker::computeIntensityErrorImage, dense_tracking.cpp:378-444: |intensity residual| per reference pixel, 0 elsewhere */
 int dvo_amd_error_image(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, const double *T,
                         int level, float *image);
@@ -341,9 +362,9 @@ int dvo_amd_bench_residual_pass(dvo_amd_context *ctx, dvo_amd_pyramid *reference
  * (block 0 of the most recent launch); this reads them back. */
 int dvo_amd_debug_finalize_stamps(dvo_amd_context *ctx, unsigned long long *stamps8);
 
-/* Diagnostic: while dvo_amd_kernel_timing is enabled every k_tick launch is logged as 6 doubles {ms, items, residual-pass
- * blocks, likelihood blocks, grid.x, selected reference pixels of the residual items}; this reads and clears the log
- * (out may be NULL to query the count). */
+/* Diagnostic: while dvo_amd_kernel_timing is enabled every k_tick launch is logged as 8 doubles {ms, items, residual-pass
+ * blocks, likelihood blocks, grid.x, selected reference pixels of the residual items, 64-pixel wave steps of the residual
+ * items, 64-pixel wave steps of the likelihood items}; this reads and clears the log (out may be NULL to query the count). */
 int dvo_amd_debug_tick_log(dvo_amd_context *ctx, double *out, int capacity_records, int *n_records);
 
 /* Host-side helpers (no GPU needed): the SE(3) exponential / logarithm with Sophus' tangent order (upsilon, omega) and the

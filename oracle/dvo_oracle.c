@@ -588,6 +588,28 @@ void orc_rank_update(const float *J, const float *alpha, int n, float *A36) {
   packed_to_dense(acc, A36);
 }
 
+/* the point loop of dense_tracking.cpp:327-342: ls.update(J, residual, weight * precision) for every valid point, i.e.
+ * A += J^T (w P) J through the packed accumulator (math_sse.cpp:82-178) and b -= (J^T (w P)) r (least_squares.cpp:58-64),
+ * sequential fp32 accumulation in scan order */
+static void normal_equations(const orc_record *points_error, int n, const float *weights, const float precision[4],
+                             float acc[24], float bvec[6]) {
+  memset(acc, 0, 24 * sizeof(float));
+  memset(bvec, 0, 6 * sizeof(float));
+  for (int i = 0; i < n; ++i) {
+    float J[12], W[4];
+    point_jacobian(points_error + i, J);
+    for (int k = 0; k < 4; ++k) W[k] = weights[i] * precision[k];
+    rank_update_2x6(acc, J, W);
+    /* b -= (J^T * W) * r, least_squares.cpp:58-64 */
+    const float r0 = points_error[i].e[0], r1 = points_error[i].e[1];
+    for (int k = 0; k < 6; ++k) {
+      const float t0 = J[2 * k] * W[0] + J[2 * k + 1] * W[1];
+      const float t1 = J[2 * k] * W[2] + J[2 * k + 1] * W[3];
+      bvec[k] -= t0 * r0 + t1 * r1;
+    }
+  }
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* SE(3) in double: Sophus SE3d (unit quaternion + translation), tangent order (upsilon, omega) */
 /* ------------------------------------------------------------------------------------------ */
@@ -960,6 +982,7 @@ int orc_match(const orc_config *cfg, orc_pyramid *ref, orc_pyramid *cur, const d
       float Tf[16];
       se3_to_matrix(&estimate, Td);
       for (int i = 0; i < 16; ++i) Tf[i] = (float)Td[i];
+      memcpy(it->estimate, Td, sizeof(Td));
 
       wa.first = R->sel;
       wa.n_sel = R->n_sel;
@@ -1013,21 +1036,7 @@ int orc_match(const orc_config *cfg, orc_pyramid *ref, orc_pyramid *cur, const d
 
       /* :327-347 normal equations */
       float acc[24], bvec[6];
-      memset(acc, 0, sizeof(acc));
-      memset(bvec, 0, sizeof(bvec));
-      for (int i = 0; i < n; ++i) {
-        float J[12], W[4];
-        point_jacobian(points_error + i, J);
-        for (int k = 0; k < 4; ++k) W[k] = weights[i] * precision[k];
-        rank_update_2x6(acc, J, W);
-        /* b -= (J^T * W) * r, least_squares.cpp:58-64 */
-        const float r0 = points_error[i].e[0], r1 = points_error[i].e[1];
-        for (int k = 0; k < 6; ++k) {
-          const float t0 = J[2 * k] * W[0] + J[2 * k + 1] * W[1];
-          const float t1 = J[2 * k] * W[2] + J[2 * k + 1] * W[3];
-          bvec[k] -= t0 * r0 + t1 * r1;
-        }
-      }
+      normal_equations(points_error, n, weights, precision, acc, bvec);
       float Af[36];
       packed_to_dense(acc, Af);
       double A[36], b[6];
@@ -1077,6 +1086,54 @@ int orc_match(const orc_config *cfg, orc_pyramid *ref, orc_pyramid *cur, const d
   free(residuals);
   free(weights);
   return 0;
+}
+
+/* One Gauss-Newton iteration body at a FIXED pose and a FIXED previous precision (dense_tracking.cpp:271-347 without the
+ * accept test and the solve): residuals, weights (unit, or t-distribution from prec_in), scale, precision, log-likelihood,
+ * normal equations.  For the stage-wise parity tests of the weighted iterations (k >= 1). */
+int orc_iteration(orc_pyramid *ref, orc_pyramid *cur, int level, float ti, float td, const float *T, const float prec_in[4],
+                  int unit_weights, int rcp_mode, float scale_out[4], float prec_out[4], float *ll_out, float A36[36],
+                  float b6[6]) {
+  orc_level *R = &ref->lv[level];
+  orc_level *C = &cur->lv[level];
+  level_select(R, ti, td);
+  const size_t max_pts = (size_t)R->w * R->h;
+  orc_record *points_error = (orc_record *)xalloc((max_pts + 1) * sizeof(orc_record));
+  float *residuals = (float *)xalloc((max_pts + 1) * 2 * sizeof(float));
+  float *weights = (float *)xalloc((max_pts + 1) * sizeof(float));
+  warp_args wa;
+  wa.first = R->sel;
+  wa.n_sel = R->n_sel;
+  wa.accel = C->accel;
+  wa.w = C->w;
+  wa.h = C->h;
+  make_kt(C, T, wa.kt);
+  make_weights8(C, wa.wref, wa.wcur);
+  wa.rcp_mode = rcp_mode;
+  wa.out_pe = points_error;
+  wa.out_r = residuals;
+  wa.out_valid = NULL;
+  const int n = warp_residuals(&wa);
+  if (n >= 6) {
+    if (unit_weights)
+      for (int i = 0; i < n; ++i) weights[i] = 1.0f;
+    else
+      tdist_weights(residuals, n, prec_in, rcp_mode, weights);
+    float cov[4], P[4], acc[24];
+    tdist_scale(residuals, n, weights, cov, rcp_mode == ORC_RCP_CLEAN);
+    inverse2f(cov, P);
+    if (scale_out) memcpy(scale_out, cov, sizeof(cov));
+    if (prec_out) memcpy(prec_out, P, sizeof(P));
+    if (ll_out) *ll_out = tdist_loglik(residuals, n, P, rcp_mode == ORC_RCP_CLEAN);
+    if (A36 && b6) {
+      normal_equations(points_error, n, weights, P, acc, b6);
+      packed_to_dense(acc, A36);
+    }
+  }
+  free(points_error);
+  free(residuals);
+  free(weights);
+  return n;
 }
 
 /* ------------------------------------------------------------------------------------------------------------------

@@ -67,6 +67,8 @@ typedef struct {
   double rhs[6];             /* b_d, extra (not in the reference's stats) */
   float scale[4];            /* 2x2 before inversion, extra */
   int has_increment;
+  double estimate[16];       /* extra: the transform (column-major 4x4, estimate()) whose float cast the residual stage of this
+                                iteration used, dense_tracking.cpp:263 */
 } orc_iteration_stats;
 
 /* DenseTracker::LevelStats (dense_tracking.h:103-116) */
@@ -143,6 +145,12 @@ void orc_jacobian(const float p[3], float Jw[12], float Jz[6]); /* dense_trackin
 void orc_rank_update(const float *J2x6_colmajor, const float *alpha_colmajor, int n, float *A36);
 float orc_weights_scale_loglik(const float *residuals, int n, const float *prec_in, int unit_weights, int rcp_mode,
                                float *weights_out, float *scale_out, float *prec_out);
+/* one iteration body at a fixed pose and previous precision (dense_tracking.cpp:271-347 minus accept test and solve):
+ * returns n; scale / precision column-major 2x2, ll as computeCompleteDataLogLikelihood returns it, A column-major 6x6
+ * (without Mu), b (without Mu).  Outputs untouched when n < 6. */
+int orc_iteration(orc_pyramid *ref, orc_pyramid *cur, int level, float ti, float td, const float *T, const float prec_in[4],
+                  int unit_weights, int rcp_mode, float scale_out[4], float prec_out[4], float *ll_out, float A36[36],
+                  float b6[6]);
 float orc_host_rcp(float x); /* _mm_rcp_ps lane 0 on this host */
 
 #ifdef __cplusplus

@@ -25,6 +25,47 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
+def _host_tag() -> str:
+    """-march=native code only runs on the CPU model it was built on: key the timing build by the host's model name"""
+    import hashlib
+
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return hashlib.sha1(model.encode()).hexdigest()[:10]
+
+
+def build_native() -> str:
+    """The TIMING build of the same source with the reference's own flags, `-O3 -march=native` + SSE
+    (dvo_core/CMakeLists.txt:35-40), compiled on the host that runs it.  Only bench.py's cpu_baseline legs use it; the
+    parity checker is always the `build()` flavour (-mno-fma -ffp-contract=off -frounding-math: portable bits)."""
+    path = os.path.join(_HERE, "_build", f"libdvo_oracle_native_{_host_tag()}.so")
+    src = [os.path.join(_HERE, f) for f in ("dvo_oracle.c", "dvo_oracle.h")]
+    if not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in src):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        subprocess.run([os.environ.get("CC", "gcc"), "-O3", "-march=native", "-msse3", "-fPIC", "-std=gnu11", "-shared", "-o",
+                        path + ".tmp", src[0], "-lm"], check=True)
+        os.replace(path + ".tmp", path)
+    return path
+
+
+def select_build(kind: str = "parity"):
+    """Switch this module between the parity build (default) and the native timing build.  Objects created under one build
+    must not be used under the other."""
+    global _lib, _lib_override
+    assert kind in ("parity", "native")
+    _lib = None
+    _lib_override = build_native() if kind == "native" else None
+
+
+_lib_override = None
+
+
 class Config(C.Structure):
     _fields_ = [("first_level", C.c_int), ("last_level", C.c_int), ("max_iterations_per_level", C.c_int),
                 ("precision", C.c_double), ("mu", C.c_double), ("use_initial_estimate", C.c_int),
@@ -36,7 +77,7 @@ class IterationStats(C.Structure):
     _fields_ = [("id", C.c_int), ("valid_constraints", C.c_int), ("tdist_loglik", C.c_double),
                 ("tdist_mean", C.c_double * 2), ("tdist_precision", C.c_double * 4), ("prior_loglik", C.c_double),
                 ("increment", C.c_double * 6), ("information", C.c_double * 36), ("rhs", C.c_double * 6),
-                ("scale", C.c_float * 4), ("has_increment", C.c_int)]
+                ("scale", C.c_float * 4), ("has_increment", C.c_int), ("estimate", C.c_double * 16)]
 
 
 class LevelStats(C.Structure):
@@ -56,7 +97,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        L = C.CDLL(build())
+        L = C.CDLL(_lib_override or build())
         fp = C.POINTER(C.c_float)
         L.orc_default_config.argtypes = [C.POINTER(Config)]
         L.orc_pyramid_create.restype = C.c_void_p
@@ -82,6 +123,7 @@ def lib():
         L.orc_rank_update.argtypes = [fp, fp, C.c_int, fp]
         L.orc_weights_scale_loglik.restype = C.c_float
         L.orc_weights_scale_loglik.argtypes = [fp, C.c_int, fp, C.c_int, C.c_int, fp, fp, fp]
+        L.orc_iteration.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, fp, fp, C.c_int, C.c_int, fp, fp, fp, fp, fp]
         L.orc_host_rcp.restype = C.c_float
         L.orc_host_rcp.argtypes = [C.c_float]
         _lib = L
@@ -155,6 +197,20 @@ def compute_residuals(ref: Pyramid, cur: Pyramid, level, T, rcp_mode=RCP_EXACT, 
     return pe[:n].copy(), r[:n].copy(), valid[: n_sel - (n_sel % 2)].copy()
 
 
+def iteration(ref: Pyramid, cur: Pyramid, level, T, prec_in=None, rcp_mode=RCP_EXACT, ti=0.0, td=0.0):
+    """One Gauss-Newton iteration body at a fixed pose (dense_tracking.cpp:271-347 minus the accept test and the solve):
+    unit weights when prec_in is None (first iteration of a level), else t-distribution weights from prec_in (2x2).
+    Returns dict(n, scale 2x2, precision 2x2, ll, A 6x6, b 6)."""
+    Tf = np.ascontiguousarray(np.asarray(T, dtype=np.float64).astype(np.float32).T)
+    pin = np.zeros(4, np.float32) if prec_in is None else np.ascontiguousarray(np.asarray(prec_in, np.float32).T).ravel()
+    scale, prec, A, b = np.zeros(4, np.float32), np.zeros(4, np.float32), np.zeros(36, np.float32), np.zeros(6, np.float32)
+    ll = np.zeros(1, np.float32)
+    n = lib().orc_iteration(ref.h, cur.h, level, ti, td, _fp(Tf), _fp(pin), int(prec_in is None), rcp_mode, _fp(scale),
+                            _fp(prec), _fp(ll), _fp(A), _fp(b))
+    return {"n": n, "scale": scale.reshape(2, 2).T.copy(), "precision": prec.reshape(2, 2).T.copy(), "ll": float(ll[0]),
+            "A": A.reshape(6, 6).T.copy(), "b": b.copy()}
+
+
 def match(cfg: Config, ref: Pyramid, cur: Pyramid, T_init=None):
     """DenseTracker::match.  Returns a dict with T (4x4), information (6x6), loglik, levels, iterations."""
     cap = (cfg.first_level - cfg.last_level + 1) * (cfg.max_iterations_per_level + 1)
@@ -187,6 +243,7 @@ def match(cfg: Config, ref: Pyramid, cur: Pyramid, T_init=None):
                 "has_increment": bool(it.has_increment), "increment": np.array(it.increment[:]),
                 "information": np.array(it.information[:]).reshape(6, 6).T.copy(), "rhs": np.array(it.rhs[:]),
                 "scale": np.array(it.scale[:]).reshape(2, 2).T.copy(),
+                "estimate": np.array(it.estimate[:]).reshape(4, 4).T.copy(),
             })
         out["levels"].append({"id": L.id, "max_valid_pixels": L.max_valid_pixels, "valid_pixels": L.valid_pixels,
                               "termination": L.termination, "iterations": iters})

@@ -20,7 +20,7 @@ out = trk.match_batch(refs, cb, stats=False, in_flight=IN_FLIGHT)
 ms, n = trk.kernel_timing(False)
 log = trk.tick_log()
 print(f"launches {n}, total {ms:.2f} ms, avg {ms / n * 1e3:.1f} us; alg GB {sum(o.alg_bytes for o in out) / 1e9:.2f}")
-t, items, rb, lb, gx, px = log.T
+t, items, rb, lb, gx, px = log.T[:6]
 A = np.stack([np.ones_like(t), px * 56 / 1e6, lb, items], 1)
 coef, *_ = np.linalg.lstsq(A, t * 1e3, rcond=None)
 print("fit us = %.2f + %.3f * MB_alg + %.4f * ll_blocks + %.3f * items" % tuple(coef))

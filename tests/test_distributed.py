@@ -166,3 +166,40 @@ def test_two_gloo_ranks_exchange_and_combine_band_records():
         assert out[0] == n
         assert np.allclose(out[1:4], ref, rtol=1e-6, atol=1e-12)
     assert np.array_equal(results[0][1], results[1][1])  # every rank ends with the identical combined record
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bench.py --gpus N starts its own ranks (no outer launcher): spawn, rendezvous, aggregation, one JSON line
+# ---------------------------------------------------------------------------------------------------------------------
+def test_bench_gpus_flag_spawns_the_ranks_itself():
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    for n in (1, 2):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--plumbing-only", "--steps", "3",
+                              "--batch", "10"], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, out.stdout  # rank 0 only
+        line = json.loads(lines[0])
+        assert line["n_gpus"] == n and line["steps"] == 3
+        assert line["config"]["pairs_total"] == n * 10 * 3  # SUM over ranks
+        # MAX over ranks: rank r sleeps 50 (r + 1) ms, so the slowest rank sets the step time
+        assert line["ms_per_step"] * 3 >= 50.0 * n * 0.95
+        assert line["metric"].startswith("frame-pairs/s") and line["scaling"] == "weak"
+
+
+def test_bench_pair_index_covers_every_combination_before_repeating():
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    pairs = [bench.pair_index(i, 12, 96) for i in range(1152)]
+    assert len(set(pairs)) == 1152 and all(0 <= r < 12 and 0 <= c < 96 for r, c in pairs)
+    # any 36 consecutive pairs (one launch's worth) are distinct combinations
+    assert all(len(set(pairs[i:i + 36])) == 36 for i in range(0, 1152, 36))

@@ -111,9 +111,159 @@ def test_error_image_matches_residuals(capi, pair640):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# stage-wise, weighted iterations (a8-a12): weights, pair-quirk scale, likelihood cut, normal equations at a FIXED pose
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("level", [3, 2, 1, 0])
+def test_weighted_iteration_stages_match_the_oracle(capi, orc, synth, pair640, level):
+    """One iteration body (dense_tracking.cpp:271-347 without accept test / solve) at fixed poses, first with unit weights
+    (k = 0) and then with the t-distribution weights of the resulting precision (k >= 1: computeWeightsSse
+    dense_tracking_impl.cpp:657-707, computeScaleSse incl. Q5 :590-638, computeCompleteDataLogLikelihood incl. Q6 :406-425,
+    rankUpdate / b -= J^T W r math_sse.cpp:82-178) -- the stages a full match() only shows through the final pose.  The
+    residual set is bit-identical on both sides, so everything agrees to summation order (fp32 sequential in the reference,
+    fp32 per wave + fp64 across blocks here) and to the 1-ulp v_rcp_f32 of the weights (deliberate deviation)."""
+    trk = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0))
+    gr, gc, orr, occ = pair640["gr"], pair640["gc"], pair640["orr"], pair640["occ"]
+    for T in (np.eye(4), pair640["Tgt"], synth.se3_exp(synth.XI_GT_PAIR * 0.9)):
+        prec = None
+        for k in range(3):  # k = 0 unit weights, k = 1, 2 weighted with the previous precision
+            o = orc.iteration(orr, occ, level, T, prec, orc.RCP_EXACT)
+            g = trk.iteration_probe(gr, gc, level, T, prec)
+            where = (level, k)
+            assert g["n"] == o["n"], where
+            assert np.allclose(g["scale"], o["scale"], rtol=3e-5, atol=3e-5 * np.abs(o["scale"]).max()), where
+            assert np.allclose(g["precision"], o["precision"], rtol=5e-5, atol=5e-5 * np.abs(o["precision"]).max()), where
+            # the oracle evaluates the likelihood with ITS precision, the GPU with its own (<= 5e-5 apart): 0.5 n log det P
+            # moves by ~n * 1e-4 / 2 of a total of ~n * 10
+            assert abs(g["ll"] - o["ll"]) <= 3e-5 * abs(o["ll"]), where + (g["ll"], o["ll"])
+            assert np.allclose(g["A"], o["A"], rtol=2e-4, atol=2e-4 * np.abs(o["A"]).max()), where
+            assert np.allclose(g["b"], o["b"], rtol=2e-4, atol=2e-4 * np.abs(o["b"]).max()), where
+            # the rcpps flavour of the reference (host specific) for the record: its 12-bit weights move the scale by < 1e-3
+            s = orc.iteration(orr, occ, level, T, prec, orc.RCP_SSE)
+            if s["n"] == o["n"] and k > 0:
+                assert np.allclose(g["scale"], s["scale"], rtol=2e-3, atol=2e-3 * np.abs(s["scale"]).max()), where
+            prec = o["precision"]
+
+
+@pytest.mark.parametrize("case", ["640x480 levels 3..0", "640x480 swapped", "336x250 levels 2..0"])
+def test_every_iteration_of_a_match_teacher_forced(capi, orc, synth, pair640, case):
+    """Every Gauss-Newton iteration of a full oracle match() (BASELINE config 2 and two more), replayed stage-wise on the GPU
+    from the ORACLE's pose and previous precision of that iteration: valid-constraint count exact, scale / precision /
+    likelihood / normal equations to summation order.  This is the per-iteration depth an unpinned oracle allows: no pose
+    drift between the two sides, so the weighted iterations (k >= 1) are held to the same tolerances as iteration 0."""
+    if case.startswith("640x480"):
+        gr, gc, orr, occ = pair640["gr"], pair640["gc"], pair640["orr"], pair640["occ"]
+        if "swapped" in case:
+            gr, gc, orr, occ = gc, gr, occ, orr
+        first = 3
+    else:
+        (Ir, Zr), (Ic, Zc), _ = synth.make_pair(336, 250, xi_gt=synth.XI_GT_PAIR * 0.4)
+        K = synth.intrinsics_for(336, 250)
+        gr, gc = capi.RgbdImagePyramid(Ir, Zr, K, 3), capi.RgbdImagePyramid(Ic, Zc, K, 3)
+        orr, occ = orc.Pyramid(Ir, Zr, K, 3), orc.Pyramid(Ic, Zc, K, 3)
+        first = 2
+    trk = capi.DenseTracker(capi.Config(FirstLevel=first, LastLevel=0))
+    ro = orc.match(orc.default_config(first_level=first, last_level=0, rcp_mode=orc.RCP_EXACT), orr, occ)
+    n_checked = n_weighted = 0
+    for L in ro["levels"]:
+        prec = None
+        for k, it in enumerate(L["iterations"]):
+            g = trk.iteration_probe(gr, gc, L["id"], it["estimate"], prec)
+            where = (case, "level", L["id"], "iteration", k)
+            assert g["n"] == it["valid_constraints"], where
+            P = it["precision"]
+            assert np.allclose(g["scale"], it["scale"], rtol=3e-5, atol=3e-5 * np.abs(it["scale"]).max()), where
+            assert np.allclose(g["precision"], P, rtol=6e-5, atol=6e-5 * np.abs(P).max()), where
+            assert abs(-g["ll"] - it["tdist_loglik"]) <= 3e-5 * abs(it["tdist_loglik"]), where
+            if it["has_increment"]:  # Mu = 0: Statistics' EstimateInformation is A, the right-hand side is b
+                A, b = it["information"], it["rhs"]
+                assert np.allclose(g["A"], A, rtol=2e-4, atol=2e-4 * np.abs(A).max()), where
+                assert np.allclose(g["b"], b, rtol=2e-4, atol=2e-4 * np.abs(b).max()), where
+                x = capi.solve6(g["A"], g["b"])
+                assert np.allclose(x, it["increment"], rtol=2e-2, atol=2e-6), where  # the LDLT solve on the moments' system
+            n_checked += 1
+            n_weighted += k > 0
+            prec = P
+    assert n_checked >= 10 and n_weighted >= 6
+
+
+@pytest.mark.parametrize("n_drop", [0, 1, 2, 3, 49])
+def test_weighted_stage_tails(capi, orc, synth, n_drop):
+    """V mod 2 / mod 4 / mod 50 tails of the order-dependent stages (Q5 odd tail :566-572, Q6 :413-424, Q7 :667-706): drop the
+    depth of the last n_drop selected pixels of a small level so that V takes every residue class."""
+    w, h = 160, 120
+    (Ir, Zr), (Ic, Zc), Tgt = synth.make_pair(w, h, xi_gt=synth.XI_GT_PAIR * 0.5)
+    Zr = Zr.copy()
+    ok = np.flatnonzero(~np.isnan(Zr.ravel()))
+    Zr.ravel()[ok[len(ok) - 2 * n_drop:]] = np.nan
+    K = synth.intrinsics_for(w, h)
+    gr, gc = capi.RgbdImagePyramid(Ir, Zr, K, 1), capi.RgbdImagePyramid(Ic, Zc, K, 1)
+    orr, occ = orc.Pyramid(Ir, Zr, K, 1), orc.Pyramid(Ic, Zc, K, 1)
+    trk = capi.DenseTracker(capi.Config(FirstLevel=0, LastLevel=0))
+    o0 = orc.iteration(orr, occ, 0, Tgt, None, orc.RCP_EXACT)
+    o1 = orc.iteration(orr, occ, 0, Tgt, o0["precision"], orc.RCP_EXACT)
+    g1 = trk.iteration_probe(gr, gc, 0, Tgt, o0["precision"])
+    assert g1["n"] == o1["n"]
+    assert np.allclose(g1["scale"], o1["scale"], rtol=3e-5, atol=3e-5 * np.abs(o1["scale"]).max())
+    assert abs(g1["ll"] - o1["ll"]) <= 3e-5 * abs(o1["ll"])
+    assert np.allclose(g1["A"], o1["A"], rtol=2e-4, atol=2e-4 * np.abs(o1["A"]).max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # full match(): pose parity, statistics, quirks
 # ---------------------------------------------------------------------------------------------------------------------
+# which configurations took the same iteration path as the oracle and which forked (see DIVERGED_PATH_TOL); the last test
+# of this file asserts that the number of forks does not grow
+_PATHS = {"same": [], "forked": []}
+# Per-iteration checks of a free-running match() against the oracle's (dense_tracking.cpp:273-352 per iteration:
+# ValidConstraints, TDistributionPrecision, TDistributionLogLikelihood, EstimateIncrement).  The first iteration of the first
+# level sees identical inputs: summation-order tolerances.  Every later iteration starts from a pose that has drifted by
+# ~1e-7 (fp32 sums taken in a different order), and near convergence the depth residuals of a noise-free synthetic scene have
+# sigma ~1e-4 m, so a 1e-7 pose drift moves the scale estimate by ~1e-3 relative: these iterations are compared at drift
+# tolerances here and at summation-order tolerances in test_every_iteration_of_the_headline_match_teacher_forced, which
+# feeds the oracle's own pose and precision of every iteration into the GPU stages.
+ITER0_PRECISION_RTOL, ITER0_LOGLIK_RTOL = 1e-4, 1e-4
+DRIFT_PRECISION_RTOL, DRIFT_LOGLIK_RTOL = 3e-3, 3e-4
+ITER_INCREMENT_RTOL, ITER_INCREMENT_ATOL = 2e-2, 3e-6
+ITER_COUNT_SLACK = 3  # constraints by which V of a later iteration may differ on a same-path run
+
+
+def _compare_iterations(levels_gpu, levels_orc, label, first_is_identical=True):
+    """levels_orc: [(V, -ll, P 2x2, has_increment, increment)] per level.  Asserts the per-iteration quantities and returns
+    (iterations compared, iterations with identical V)."""
+    n_it = n_same_v = 0
+    for li, (Lg, Lo) in enumerate(zip(levels_gpu, levels_orc)):
+        assert len(Lg["Iterations"]) == len(Lo), (label, li)
+        for k, (ig, io) in enumerate(zip(Lg["Iterations"], Lo)):
+            V, nll, P, has_inc, inc = io
+            where = (label, "level", Lg["Id"], "iteration", k)
+            n_it += 1
+            identical = first_is_identical and k == 0 and li == 0
+            if identical:
+                assert ig["ValidConstraints"] == V, where  # identical inputs
+            assert abs(ig["ValidConstraints"] - V) <= ITER_COUNT_SLACK, where + (ig["ValidConstraints"], V)
+            if ig["ValidConstraints"] != V:
+                continue
+            n_same_v += 1
+            if V < 6:
+                continue
+            p_rtol = ITER0_PRECISION_RTOL if identical else DRIFT_PRECISION_RTOL
+            l_rtol = ITER0_LOGLIK_RTOL if identical else DRIFT_LOGLIK_RTOL
+            assert np.allclose(ig["TDistributionPrecision"], P, rtol=p_rtol, atol=p_rtol * np.abs(P).max()), where
+            assert abs(ig["TDistributionLogLikelihood"] - nll) <= l_rtol * abs(nll), where
+            if has_inc:
+                assert np.allclose(ig["EstimateIncrement"], inc, rtol=ITER_INCREMENT_RTOL, atol=ITER_INCREMENT_ATOL), where
+    return n_it, n_same_v
+
+
+def _oracle_levels(ro):
+    return [[(it["valid_constraints"], it["tdist_loglik"], it["precision"], it["has_increment"], it["increment"])
+             for it in L["iterations"]] for L in ro["levels"]]
+
+
 def _check_match(capi, orc, synth, g_ref, g_cur, o_ref, o_cur, cfg_kw, T_init=None, tol=POSE_TOL):
+    import inspect
+
+    label = inspect.stack()[1].function + repr(sorted(cfg_kw.items()))
     gcfg = capi.Config(**cfg_kw)
     trk = capi.DenseTracker(gcfg)
     rg = trk.match(g_ref, g_cur, T_init)
@@ -126,10 +276,20 @@ def _check_match(capi, orc, synth, g_ref, g_cur, o_ref, o_cur, cfg_kw, T_init=No
     err = synth.pose_error(ro["T"], rg.Transformation)
     same_path = all(Lg["TerminationCriterion"] == Lo["termination"] and len(Lg["Iterations"]) == len(Lo["iterations"])
                     for Lg, Lo in zip(rg.Levels, ro["levels"]))
+    _PATHS["same" if same_path else "forked"].append(label)
     if same_path:
         assert err <= tol, err
+        # every Gauss-Newton iteration, not only the final pose
+        n_it, n_same_v = _compare_iterations(rg.Levels, _oracle_levels(ro), label)
+        print(f"[iterations] {label}: {n_it} compared, {n_same_v} with identical ValidConstraints, pose err {err:.2e}")
     else:
         assert err <= DIVERGED_PATH_TOL, err
+        # up to the fork both ran the same iterations: compare the common prefix of every level up to the first level whose
+        # iteration count differs
+        for Lg, Lo in zip(rg.Levels, ro["levels"]):
+            if len(Lg["Iterations"]) != len(Lo["iterations"]) or Lg["TerminationCriterion"] != Lo["termination"]:
+                break
+            _compare_iterations([Lg], _oracle_levels({"levels": [Lo]}), label + " (prefix)", first_is_identical=Lg is rg.Levels[0])
     assert rg.isNaN() == ro["is_nan"]
     assert [L["Id"] for L in rg.Levels] == [L["id"] for L in ro["levels"]]
     for Lg, Lo in zip(rg.Levels, ro["levels"]):
@@ -271,6 +431,16 @@ def test_match_against_committed_golden_vectors(capi, synth, name):
     rg = trk.match(gr, gc, T0)
     assert synth.pose_error(want["T"], rg.Transformation) <= POSE_TOL
     assert [L["ValidPixels"] for L in rg.Levels] == list(want["levels"][:, 1])
+    # the committed per-iteration vectors (V, -ll, P, increment) of every Gauss-Newton iteration (dense_tracking.cpp:273-352)
+    assert [L["Id"] for L in rg.Levels] == list(want["levels"][:, 0])
+    assert [L["TerminationCriterion"] for L in rg.Levels] == list(want["levels"][:, 2])
+    assert [len(L["Iterations"]) for L in rg.Levels] == list(want["levels"][:, 3])
+    rows = want["iterations"]
+    per_level = [[(int(r[2]), r[3], r[5:9].reshape(2, 2).T, bool(r[4]), r[9:15]) for r in rows if int(r[0]) == L["Id"]]
+                 for L in rg.Levels]
+    n_it, n_same_v = _compare_iterations(rg.Levels, per_level, name)
+    assert n_it == len(rows)
+    assert np.allclose(rg.Information, want["information"], rtol=5e-3, atol=5e-3 * np.abs(want["information"]).max())
     assert [gr.select(l)[0] for l in range(levels)] == list(want["sel_counts"])
     res, n = trk.residuals(gr, gc, last, np.eye(4))
     assert n == int(want["res_count"])
@@ -582,3 +752,20 @@ def test_sharded_match_with_single_rank_communicator(capi, synth, pair640):
     whole = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0)).match(pair640["gr"], pair640["gc"])
     assert synth.pose_error(whole.Transformation, sharded.Transformation) <= 1e-7
     assert [len(L["Iterations"]) for L in sharded.Levels] == [len(L["Iterations"]) for L in whole.Levels]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# keep last: the fork budget
+# ---------------------------------------------------------------------------------------------------------------------
+MAX_FORKED_CONFIGS = 1  # round 1: one of the oracle-checked configurations forked (chaos caveat)
+
+
+def test_zz_forked_paths_do_not_grow(capsys):
+    """Every _check_match() above recorded whether GPU and oracle took the same iteration path.  A fork is legitimate (the
+    reference algorithm amplifies 1e-9 into an accept / reject flip, tests/test_oracle.py::test_reference_algorithm_is_chaotic)
+    but it waives the 1e-5 bar for that configuration, so the number of forks is pinned."""
+    with capsys.disabled():
+        print(f"\n[paths] same: {len(_PATHS['same'])}, forked: {len(_PATHS['forked'])} {_PATHS['forked']}")
+    if not _PATHS["same"] and not _PATHS["forked"]:
+        pytest.skip("no match configuration ran in this session")
+    assert len(_PATHS["forked"]) <= MAX_FORKED_CONFIGS, _PATHS["forked"]

@@ -417,3 +417,23 @@ def test_raw_synthetic_frame_round_trips_through_ingest(orc, synth):
     m = ~np.isnan(Z)
     assert np.abs(Zg[m] - Z[m]).max() <= 0.5 / 5000.0 + 1e-6
     assert np.abs(Ig - I).max() <= 16.5
+
+
+def test_iteration_probe_reproduces_the_iterations_of_match(orc, synth, small_pair):
+    """orc_iteration (the stage oracle of the weighted-iteration GPU tests) is the loop body of orc_match: fed the pose and
+    the previous precision of iterations 0 and 1 of a level it reproduces their statistics bit for bit."""
+    (Ir, Zr), (Ic, Zc), Tgt, K = small_pair
+    pr, pc = orc.Pyramid(Ir, Zr, K, 2), orc.Pyramid(Ic, Zc, K, 2)
+    m = orc.match(orc.default_config(first_level=1, last_level=1, rcp_mode=orc.RCP_EXACT), pr, pc)
+    its = m["levels"][0]["iterations"]
+    assert len(its) >= 3
+    T, prec = np.eye(4), None
+    for k in range(2):
+        it = orc.iteration(pr, pc, 1, T, prec, orc.RCP_EXACT)
+        assert it["n"] == its[k]["valid_constraints"]
+        assert np.array_equal(it["precision"].astype(np.float64), its[k]["precision"])
+        assert np.float64(it["ll"]) == -its[k]["tdist_loglik"]
+        assert np.array_equal(it["A"].astype(np.float64), its[k]["information"])
+        assert np.array_equal(it["b"].astype(np.float64), its[k]["rhs"])
+        T = orc.se3_exp(its[k]["increment"]) @ T  # estimate = inc * estimate (dense_tracking.cpp:261)
+        prec = it["precision"]
