@@ -31,7 +31,7 @@ EXPORTS = [
     "dvo_amd_match_sharded", "dvo_amd_match_banded", "dvo_amd_debug_combine_bands", "dvo_amd_pyramid_create_raw",
     "dvo_amd_default_validator_stages", "dvo_amd_proposals_for_candidates", "dvo_amd_validate_proposals",
     "dvo_amd_track_frame", "dvo_amd_png_info", "dvo_amd_png_read_bgr8", "dvo_amd_png_read_gray16",
-    "dvo_amd_format_trajectory_line", "dvo_amd_debug_tick_log", "dvo_amd_debug_iteration",
+    "dvo_amd_format_trajectory_line", "dvo_amd_debug_tick_log", "dvo_amd_debug_iteration", "dvo_amd_match_selection", "dvo_amd_bench_residual_pass_pairs",
 ]
 
 
@@ -139,14 +139,17 @@ def lib():
     L.dvo_amd_pyramid_download_plane.argtypes = [vp, C.c_int, C.c_int, fp]
     L.dvo_amd_pyramid_select.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_ubyte)]
     L.dvo_amd_match.argtypes = [vp, vp, vp, dp, C.POINTER(CResult)]
+    L.dvo_amd_match_selection.argtypes = [vp, vp, C.c_float, C.c_float, vp, dp, C.POINTER(CResult)]
     L.dvo_amd_match_batch.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), dp, C.POINTER(CResult)]
     L.dvo_amd_match_many.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), dp, C.POINTER(CResult), C.c_int]
     L.dvo_amd_residuals.argtypes = [vp, vp, vp, C.c_int, fp, fp, C.POINTER(C.c_int)]
     L.dvo_amd_error_image.argtypes = [vp, vp, vp, dp, C.c_int, fp]
-    L.dvo_amd_debug_iteration.argtypes = [vp, vp, vp, C.c_int, fp, fp, C.POINTER(CIterationProbe)]
+    L.dvo_amd_debug_iteration.argtypes = [vp, vp, vp, C.c_int, fp, fp, fp, C.POINTER(CIterationProbe)]
     L.dvo_amd_kernel_timing.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_longlong), C.c_int]
     L.dvo_amd_bench_residual_pass.argtypes = [vp, vp, vp, C.c_int, fp, C.c_int, C.c_int, C.c_int, dp, dp,
                                               C.POINTER(C.c_int)]
+    L.dvo_amd_bench_residual_pass_pairs.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int, fp, C.c_int, C.c_int, dp, dp,
+                                                    C.POINTER(C.c_int)]
     L.dvo_amd_debug_finalize_stamps.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     L.dvo_amd_comm_unique_id.argtypes = [C.POINTER(C.c_ubyte)]
     L.dvo_amd_comm_create.argtypes = [vp, C.POINTER(C.c_ubyte), C.c_int, C.c_int]
@@ -463,15 +466,19 @@ class DenseTracker:
                "dvo_amd_residuals")
         return out, n.value
 
-    def iteration_probe(self, reference: RgbdImagePyramid, current: RgbdImagePyramid, level: int, T, precision_in=None):
+    def iteration_probe(self, reference: RgbdImagePyramid, current: RgbdImagePyramid, level: int, T, precision_in=None,
+                        precision_eval=None):
         """One Gauss-Newton iteration body at the fixed pose T (dense_tracking.cpp:271-347 minus accept test and solve)
         through the kernels and host arithmetic match() uses: unit weights when precision_in is None, else t-distribution
-        weights from the 2x2 precision_in.  Returns dict(n, scale, precision, ll, A, b, moments, scale_sums)."""
+        weights from the 2x2 precision_in.  precision_eval: evaluate A / b / ll with this 2x2 precision instead of the computed
+        one.  Returns dict(n, scale, precision, ll, A, b, moments, scale_sums)."""
         Tf = np.ascontiguousarray(np.asarray(T, dtype=np.float64).astype(np.float32).T)
         pin = None if precision_in is None else np.ascontiguousarray(np.asarray(precision_in, np.float32).T).ravel()
+        pev = None if precision_eval is None else np.ascontiguousarray(np.asarray(precision_eval, np.float32).T).ravel()
         pr = CIterationProbe()
         _check(lib().dvo_amd_debug_iteration(self._h, reference._h, current._h, level, _fp(Tf),
-                                             None if pin is None else _fp(pin), C.byref(pr)), "dvo_amd_debug_iteration")
+                                             None if pin is None else _fp(pin), None if pev is None else _fp(pev),
+                                             C.byref(pr)), "dvo_amd_debug_iteration")
         return {"n": pr.valid_constraints, "scale": np.array(pr.scale[:], np.float32).reshape(2, 2).T.copy(),
                 "precision": np.array(pr.precision[:], np.float32).reshape(2, 2).T.copy(), "ll": float(pr.loglik),
                 "A": np.array(pr.information[:]).reshape(6, 6).T.copy(), "b": np.array(pr.rhs[:]),
@@ -491,6 +498,17 @@ class DenseTracker:
         ms, ab, nl = C.c_double(), C.c_double(), C.c_int()
         _check(lib().dvo_amd_bench_residual_pass(self._h, reference._h, current._h, level, _fp(Tf), n_items, rounds, reps,
                                                  C.byref(ms), C.byref(ab), C.byref(nl)), "dvo_amd_bench_residual_pass")
+        return ms.value, ab.value, nl.value
+
+    def bench_residual_pass_pairs(self, references, currents, level: int, T, rounds: int = 0, reps: int = 20):
+        """The same over different (reference, current) pairs: nothing for the caches to deduplicate."""
+        n = len(references)
+        Tf = np.ascontiguousarray(np.asarray(T, dtype=np.float64).astype(np.float32).T)
+        refs = (C.c_void_p * n)(*[r._h for r in references])
+        curs = (C.c_void_p * n)(*[c._h for c in currents])
+        ms, ab, nl = C.c_double(), C.c_double(), C.c_int()
+        _check(lib().dvo_amd_bench_residual_pass_pairs(self._h, n, refs, curs, level, _fp(Tf), rounds, reps, C.byref(ms),
+                                                       C.byref(ab), C.byref(nl)), "dvo_amd_bench_residual_pass_pairs")
         return ms.value, ab.value, nl.value
 
     def tick_log(self) -> np.ndarray:

@@ -17,6 +17,9 @@
 // (deterministic run to run).
 //
 // This file is compiled with -ffp-contract=off: every a*b+c that may fuse is written as __builtin_fmaf explicitly.
+#include <cstdlib>
+#include <cstring>
+
 #include "dvo_types.h"
 
 namespace dvo_amd {
@@ -33,6 +36,13 @@ namespace dvo_amd {
 
 __device__ __forceinline__ void round_toward_zero() { __builtin_amdgcn_s_setreg(DVO_HWREG_MODE_FP32_ROUND, 3); }
 __device__ __forceinline__ void round_to_nearest() { __builtin_amdgcn_s_setreg(DVO_HWREG_MODE_FP32_ROUND, 0); }
+
+// v_mul_legacy_f32: 0 * x = 0 for every x (NaN and infinity included); otherwise an ordinary IEEE multiply
+__device__ __forceinline__ float mul_legacy(float a, float b) {
+  float r;
+  asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 
 __device__ __forceinline__ float u2f(unsigned u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ unsigned f2u(float f) { return __builtin_bit_cast(unsigned, f); }
@@ -177,6 +187,9 @@ __device__ __forceinline__ Gathered gather_pixel(const LevelPairDesc &d, int bas
   return g;
 }
 
+// ZERO_E: also zero the gradient terms of an invalid pixel (the register-accumulator form needs that; the staged forms scale
+// them by a zero weight with a multiply whose 0 * anything is 0, so the four selects are saved)
+template <bool ZERO_E>
 __device__ __forceinline__ void finish_pixel_rtz(const LevelPairDesc &d, const Proj &p, const Gathered &g, float z, float ri,
                                                  float rix, float riy, float &r0, float &r1, float &e2, float &e3, float &e4,
                                                  float &e5, bool &valid) {
@@ -203,13 +216,21 @@ __device__ __forceinline__ void finish_pixel_rtz(const LevelPairDesc &d, const P
   valid = p.inb && !has_nan && (t1 > -20.0f * s);
   r0 = valid ? t0 : 0.0f;
   r1 = valid ? t1 : 0.0f;
-  e2 = valid ? d.wc[2] * cix + d.wr[2] * rix : 0.0f;
-  e3 = valid ? d.wc[3] * ciy + d.wr[3] * riy : 0.0f;
-  e4 = valid ? d.wc[4] * czx : 0.0f;  // wref is 0 for the depth derivatives (dense_tracking.cpp:217-220)
-  e5 = valid ? d.wc[5] * czy : 0.0f;
+  e2 = d.wc[2] * cix + d.wr[2] * rix;
+  e3 = d.wc[3] * ciy + d.wr[3] * riy;
+  e4 = d.wc[4] * czx;  // wref is 0 for the depth derivatives (dense_tracking.cpp:217-220)
+  e5 = d.wc[5] * czy;
+  if (ZERO_E) e2 = valid ? e2 : 0.0f, e3 = valid ? e3 : 0.0f, e4 = valid ? e4 : 0.0f, e5 = valid ? e5 : 0.0f;
 }
 
 typedef float v4acc __attribute__((ext_vector_type(4)));
+
+// wave-local LDS hand-off: the LDS queue of a wave is in order, the fences only pin the compiler
+#define DVO_WAVE_LDS_SYNC()                                 \
+  do {                                                      \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  \
+    __builtin_amdgcn_wave_barrier();                        \
+  } while (0)
 
 // Timing-only ablation builds (scripts/ablate.sh: -DDVO_ABLATE=<mask>); never defined in the shipped library.
 // 1: no LDS staging / MFMA   2: no gather loads   4: no rank / pair-sum logic   8: no residual spill store
@@ -228,6 +249,10 @@ typedef float v4acc __attribute__((ext_vector_type(4)));
 //        through LDS (lane-per-point -> lane-per-component) and accumulated by v_mfma_f32_16x16x4_f32 into 2 x 4
 //        registers.  The MFMA sums over the points itself, so no 87-value wave reduction is needed and the kernel fits
 //        4 waves per SIMD (the 87-register form is capped at 2).
+// ACC 2: the same Gram matrix from its 4x4 blocks: v is cut into the groups [Ja0..3] [Ja4,Ja5,Jb0,Jb1] [Jb2..5] [r0,r1,0,0] and
+//        v_mfma_f32_4x4x1_16B_f32 (16 independent 4x4 outer products per instruction, one pixel each) accumulates only the 9
+//        group pairs the 87 moments need (6 of the symmetric J J^T part + 3 J r^T): 36 instructions x 8 cycles per 64 pixels
+//        instead of 16 x 32, at the price of 36 accumulator registers and a 16-block reduction in the epilogue.
 template <int RMODE, int ACC>
 __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const int lb) {
   const int lane = threadIdx.x & (kWave - 1);
@@ -245,12 +270,17 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
   for (int i = 0; i < (ACC == 0 ? kNumAcc : 1); ++i) acc[i] = 0.0f;
   v4acc gram_a = {0.0f, 0.0f, 0.0f, 0.0f}, gram_b = {0.0f, 0.0f, 0.0f, 0.0f};
   // staging for the MFMA operands: [wave][point = lane][16 components], 16-byte chunks XOR-swizzled by point
-  __shared__ __attribute__((aligned(16))) float stage[ACC == 1 ? kWavesPerBlock * 2 * kWave * 16 : 4];
+  __shared__ __attribute__((aligned(16))) float stage[ACC >= 1 ? kWavesPerBlock * 2 * kWave * 16 : 4];
   float S0[3] = {0.0f, 0.0f, 0.0f}, S1[3] = {0.0f, 0.0f, 0.0f};
   float first_w = 0.0f;
   int run_count = 0;                        // wave uniform
-  float carry_r0 = 0.0f, carry_r1 = 0.0f;   // wave uniform: residual of the last valid pixel of earlier steps
-  bool carry_has = false;
+  // The pair quirk needs, for every valid pixel, the residual of the valid pixel before it in scan order.  Each wave keeps
+  // the valid residuals of the current step compacted in LDS: slot 0 = the last valid pixel of earlier steps (zeros at
+  // the start of a segment), slot 1 + k = the k-th valid pixel of this step; a pixel with k valid pixels below it in the
+  // wave finds its predecessor in slot k.  (Ballot / mbcnt give k; no cross-lane shuffles, no carry registers.)
+  __shared__ __attribute__((aligned(8))) v2f pair_slots[kWavesPerBlock][kWave + 2];
+  v2f *const slots = pair_slots[wave];
+  if (lane == 0) slots[0] = v2f{0.0f, 0.0f};
 
   // K*T lives in vector registers: as scalars the 12 values do not fit next to the descriptors, and the compiler re-reads
   // them from the kernel arguments inside every step, with a full scalar-memory wait in front of the projection
@@ -260,7 +290,6 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
     kt[i] = it.kt[i];
     DVO_OPAQUE(kt[i]);
   }
-  const unsigned long long below = (1ull << lane) - 1ull;
   const bool unit_w = (it.flags & kItemUnitWeights) != 0;
   const float P0 = it.P[0], P1 = it.P[1], P2 = it.P[2], P3 = it.P[3];
   const DVO_GLOBAL void *const p_z = (const DVO_GLOBAL void *)d.r_zsel, *const p_i = (const DVO_GLOBAL void *)d.r_i,
@@ -280,7 +309,35 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
   const int g_comp = lane & 15, g_sub = lane >> 4, g_cb = (g_comp >> 2) ^ (g_sub >> 1);
   const float *const g_even = stage + (wave * 2 * kWave + g_sub) * 16 + ((g_cb << 2) | (g_comp & 3));
   const float *const g_odd = stage + (wave * 2 * kWave + g_sub) * 16 + (((g_cb ^ 2) << 2) | (g_comp & 3));
+  // 4x4-block form (ACC 2): MFMA m of a step covers the 16 pixels 16 m .. 16 m + 15, one per block; lane 4 b + i supplies
+  // element i of a component group of pixel 16 m + b.  A group is exactly one 16-byte chunk of the staged row, at chunk position
+  // g ^ ((p >> 1) & 3) = g ^ ((b >> 1) & 3): four lane-constant offsets, the rest are immediates.  Conflict free: within a
+  // half wave the 8 blocks x 4 elements fall on 32 different banks.
+  constexpr int kGram4Types = 9;  // (gA, gB): (0,0) (0,1) (0,2) (1,1) (1,2) (2,2) (0,3) (1,3) (2,3)
+  v4acc g4[ACC == 2 ? kGram4Types : 1];
+#pragma unroll
+  for (int t = 0; t < (ACC == 2 ? kGram4Types : 1); ++t) g4[t] = v4acc{0.0f, 0.0f, 0.0f, 0.0f};
+  const int b4 = lane >> 2, i4 = lane & 3, sw4 = (b4 >> 1) & 3;
+  const float *const g4_base = stage + (wave * 2 * kWave + b4) * 16 + i4;
   auto gram_from_stage = [&](const int q) __attribute__((always_inline)) {
+    if (ACC == 2) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        float R[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) R[g] = g4_base[((g ^ sw4) << 2) + q * kWave * 16 + m * 256];
+        g4[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(R[0], R[0], g4[0], 0, 0, 0);
+        g4[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(R[0], R[1], g4[1], 0, 0, 0);
+        g4[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(R[0], R[2], g4[2], 0, 0, 0);
+        g4[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(R[1], R[1], g4[3], 0, 0, 0);
+        g4[4] = __builtin_amdgcn_mfma_f32_4x4x1f32(R[1], R[2], g4[4], 0, 0, 0);
+        g4[5] = __builtin_amdgcn_mfma_f32_4x4x1f32(R[2], R[2], g4[5], 0, 0, 0);
+        g4[6] = __builtin_amdgcn_mfma_f32_4x4x1f32(R[0], R[3], g4[6], 0, 0, 0);
+        g4[7] = __builtin_amdgcn_mfma_f32_4x4x1f32(R[1], R[3], g4[7], 0, 0, 0);
+        g4[8] = __builtin_amdgcn_mfma_f32_4x4x1f32(R[2], R[3], g4[8], 0, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int m = 0; m < 16; m += 2) {
       const float va = g_even[q * kWave * 16 + 64 * m];
@@ -328,11 +385,11 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
       // (v_mfma_f32 ignores MODE.FP_ROUND -- probed on gfx950, scripts/probes/mfma_round.hip -- so it may sit in
       // the toward-zero window).  This overlaps ~512 matrix-pipe cycles with the gather latency and with the next
       // wave's arithmetic instead of serialising them behind this wave's own VALU work.
-      if (ACC == 1 && !(DVO_ABLATE & 1) && step > 0) {
+      if (ACC >= 1 && !(DVO_ABLATE & 1) && step > 0) {
         gram_from_stage(q ^ 1);
         __builtin_amdgcn_sched_barrier(0);
       }
-      finish_pixel_rtz(d, p, g, z, ri, rix, riy, r0, r1, e2, e3, e4, e5, ok);
+      finish_pixel_rtz<ACC == 0>(d, p, g, z, ri, rix, riy, r0, r1, e2, e3, e4, e5, ok);
     }
     // ---- back to round-to-nearest
     DVO_OPAQUE(r0); DVO_OPAQUE(r1); DVO_OPAQUE(e2); DVO_OPAQUE(e3); DVO_OPAQUE(e4); DVO_OPAQUE(e5);
@@ -374,19 +431,26 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
     const float j03 = j02 * y, j13 = __builtin_fmaf(j12, y, -1.0f);
     const float j04 = __builtin_fmaf(-j02, x, 1.0f), j14 = -j03;
     const float j05 = -y * iz, j15 = x * iz;
+    // The staged forms accumulate sqrt(w) v: the factor goes onto the four gradient terms and the three constants of Jz
+    // before the 2 x 6 rows are formed (8 multiplies instead of 14 on the finished rows).  v_mul_legacy_f32: 0 * x = 0 for
+    // every x, so the zero weight of an invalid pixel also wipes whatever its gradient terms hold (NaN included).
+    const float sw = ACC == 0 ? 1.0f : __builtin_amdgcn_sqrtf(wgt);
+    const float g2 = ACC == 0 ? e2 : mul_legacy(sw, e2), g3 = ACC == 0 ? e3 : mul_legacy(sw, e3);
+    const float g4 = ACC == 0 ? e4 : mul_legacy(sw, e4), g5 = ACC == 0 ? e5 : mul_legacy(sw, e5);
+    const float swx = sw * x, swy = sw * y;
     float Ja[6], Jb[6];
-    Ja[0] = e2 * iz;
-    Ja[1] = e3 * iz;
-    Ja[2] = __builtin_fmaf(e2, j02, e3 * j12);
-    Ja[3] = __builtin_fmaf(e2, j03, e3 * j13);
-    Ja[4] = __builtin_fmaf(e2, j04, e3 * j14);
-    Ja[5] = __builtin_fmaf(e2, j05, e3 * j15);
-    Jb[0] = e4 * iz;
-    Jb[1] = e5 * iz;
-    Jb[2] = __builtin_fmaf(e4, j02, __builtin_fmaf(e5, j12, -1.0f));
-    Jb[3] = __builtin_fmaf(e4, j03, __builtin_fmaf(e5, j13, -y));
-    Jb[4] = __builtin_fmaf(e4, j04, __builtin_fmaf(e5, j14, x));
-    Jb[5] = __builtin_fmaf(e4, j05, e5 * j15);
+    Ja[0] = g2 * iz;
+    Ja[1] = g3 * iz;
+    Ja[2] = __builtin_fmaf(g2, j02, g3 * j12);
+    Ja[3] = __builtin_fmaf(g2, j03, g3 * j13);
+    Ja[4] = __builtin_fmaf(g2, j04, g3 * j14);
+    Ja[5] = __builtin_fmaf(g2, j05, g3 * j15);
+    Jb[0] = g4 * iz;
+    Jb[1] = g5 * iz;
+    Jb[2] = __builtin_fmaf(g4, j02, __builtin_fmaf(g5, j12, -sw));
+    Jb[3] = __builtin_fmaf(g4, j03, __builtin_fmaf(g5, j13, -swy));
+    Jb[4] = __builtin_fmaf(g4, j04, __builtin_fmaf(g5, j14, swx));
+    Jb[5] = __builtin_fmaf(g4, j05, g5 * j15);
     // A += J^T (w P) J and b -= J^T (w P) r are linear in P: accumulate the P-free moments (87 sums)
     if (ACC == 0) {
       float wa[6], wb[6];
@@ -416,13 +480,12 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
     } else {
       // stage sqrt(w) * v for this lane's pixel; chunk c of point p sits at chunk position c ^ ((p >> 1) & 3).
       // Two buffers alternate: the matrix pipe consumes this one during the NEXT step (see above).
-      const float sw = __builtin_amdgcn_sqrtf(wgt);
       float *buf = stage + ((wave * 2 + q) * kWave) * 16;
       v4f *row = reinterpret_cast<v4f *>(buf + lane * 16);
       const int swz = (lane >> 1) & 3;
-      v4f c0 = {sw * Ja[0], sw * Ja[1], sw * Ja[2], sw * Ja[3]};
-      v4f c1 = {sw * Ja[4], sw * Ja[5], sw * Jb[0], sw * Jb[1]};
-      v4f c2 = {sw * Jb[2], sw * Jb[3], sw * Jb[4], sw * Jb[5]};
+      v4f c0 = {Ja[0], Ja[1], Ja[2], Ja[3]};  // the rows carry sqrt(w) already
+      v4f c1 = {Ja[4], Ja[5], Jb[0], Jb[1]};
+      v4f c2 = {Jb[2], Jb[3], Jb[4], Jb[5]};
       v4f c3 = {sw * r0, sw * r1, 0.0f, 0.0f};
       // the LDS queue of a wave is in order: these writes land after the reads of two steps ago and before the reads of
       // the next step; the fences only stop the compiler from reordering across them
@@ -438,25 +501,26 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
 
     if (DVO_ABLATE & 4) {
       S0[0] += wgt * r0;
-      run_count += ok ? 1 : 0;
+      run_count += __popcll(__ballot(ok));
       return;
     }
     // ---- rank of every valid pixel in scan order within this wave's segment (needed by the pair quirk Q5)
     const unsigned long long bk = __ballot(ok);
-    const unsigned long long prev_lanes = bk & below;
-    const int rank = run_count + __popcll(prev_lanes);
-    // residual of the valid pixel that precedes this one: the nearest valid lower lane, else the carry of earlier steps
-    const int src_lane = prev_lanes ? 63 - __clzll((long long)prev_lanes) : 0;
-    const float sh_r0 = __shfl(r0, src_lane, 64), sh_r1 = __shfl(r1, src_lane, 64);
-    const float prev_r0 = prev_lanes ? sh_r0 : carry_r0;
-    const float prev_r1 = prev_lanes ? sh_r1 : carry_r1;
-    const bool prev_has = prev_lanes ? true : carry_has;
+    const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bk, 0u));
+    const int rank = run_count + pos;
+    const int n_here = __popcll(bk);
+    DVO_WAVE_LDS_SYNC();
+    if (ok) slots[pos + 1] = v2f{r0, r1};
+    DVO_WAVE_LDS_SYNC();
+    const v2f prev = slots[pos];  // the valid pixel before this one (invalid lanes read a valid slot too: weight 0)
+    DVO_WAVE_LDS_SYNC();
+    if (n_here) slots[0] = slots[n_here];  // every lane moves the same value: the carry for the next step
     {
       // computeScaleSse with Q5: a pair (2j, 2j+1) contributes (w_2j + w_2j+1) r_2j r_2j^T (:603-621).
       // S0 assumes this segment starts on an even global rank, S1 on an odd one.  Invalid pixels have weight 0.
       const float sxx = r0 * r0, sxy = r0 * r1, syy = r1 * r1;
-      // without a preceding valid pixel prev_r0 = prev_r1 = 0 (the initial carry), so the products vanish by themselves
-      const float pxx = prev_r0 * prev_r0, pxy = prev_r0 * prev_r1, pyy = prev_r1 * prev_r1;
+      // the segment's first valid pixel reads the zeros slot 0 starts with, so its "predecessor" products vanish
+      const float pxx = prev.x * prev.x, pxy = prev.x * prev.y, pyy = prev.y * prev.y;
       const bool odd = (rank & 1) != 0;
       S0[0] = __builtin_fmaf(wgt, odd ? pxx : sxx, S0[0]);
       S0[1] = __builtin_fmaf(wgt, odd ? pxy : sxy, S0[1]);
@@ -465,15 +529,9 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
       S1[1] = __builtin_fmaf(wgt, odd ? sxy : pxy, S1[1]);
       S1[2] = __builtin_fmaf(wgt, odd ? syy : pyy, S1[2]);
       // first valid pixel of the segment: its partner (if any) lives in an earlier segment
-      first_w = (ok && !prev_has) ? wgt : first_w;
+      first_w = (ok && rank == 0) ? wgt : first_w;
     }
-    if (bk) {
-      const int top = 63 - __clzll((long long)bk);
-      carry_r0 = u2f(__builtin_amdgcn_readlane(f2u(r0), top));
-      carry_r1 = u2f(__builtin_amdgcn_readlane(f2u(r1), top));
-      carry_has = true;
-    }
-    run_count += __popcll(bk);
+    run_count += n_here;
   };
   // the last pair of steps is peeled so that "is there a next step to prefetch" is a compile-time fact in every copy
   if (!(DVO_ABLATE & 16)) {  // (ablation 16: prologue + epilogue only)
@@ -486,24 +544,46 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
   }
 
   if (DVO_ABLATE & 32) {  // (ablation 32: no epilogue -- keep the accumulators alive, write nothing)
-    DVO_KEEP(S0[0] + S1[0] + first_w + gram_a[0] + gram_b[0] + carry_r0 + (float)run_count);
+    DVO_KEEP(S0[0] + S1[0] + first_w + gram_a[0] + gram_b[0] + g4[0][0] + (float)run_count);
     return;
   }
-  if (ACC == 1 && !(DVO_ABLATE & 1) && steps > 0) gram_from_stage(1);  // the last step (odd index) staged into buffer 1
+  if (ACC >= 1 && !(DVO_ABLATE & 1) && steps > 0) gram_from_stage(1);  // the last step (odd index) staged into buffer 1
 
   // ---- wave reduction, then the four waves of the block through LDS
   __shared__ float sm[kWavesPerBlock][kRecStride];
-  __shared__ float gsm[ACC == 1 ? kWavesPerBlock * 256 : 4];
+  // ACC 2: a wave's 4x4 block sums go to the start of its own staging area (its last reads of it are behind it in the wave's
+  // in-order LDS queue): [row of 16 lanes][type][i][j], 576 floats
+  constexpr int kG4Scratch = 4 * kGram4Types * 16;
+  static_assert(kG4Scratch <= 2 * kWave * 16, "the 4x4 block sums fit a wave's staging area");
   if (ACC == 0) {
 #pragma unroll
     for (int i = 0; i < kNumAcc; ++i) {
       const float s = wave_sum_to_lane63<RMODE>(acc[i]);
       if (lane == 63) sm[wave][kRecAcc + i] = s;
     }
+  } else if (ACC == 2) {
+    // D of block b sits in lanes 4 b .. 4 b + 3 (column j), register i (row): first the four blocks of every 16-lane row
+    // (two DPP row shifts leave the row's sum in its lanes 12..15), then one LDS word per (row, type, i, j)
+    float *scr = stage + wave * 2 * kWave * 16;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < kGram4Types; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v = g4[t][i];
+        v += dpp_read<0x114, 0xF>(v);  // row_shr:4
+        v += dpp_read<0x118, 0xF>(v);  // row_shr:8
+        if ((lane & 15) >= 12) scr[((lane >> 4) * kGram4Types + t) * 16 + i * 4 + (lane & 3)] = v;
+      }
   } else {
     // C/D layout of the 16x16 MFMA: register r of lane l is G[row = (l>>4)*4 + r][col = l&15]
+    // into the start of the wave's own staging area (its reads of it are behind it in the in-order LDS queue)
+    float *gsm = stage + wave * 2 * kWave * 16;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) gsm[wave * 256 + ((lane >> 4) * 4 + r) * 16 + (lane & 15)] = gram_a[r] + gram_b[r];
+    for (int r = 0; r < 4; ++r) gsm[((lane >> 4) * 4 + r) * 16 + (lane & 15)] = gram_a[r] + gram_b[r];
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -514,10 +594,11 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
   {
     const float fw = wave_sum_to_lane63<RMODE>(first_w);
     if (lane == 63) {
+      const v2f last = slots[0];  // the last valid residual of the segment (zeros if there is none)
       sm[wave][kRecFirstW] = fw;
       sm[wave][kRecCount] = u2f((unsigned)run_count);
-      sm[wave][kRecLastR] = carry_r0;
-      sm[wave][kRecLastR + 1] = carry_r1;
+      sm[wave][kRecLastR] = last.x;
+      sm[wave][kRecLastR + 1] = last.y;
     }
   }
   __syncthreads();
@@ -546,8 +627,27 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
         const int q = tid - kAccAR0, grp = q / 6, i = q - grp * 6;  // AR0, AR1, BR0, BR1
         e0 = ((grp >> 1) * 6 + i) * 16 + 12 + (grp & 1);
       }
-      float v = (gsm[e0] + gsm[256 + e0]) + (gsm[512 + e0] + gsm[768 + e0]);
-      if (e1 >= 0) v += (gsm[e1] + gsm[256 + e1]) + (gsm[512 + e1] + gsm[768 + e1]);
+      float v;
+      if (ACC == 2) {
+        // Gram entry (r, c), r <= c, lives in block type (r / 4, c / 4) at (r % 4, c % 4): sum over the 4 waves x 4 rows
+        auto entry = [&](const int e) {
+          const int r = e >> 4, c = e & 15, ga = r >> 2, gb = c >> 2;
+          const int type = gb == 3 ? 6 + ga : (ga == 0 ? gb : (ga == 1 ? 2 + gb : 5));
+          const int off = type * 16 + (r & 3) * 4 + (c & 3);
+          float sum = 0.0f;
+          for (int wv = 0; wv < kWavesPerBlock; ++wv) {
+            const float *scr = stage + wv * 2 * kWave * 16 + off;
+            sum += (scr[0] + scr[kGram4Types * 16]) + (scr[2 * kGram4Types * 16] + scr[3 * kGram4Types * 16]);
+          }
+          return sum;
+        };
+        v = entry(e0);
+        if (e1 >= 0) v += entry(e1);
+      } else {
+        constexpr int kW = 2 * kWave * 16;  // floats between the staging areas of two waves
+        v = (stage[e0] + stage[kW + e0]) + (stage[2 * kW + e0] + stage[3 * kW + e0]);
+        if (e1 >= 0) v += (stage[e1] + stage[kW + e1]) + (stage[2 * kW + e1] + stage[3 * kW + e1]);
+      }
       rec[kRecAcc + tid] = v;
     }
   } else if (tid == 128) {
@@ -707,27 +807,30 @@ __global__ __launch_bounds__(kBlockThreads, OCC) void k_tick_table(const TickIte
 }
 
 static int g_reduce_mode = -1;  // DVO_AMD_REDUCE=0: ds_bpermute butterfly instead of DPP (debug cross-check)
-static int g_acc_mode = -1;     // DVO_AMD_ACCUM=valu: 87 register accumulators instead of the MFMA Gram matrix
-static int g_occ = 4;           // DVO_AMD_OCC=5: compile-time register budget for 5 waves/SIMD (MFMA form only)
+static int g_acc_mode = -1;     // DVO_AMD_ACCUM=valu: 87 register accumulators; =mfma4: the Gram matrix from 4x4 blocks; default: the full 16x16 Gram matrix
+static int g_occ = 4;           // DVO_AMD_OCC=3|4|5: compile-time register budget in waves per SIMD
 
-hipError_t launch_tick(const TickArgs &args, int max_blocks, hipStream_t stream, hipEvent_t t_start, hipEvent_t t_stop) {
+typedef void (*TickKernel)(const TickArgs);
+static TickKernel pick_tick_kernel() {
   if (g_reduce_mode < 0) {
     const char *e = getenv("DVO_AMD_REDUCE");
     g_reduce_mode = (e && e[0] == '0') ? 0 : 1;
     const char *a = getenv("DVO_AMD_ACCUM");
-    g_acc_mode = (a && (a[0] == 'v' || a[0] == 'V' || a[0] == '0')) ? 0 : 1;
+    g_acc_mode = 1;
+    if (a && (a[0] == 'v' || a[0] == 'V' || a[0] == '0')) g_acc_mode = 0;
+    if (a && !strcmp(a, "mfma4")) g_acc_mode = 2;
     const char *o = getenv("DVO_AMD_OCC");
-    g_occ = (o && o[0] == '5') ? 5 : 4;
+    g_occ = (o && o[0] == '5') ? 5 : (o && o[0] == '3') ? 3 : 4;
   }
+  if (g_acc_mode == 0) return g_reduce_mode == 0 ? k_tick<0, 0, 2> : k_tick<1, 0, 2>;
+  if (g_acc_mode == 1) return g_occ == 5 ? k_tick<1, 1, 5> : g_reduce_mode == 0 ? k_tick<0, 1, 4> : k_tick<1, 1, 4>;
+  return g_occ == 3 ? k_tick<1, 2, 3> : g_occ == 5 ? k_tick<1, 2, 5> : k_tick<1, 2, 4>;
+}
+
+hipError_t launch_tick(const TickArgs &args, int max_blocks, hipStream_t stream, hipEvent_t t_start, hipEvent_t t_stop) {
+  TickKernel kernel = pick_tick_kernel();
   if (args.n_items <= 0 || max_blocks <= 0) return hipSuccess;
   dim3 grid((unsigned)((max_blocks + 7) & ~7), (unsigned)args.n_items, 1);
-  void (*kernel)(const TickArgs) = k_tick<1, 1, 4>;
-  if (g_acc_mode == 0)
-    kernel = g_reduce_mode == 0 ? k_tick<0, 0, 2> : k_tick<1, 0, 2>;
-  else if (g_occ == 5)
-    kernel = k_tick<1, 1, 5>;
-  else if (g_reduce_mode == 0)
-    kernel = k_tick<0, 1, 4>;
   if (t_start && t_stop) {
     void *kargs[] = {const_cast<TickArgs *>(&args)};
     const hipError_t e = hipExtLaunchKernel(reinterpret_cast<const void *>(kernel), grid, dim3(kBlockThreads), kargs, 0, stream,
@@ -804,12 +907,6 @@ __device__ unsigned long long g_fin_stamps[8];
     if (args.pad == 0x57A3 && blockIdx.x == 0 && threadIdx.x == 0) g_fin_stamps[i] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 
-// wave-local LDS hand-off: the LDS queue of a wave is in order, the fences only pin the compiler
-#define DVO_WAVE_LDS_SYNC()                                 \
-  do {                                                      \
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  \
-    __builtin_amdgcn_wave_barrier();                        \
-  } while (0)
 
 // One block per job.  Wave 0 folds the ordered part of the block records (count, S under both start parities, boundary
 // residual / weight) left to right and locates the log-likelihood cut; threads 256.. sum the 87 moments and the

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -131,7 +132,9 @@ struct dvo_amd_pyramid {
   CurLevelDesc *cur_desc = nullptr;   // device, [levels], inside the slab
   RefLevelDesc *ref_desc0 = nullptr;  // device, [levels], inside the slab: room for the first selection's descriptors
   std::mutex mu;
-  std::vector<Selection> selections;
+  // entries are never moved or removed while the pyramid lives: a pointer handed out by pyramid_selection() stays valid and may
+  // be read without the lock (only the vector itself needs `mu`)
+  std::vector<std::unique_ptr<Selection>> selections;
 };
 
 namespace {
@@ -159,6 +162,7 @@ size_t pyramid_layout(dvo_amd_pyramid *p, char *base) {
   p->counters = (int *)carve(sizeof(int) * 2 * DVO_AMD_MAX_LEVELS);
   p->cur_desc = (CurLevelDesc *)carve(sizeof(CurLevelDesc) * DVO_AMD_MAX_LEVELS);
   p->ref_desc0 = (RefLevelDesc *)carve(sizeof(RefLevelDesc) * DVO_AMD_MAX_LEVELS);
+  (void)carve(8192);  // tail: the residual pass touches (prefetches) up to 2 KB past the planes it reads
   return off;
 }
 
@@ -302,18 +306,19 @@ int pyramid_build(int device, const float *src_i, const float *src_z, const RawF
 
 // PointSelection::select for every level, cached per threshold pair (the reference caches per PointSelection object until
 // setRgbdImagePyramid, point_selection.cpp:51-59,100; pyramids are immutable here, so the cache never goes stale)
-int pyramid_selection(dvo_amd_pyramid *p, float ti, float td, int *index) {
+int pyramid_selection(dvo_amd_pyramid *p, float ti, float td, const Selection **out) {
   std::lock_guard<std::mutex> lk(p->mu);
   for (size_t i = 0; i < p->selections.size(); ++i)
-    if (p->selections[i].ti == ti && p->selections[i].td == td) {
-      *index = (int)i;
+    if (p->selections[i]->ti == ti && p->selections[i]->td == td) {
+      *out = p->selections[i].get();
       return DVO_AMD_OK;
     }
   HIP_TRY(hipSetDevice(p->device));
   hipStream_t st;
   int rc = device_prep_stream(p->device, &st);
   if (rc) return rc;
-  Selection s;
+  std::unique_ptr<Selection> sp(new Selection());
+  Selection &s = *sp;
   s.ti = ti, s.td = td, s.extra_slab = nullptr, s.extra_bytes = 0;
   if (p->selections.empty()) {
     for (int l = 0; l < p->n_levels; ++l) s.zsel[l] = p->lv[l].zsel0;
@@ -321,6 +326,7 @@ int pyramid_selection(dvo_amd_pyramid *p, float ti, float td, int *index) {
   } else {
     size_t bytes = align_up(sizeof(RefLevelDesc) * DVO_AMD_MAX_LEVELS, 256);
     for (int l = 0; l < p->n_levels; ++l) bytes += align_up(sizeof(float) * p->lv[l].n_pad, 256);
+    bytes += 8192;  // tail: the residual pass prefetches a little past the plane it reads
     HIP_TRY(hipMalloc(&s.extra_slab, bytes));
     s.extra_bytes = bytes;
     s.ref_desc = (RefLevelDesc *)s.extra_slab;
@@ -330,6 +336,12 @@ int pyramid_selection(dvo_amd_pyramid *p, float ti, float td, int *index) {
       off += align_up(sizeof(float) * p->lv[l].n_pad, 256);
     }
   }
+  // any failure below must not leak the selection's own allocation
+  auto fail = [&](const char *what, hipError_t e) {
+    (void)hipStreamSynchronize(st);
+    if (s.extra_slab) (void)hipFree(s.extra_slab);
+    return fail_hip(what, e);
+  };
   RefLevelDesc ref_host[DVO_AMD_MAX_LEVELS];
   std::memset(ref_host, 0, sizeof(ref_host));
   for (int l = 0; l < p->n_levels; ++l) {
@@ -338,18 +350,21 @@ int pyramid_selection(dvo_amd_pyramid *p, float ti, float td, int *index) {
     ref_host[l].r_i = R.r_i, ref_host[l].r_ix = R.r_ix, ref_host[l].r_iy = R.r_iy;
     ref_host[l].tx = R.tx, ref_host[l].ty = R.ty;
   }
-  HIP_TRY(hipMemcpyAsync(s.ref_desc, ref_host, sizeof(RefLevelDesc) * p->n_levels, hipMemcpyHostToDevice, st));
+  hipError_t e = hipMemcpyAsync(s.ref_desc, ref_host, sizeof(RefLevelDesc) * p->n_levels, hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return fail("selection descriptors", e);
   for (int l = 0; l < p->n_levels; ++l) {
     const LevelData &L = p->lv[l];
-    hipError_t e = launch_select(L.z_plane, L.c_a, L.c_b, L.n, L.n_pad, ti, td, s.zsel[l], p->counters + 2 * l, st);
-    if (e != hipSuccess) return fail_hip("select", e);
+    e = launch_select(L.z_plane, L.c_a, L.c_b, L.n, L.n_pad, ti, td, s.zsel[l], p->counters + 2 * l, st);
+    if (e != hipSuccess) return fail("select", e);
   }
   int host_counters[2 * DVO_AMD_MAX_LEVELS];
-  HIP_TRY(hipMemcpyAsync(host_counters, p->counters, sizeof(int) * 2 * p->n_levels, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  e = hipMemcpyAsync(host_counters, p->counters, sizeof(int) * 2 * p->n_levels, hipMemcpyDeviceToHost, st);
+  if (e != hipSuccess) return fail("selection counters", e);
+  e = hipStreamSynchronize(st);  // (also keeps ref_host alive until the copy has read it)
+  if (e != hipSuccess) return fail("selection", e);
   for (int l = 0; l < p->n_levels; ++l) s.count[l] = host_counters[2 * l], s.last[l] = host_counters[2 * l + 1];
-  p->selections.push_back(s);
-  *index = (int)p->selections.size() - 1;
+  p->selections.push_back(std::move(sp));
+  *out = p->selections.back().get();
   return DVO_AMD_OK;
 }
 
@@ -384,6 +399,7 @@ struct dvo_amd_context {
   // item tables for launches with more pairs than the kernel-argument block holds: per tick stream a pinned host staging
   // area and its device copy (uploaded in-stream in front of the launch)
   TickItem *item_host = nullptr, *item_dev = nullptr;  // [kMaxTickStreams][kMaxTableItems]
+  int stage_owner[kMaxTickStreams] = {0, 0, 0, 0, 0, 0, 0, 0};  // pair group (id + 1) whose table upload last used a staging slot
   int items_per_launch = kMaxItemsPerLaunch;           // DVO_AMD_ITEMS_PER_LAUNCH (<= kMaxTableItems)
   bool spec_levels = false;                            // DVO_AMD_SPEC_LEVELS=1: start the next level speculatively in the tick of a
                                                        // level's last likelihood (-2..3 ticks per pair, but a converged level's last
@@ -402,6 +418,7 @@ struct dvo_amd_context {
   ncclResult_t (*p_allgather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*p_comm_destroy)(ncclComm_t) = nullptr;
   unsigned tick_seq = 0;
+  int fault_slot_alloc = -1;           // DVO_AMD_FAULT_SLOT_ALLOC: fail the allocation of this slot once (tests of the error path)
   bool fin_stamps = false;             // DVO_AMD_FIN_STAMPS=1: k_finalize records phase stamps (diagnostic)
   bool poll = true;                    // wait for a tick by polling the records' sequence words instead of hipStreamSynchronize
   // optional kernel timing (bench.py roofline section)
@@ -440,7 +457,7 @@ struct IterCtx {
 
 struct Job {
   dvo_amd_pyramid *ref = nullptr, *cur = nullptr;
-  int sel = 0;
+  const Selection *sel = nullptr;  // stable for the life of `ref` (pyramid_selection)
   dvo_amd_result *result = nullptr;
   JobSlot *slot = nullptr;
   const dvo_amd_config *cfg = nullptr;
@@ -550,7 +567,7 @@ void end_level(Job &j) {
 void start_level(Job &j) {
   dvo_amd_result *r = j.result;
   dvo_amd_level_stats &ls = r->levels[r->n_levels++];
-  const Selection &sel = j.ref->selections[j.sel];
+  const Selection &sel = *j.sel;
   const LevelData &L0 = j.ref->lv[0];
   ls.id = j.level;
   // PointSelection::getMaximumNumberOfPoints, point_selection.cpp:68-71
@@ -728,23 +745,29 @@ void process_loglik(Job &j, const FinOut *outs) {
   process_residual(j, b, o);
 }
 
-int ensure_slots(dvo_amd_context *ctx, int n_jobs, int n_pad) {
-  if ((int)ctx->slots.size() >= n_jobs && ctx->slot_n_pad >= n_pad) return DVO_AMD_OK;
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  for (hipStream_t st : ctx->extra_streams) HIP_TRY(hipStreamSynchronize(st));
-  const int new_pad = std::max(n_pad, ctx->slot_n_pad);
+// frees every slot and forgets the capacity, so that the next ensure_slots() rebuilds from scratch
+void release_slots(dvo_amd_context *ctx) {
   for (JobSlot &s : ctx->slots)
     if (s.dev_block) (void)hipFree(s.dev_block);
   ctx->slots.clear();
+  if (ctx->slot_desc) (void)hipFree(ctx->slot_desc);
+  ctx->slot_desc = nullptr;
+  ctx->slot_n_pad = 0;
+}
+
+int ensure_slots_impl(dvo_amd_context *ctx, int n_jobs, int n_pad) {
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (hipStream_t st : ctx->extra_streams) HIP_TRY(hipStreamSynchronize(st));
+  const int new_pad = std::max(n_pad, ctx->slot_n_pad);
+  release_slots(ctx);
   const int n_slots = std::max(n_jobs, 1);
   if (ctx->out_capacity < n_slots) {
     if (ctx->out_host) (void)hipHostFree(ctx->out_host);
     ctx->out_host = nullptr;
+    ctx->out_capacity = 0;
     HIP_TRY(hipHostMalloc((void **)&ctx->out_host, sizeof(FinOut) * n_slots, hipHostMallocMapped | hipHostMallocCoherent));
     ctx->out_capacity = n_slots;
   }
-  if (ctx->slot_desc) (void)hipFree(ctx->slot_desc);
-  ctx->slot_desc = nullptr;
   HIP_TRY(hipMalloc((void **)&ctx->slot_desc, sizeof(SlotDesc) * n_slots));
   if (!ctx->tickets) {
     HIP_TRY(hipMalloc((void **)&ctx->tickets, sizeof(unsigned) * 16 * kMaxTickStreams));
@@ -761,6 +784,10 @@ int ensure_slots(dvo_amd_context *ctx, int n_jobs, int n_pad) {
   ctx->slots.resize(n_slots);
   for (int i = 0; i < n_slots; ++i) {
     JobSlot &s = ctx->slots[i];
+    if (i == ctx->fault_slot_alloc) {  // DVO_AMD_FAULT_SLOT_ALLOC=i (tests): this allocation fails once
+      ctx->fault_slot_alloc = -1;
+      return fail_hip("slot allocation (injected fault)", hipErrorOutOfMemory);
+    }
     HIP_TRY(hipMalloc(&s.dev_block, total));
     char *p = (char *)s.dev_block;
     s.res[0] = (float2 *)p, p += b_res;
@@ -781,8 +808,18 @@ int ensure_slots(dvo_amd_context *ctx, int n_jobs, int n_pad) {
   }
   HIP_TRY(hipMemcpy(ctx->slot_desc, slot_host.data(), sizeof(SlotDesc) * n_slots, hipMemcpyHostToDevice));
   ctx->tick_seq = 0;
-  ctx->slot_n_pad = new_pad;
+  ctx->slot_n_pad = new_pad;  // set last: only a completely built set of slots counts as capacity
   return DVO_AMD_OK;
+}
+
+// Scratch for n_jobs resident pairs of up to n_pad padded pixels.  Failure atomic: if any allocation fails, everything built
+// so far is released and the recorded capacity is zero, so a retry (e.g. with fewer resident pairs after
+// DVO_AMD_ERR_OUT_OF_MEMORY) rebuilds instead of launching on half-initialised slots.
+int ensure_slots(dvo_amd_context *ctx, int n_jobs, int n_pad) {
+  if ((int)ctx->slots.size() >= n_jobs && ctx->slot_n_pad >= n_pad && ctx->slot_n_pad > 0) return DVO_AMD_OK;
+  const int rc = ensure_slots_impl(ctx, n_jobs, n_pad);
+  if (rc) release_slots(ctx);
+  return rc;
 }
 
 int pick_rounds(long long total_px) {
@@ -883,6 +920,7 @@ int wait_tick(dvo_amd_context *ctx, const std::vector<Job> &jobs, size_t lo, siz
 struct GroupTick {
   size_t lo = 0, hi = 0;
   size_t stream_first = 0;  // tick stream of the group's first launch
+  int id = 0;
   unsigned seq = 0;
   bool in_flight = false;
 };
@@ -922,7 +960,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
     TickItem w;
     std::memset(&w, 0, sizeof(w));
     int res_rounds = 1, ll_rounds = 1;
-    w.ref = j.ref->selections[j.sel].ref_desc + j.level;
+    w.ref = j.sel->ref_desc + j.level;
     w.cur = j.cur->cur_desc + j.level;
     w.slot = ctx->slot_desc + slot_index;
     FinItem f;
@@ -951,7 +989,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
       f.n_blocks = w.res_blocks;
       f.seg_prefix_out = j.slot->seg_prefix[j.b.buf];
       j.sub_res = true;
-      j.sub_px = (double)j.ref->selections[j.sel].count[j.level];
+      j.sub_px = (double)j.sel->count[j.level];
       j.result->n_residual_passes++;
       j.alg_px += j.sub_px;
     } else if (wants_spec(j)) {
@@ -961,7 +999,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
       j.spec_b.rounds = rounds_now;
       while (j.spec_b.rounds < kMaxRounds && blocks_for(j.ref->lv[nl].n, j.spec_b.rounds) > 2048) j.spec_b.rounds *= 2;
       j.spec_b.n_blocks = blocks_for(j.ref->lv[nl].n, j.spec_b.rounds);
-      w.ref = j.ref->selections[j.sel].ref_desc + nl;  // the likelihood pass only uses the slot's buffers
+      w.ref = j.sel->ref_desc + nl;  // the likelihood pass only uses the slot's buffers
       w.cur = j.cur->cur_desc + nl;
       w.res_blocks = (uint16_t)j.spec_b.n_blocks;
       w.res_phys = w.res_blocks;
@@ -974,7 +1012,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
       f.seg_prefix_out = j.slot->seg_prefix[j.spec_b.buf];
       j.have_spec = true;
       j.sub_res = true;
-      j.sub_px = (double)j.ref->selections[j.sel].count[nl];
+      j.sub_px = (double)j.sel->count[nl];
       j.result->n_residual_passes++;
       j.alg_px += j.sub_px;
     }
@@ -1024,8 +1062,15 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
       stage[i].res_phys = (uint16_t)std::min<int>(stage[i].res_blocks, ((stage[i].res_blocks + walk - 1) / walk + 7) & ~7);
       max_blocks = std::max(max_blocks, (int)stage[i].res_phys + (int)stage[i].ll_blocks);
     }
-    if (use_table && launch_index >= kMaxTickStreams) HIP_TRY(hipStreamSynchronize(st));  // staging of this stream is still in use
-    if (use_table)  // otherwise the staging area is free: the tick that used it has been waited for
+    if (use_table) {
+      // The staging slot (and its stream) is shared with whatever launch maps to the same index.  Within one group the tick
+      // that used it has been waited for; a second lap of this tick's launches, or another group's launch that may still be
+      // in flight (groups with more than one launch each), must drain first: the async upload reads the pinned area later.
+      if (launch_index >= (size_t)kMaxTickStreams || (ctx->stage_owner[stream_slot] != 0 && ctx->stage_owner[stream_slot] != grp.id + 1))
+        HIP_TRY(hipStreamSynchronize(st));
+      ctx->stage_owner[stream_slot] = grp.id + 1;
+    }
+    if (use_table)
       HIP_TRY(hipMemcpyAsync(ctx->item_dev + stream_slot * kMaxTableItems, stage, sizeof(TickItem) * (size_t)n_here,
                              hipMemcpyHostToDevice, st));
     size_t ev = 0;
@@ -1160,14 +1205,14 @@ int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, i
   if (j.have_b) {
     j.b.rounds = 1, j.b.n_blocks = nb_level;
     j.result->n_residual_passes++;
-    j.alg_px += (double)j.ref->selections[j.sel].count[j.level];
+    j.alg_px += (double)j.sel->count[j.level];
   }
   j.result->n_ticks++;
   int max_blocks = 0;
   for (int li = 0; li < n_local; ++li) {
     const int band = band_first + li;
     TickItem &w = ta.items[li];
-    w.ref = j.ref->selections[j.sel].ref_desc + j.level;
+    w.ref = j.sel->ref_desc + j.level;
     w.cur = j.cur->cur_desc + j.level;
     w.slot = ctx->slot_desc;  // every band works in slot 0's buffers (logical block indexing), disjoint ranges
     FinItem &f = fa.items[li];
@@ -1353,6 +1398,7 @@ int dvo_amd_context_create(int device, const dvo_amd_config *cfg, dvo_amd_contex
   const char *hp = getenv("DVO_AMD_HOST_PROF");
   ctx->host_prof = hp && hp[0] == '1';
   if (const char *sl = getenv("DVO_AMD_SPEC_LEVELS")) ctx->spec_levels = sl[0] == '1';
+  if (const char *fs2 = getenv("DVO_AMD_FAULT_SLOT_ALLOC")) ctx->fault_slot_alloc = atoi(fs2);
   if (const char *pb = getenv("DVO_AMD_PHYS_BLOCKS")) {
     const int v = atoi(pb);
     if (v >= 64) ctx->phys_block_target = v;
@@ -1381,10 +1427,8 @@ void dvo_amd_context_destroy(dvo_amd_context *ctx) {
     (void)hipStreamDestroy(st);
   }
   if (ctx->desc_ready) (void)hipEventDestroy(ctx->desc_ready);
-  for (JobSlot &s : ctx->slots)
-    if (s.dev_block) (void)hipFree(s.dev_block);
+  release_slots(ctx);
   if (ctx->out_host) (void)hipHostFree(ctx->out_host);
-  if (ctx->slot_desc) (void)hipFree(ctx->slot_desc);
   if (ctx->tickets) (void)hipFree(ctx->tickets);
   if (ctx->item_host) (void)hipHostFree(ctx->item_host);
   if (ctx->item_dev) (void)hipFree(ctx->item_dev);
@@ -1439,8 +1483,8 @@ void dvo_amd_pyramid_release(dvo_amd_pyramid *p) {
   if (!p) return;
   if (p->refs.fetch_sub(1) != 1) return;
   (void)hipSetDevice(p->device);
-  for (Selection &s : p->selections)
-    if (s.extra_slab) (void)hipFree(s.extra_slab);
+  for (auto &s : p->selections)
+    if (s->extra_slab) (void)hipFree(s->extra_slab);
   slab_free(p->device, p->slab_bytes, p->slab);
   delete p;
 }
@@ -1476,14 +1520,10 @@ int dvo_amd_pyramid_download_plane(const dvo_amd_pyramid *p, int level, int plan
 
 int dvo_amd_pyramid_select(dvo_amd_pyramid *p, int level, float ti, float td, int *count, unsigned char *mask) {
   if (!p || level < 0 || level >= p->n_levels) return DVO_AMD_ERR_INVALID_ARGUMENT;
-  int idx = 0;
-  int rc = pyramid_selection(p, ti, td, &idx);
+  const Selection *sp = nullptr;
+  int rc = pyramid_selection(p, ti, td, &sp);
   if (rc) return rc;
-  Selection s;
-  {
-    std::lock_guard<std::mutex> lk(p->mu);
-    s = p->selections[idx];
-  }
+  const Selection &s = *sp;
   if (count) *count = s.count[level];
   if (mask) {
     HIP_TRY(hipSetDevice(p->device));
@@ -1552,14 +1592,21 @@ int dvo_amd_match_many(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *refe
     groups[(size_t)g].lo = (size_t)std::min(g * per_group, in_flight);
     groups[(size_t)g].hi = (size_t)std::min((g + 1) * per_group, in_flight);
     groups[(size_t)g].stream_first = (size_t)g;
+    groups[(size_t)g].id = g;
   }
+  // on an error return no kernel of this call may still be running: the caller is free to release the pyramids
+  auto drain = [&](int code) {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (hipStream_t st : ctx->extra_streams) (void)hipStreamSynchronize(st);
+    return code;
+  };
   int next = 0, finished = 0;
   int g = 0;
   while (finished < n) {
     GroupTick &grp = groups[(size_t)g];
     g = (g + 1) % n_groups;
     rc = complete_tick(ctx, jobs, grp);
-    if (rc) return rc;
+    if (rc) return drain(rc);
     for (size_t sidx = grp.lo; sidx < grp.hi; ++sidx)
       if (jobs[sidx].done && job_of_slot[sidx] >= 0) {
         job_of_slot[sidx] = -1;
@@ -1575,7 +1622,7 @@ int dvo_amd_match_many(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *refe
       j.slot = &ctx->slots[sidx];
       j.cfg = &ctx->cfg;
       rc = pyramid_selection(j.ref, cfg.intensity_derivative_threshold, cfg.depth_derivative_threshold, &j.sel);
-      if (rc) return rc;
+      if (rc) return drain(rc);
       dvo_amd_result *r = j.result;
       r->n_levels = 0, r->n_iterations = 0, r->n_ticks = 0, r->n_residual_passes = 0, r->alg_bytes = 0.0, r->is_nan = 0;
       if (!r->iterations) r->iterations_capacity = 0;
@@ -1589,7 +1636,7 @@ int dvo_amd_match_many(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *refe
       start_level(j);
     }
     rc = submit_tick(ctx, jobs, grp);
-    if (rc) return rc;
+    if (rc) return drain(rc);
   }
   return DVO_AMD_OK;
 }
@@ -1648,8 +1695,12 @@ int dvo_amd_comm_create(dvo_amd_context *ctx, const unsigned char *id128, int nr
     return DVO_AMD_ERR_COMM;
   }
   ctx->comm_ranks = nranks, ctx->comm_rank = rank;
-  HIP_TRY(hipMalloc((void **)&ctx->gather_dev, sizeof(FinOut) * kMaxBands));
-  HIP_TRY(hipHostMalloc((void **)&ctx->gather_host, sizeof(FinOut) * kMaxBands, hipHostMallocDefault));
+  hipError_t e = hipMalloc((void **)&ctx->gather_dev, sizeof(FinOut) * kMaxBands);
+  if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->gather_host, sizeof(FinOut) * kMaxBands, hipHostMallocDefault);
+  if (e != hipSuccess) {  // never leave a communicator behind whose exchange buffers do not exist
+    dvo_amd_comm_destroy(ctx);
+    return fail_hip("communicator buffers", e);
+  }
   return DVO_AMD_OK;
 }
 
@@ -1696,10 +1747,24 @@ int dvo_amd_match(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyra
   return dvo_amd_match_batch(ctx, 1, r, c, T_init, result);
 }
 
+int dvo_amd_match_selection(dvo_amd_context *ctx, dvo_amd_pyramid *reference, float intensity_threshold, float depth_threshold,
+                            dvo_amd_pyramid *current, const double *T_init, dvo_amd_result *result) {
+  if (!ctx) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  // the PointSelection's predicate decides which reference pixels take part, not the tracker's configuration
+  // (dense_tracking.cpp:131,226: reference.select(level)); a context is single-threaded by contract
+  const float keep_i = ctx->cfg.intensity_derivative_threshold, keep_d = ctx->cfg.depth_derivative_threshold;
+  ctx->cfg.intensity_derivative_threshold = intensity_threshold;
+  ctx->cfg.depth_derivative_threshold = depth_threshold;
+  const int rc = dvo_amd_match(ctx, reference, current, T_init, result);
+  ctx->cfg.intensity_derivative_threshold = keep_i;
+  ctx->cfg.depth_derivative_threshold = keep_d;
+  return rc;
+}
+
 namespace {
 // One k_tick + k_finalize over slot 0 outside the match driver (the stage-wise parity entries): optionally the residual pass
 // at the float transform T (into residual buffer 0) and / or the log-likelihood pass over residual buffer 0.
-int single_tick(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, int level, int sel, const float *T,
+int single_tick(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, int level, const Selection *sel, const float *T,
                 const float P[4], bool unit_weights, bool residual_pass, bool loglik_pass, int ll_cut_rank) {
   const LevelData &R = reference->lv[level];
   const LevelData &C = current->lv[level];
@@ -1708,10 +1773,7 @@ int single_tick(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyrami
   std::memset(&ta, 0, sizeof(ta));
   ta.n_items = 1;
   TickItem &w = ta.items[0];
-  {
-    std::lock_guard<std::mutex> lk(reference->mu);
-    w.ref = reference->selections[(size_t)sel].ref_desc + level;
-  }
+  w.ref = sel->ref_desc + level;
   w.cur = current->cur_desc + level;
   w.slot = ctx->slot_desc;
   int rounds = 1;
@@ -1768,7 +1830,7 @@ int dvo_amd_residuals(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_
   if (rc) return rc;
   const LevelData &R = reference->lv[level];
   HIP_TRY(hipSetDevice(ctx->device));
-  int sel = 0;
+  const Selection *sel = nullptr;
   rc = pyramid_selection(reference, ctx->cfg.intensity_derivative_threshold, ctx->cfg.depth_derivative_threshold, &sel);
   if (rc) return rc;
   rc = ensure_slots(ctx, 1, R.n_pad);
@@ -1783,13 +1845,14 @@ int dvo_amd_residuals(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_
 }
 
 int dvo_amd_debug_iteration(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, int level,
-                            const float *T, const float *precision_in, dvo_amd_iteration_probe *out) {
+                            const float *T, const float *precision_in, const float *precision_eval,
+                            dvo_amd_iteration_probe *out) {
   if (!ctx || !reference || !current || !T || !out || level < 0) return DVO_AMD_ERR_INVALID_ARGUMENT;
   int rc = check_level_pair(ctx, reference, current, level);
   if (rc) return rc;
   const LevelData &R = reference->lv[level];
   HIP_TRY(hipSetDevice(ctx->device));
-  int sel = 0;
+  const Selection *sel = nullptr;
   rc = pyramid_selection(reference, ctx->cfg.intensity_derivative_threshold, ctx->cfg.depth_derivative_threshold, &sel);
   if (rc) return rc;
   rc = ensure_slots(ctx, 1, R.n_pad);
@@ -1808,6 +1871,9 @@ int dvo_amd_debug_iteration(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dv
   scale_and_precision(o, o.valid, cov, P);
   std::memcpy(out->scale, cov, sizeof(cov));
   std::memcpy(out->precision, P, sizeof(P));
+  // the normal equations and the likelihood are evaluated with this iteration's precision -- the one just computed, or the
+  // caller's (a checker that wants to separate "is P right" from "are the sums right" passes its own)
+  if (precision_eval) std::memcpy(P, precision_eval, sizeof(P));
   const double zero6[6] = {0, 0, 0, 0, 0, 0};
   system_from_moments(o, P, 0.0, zero6, out->information, out->rhs);
   // tick 2: the log-likelihood of the same residuals under the new precision, cut at 50 * floor(V / 50) (Q6)
@@ -1836,29 +1902,31 @@ int dvo_amd_error_image(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_am
   return DVO_AMD_OK;
 }
 
-int dvo_amd_bench_residual_pass(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, int level,
-                                const float *T, int n_items, int rounds, int reps, double *avg_ms, double *alg_bytes,
-                                int *n_launches) {
-  if (!ctx || !reference || !current || !T || level < 0 || n_items < 1 || n_items > 1024 || reps < 1)
+int dvo_amd_bench_residual_pass_pairs(dvo_amd_context *ctx, int n_items, dvo_amd_pyramid *const *references,
+                                      dvo_amd_pyramid *const *currents, int level, const float *T, int rounds, int reps,
+                                      double *avg_ms, double *alg_bytes, int *n_launches) {
+  if (!ctx || !references || !currents || !T || level < 0 || n_items < 1 || n_items > 1024 || reps < 1)
     return DVO_AMD_ERR_INVALID_ARGUMENT;
-  if (level >= reference->n_levels || level >= current->n_levels) return DVO_AMD_ERR_TOO_FEW_LEVELS;
-  if (reference->device != ctx->device || current->device != ctx->device) return DVO_AMD_ERR_DEVICE_MISMATCH;
-  const LevelData &R = reference->lv[level];
-  const LevelData &C = current->lv[level];
-  if (R.w != C.w || R.h != C.h) return DVO_AMD_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(ctx->device));
-  int sel = 0;
-  int rc = pyramid_selection(reference, ctx->cfg.intensity_derivative_threshold, ctx->cfg.depth_derivative_threshold, &sel);
-  if (rc) return rc;
-  rc = ensure_slots(ctx, n_items, R.n_pad);
+  std::vector<const Selection *> sels((size_t)n_items);
+  double px = 0.0;
+  for (int i = 0; i < n_items; ++i) {
+    if (!references[i] || !currents[i]) return DVO_AMD_ERR_INVALID_ARGUMENT;
+    int rc = check_level_pair(ctx, references[i], currents[i], level);
+    if (rc) return rc;
+    if (references[i]->lv[level].n != references[0]->lv[level].n) return DVO_AMD_ERR_INVALID_ARGUMENT;
+    rc = pyramid_selection(references[i], ctx->cfg.intensity_derivative_threshold, ctx->cfg.depth_derivative_threshold, &sels[(size_t)i]);
+    if (rc) return rc;
+    px += (double)sels[(size_t)i]->count[level];
+  }
+  const LevelData &R = references[0]->lv[level];
+  int rc = ensure_slots(ctx, n_items, R.n_pad);
   if (rc) return rc;
   if (rounds <= 0) rounds = pick_rounds((long long)R.n * n_items);
   if (rounds != 1 && rounds != 2 && rounds != 4 && rounds != 8 && rounds != 16) return DVO_AMD_ERR_INVALID_ARGUMENT;
   while (rounds < kMaxRounds && blocks_for(R.n, rounds) > 2048) rounds *= 2;
   TickItem proto;
   std::memset(&proto, 0, sizeof(proto));
-  proto.ref = reference->selections[sel].ref_desc + level;
-  proto.cur = current->cur_desc + level;
   item_set_rounds(proto, rounds, 1);
   proto.res_blocks = (uint16_t)blocks_for(R.n, rounds);
   {
@@ -1868,10 +1936,6 @@ int dvo_amd_bench_residual_pass(dvo_amd_context *ctx, dvo_amd_pyramid *reference
   }
   proto.flags = 0;
   proto.P[0] = 1500.0f, proto.P[3] = 7000.0f;  // a typical precision: the weights take the non-trivial branch
-  const float K[9] = {C.fx, 0.0f, C.ox, 0.0f, C.fy, C.oy, 0.0f, 0.0f, 1.0f};
-  for (int i = 0; i < 3; ++i)
-    for (int cc = 0; cc < 4; ++cc)
-      proto.kt[i * 4 + cc] = (K[i * 3 + 0] * T[cc * 4 + 0] + K[i * 3 + 1] * T[cc * 4 + 1]) + K[i * 3 + 2] * T[cc * 4 + 2];
   const int launches = (n_items + kMaxItemsPerLaunch - 1) / kMaxItemsPerLaunch;
   const int per = (n_items + launches - 1) / launches;
   hipEvent_t e0, e1;
@@ -1884,8 +1948,16 @@ int dvo_amd_bench_residual_pass(dvo_amd_context *ctx, dvo_amd_pyramid *reference
       ta.n_items = std::min(per, n_items - first);
       ta.pad = 0;
       for (int i = 0; i < ta.n_items; ++i) {
-        ta.items[i] = proto;
-        ta.items[i].slot = ctx->slot_desc + (first + i);
+        TickItem &w = ta.items[i];
+        w = proto;
+        const LevelData &C = currents[first + i]->lv[level];
+        w.ref = sels[(size_t)(first + i)]->ref_desc + level;
+        w.cur = currents[first + i]->cur_desc + level;
+        w.slot = ctx->slot_desc + (first + i);
+        const float K[9] = {C.fx, 0.0f, C.ox, 0.0f, C.fy, C.oy, 0.0f, 0.0f, 1.0f};
+        for (int r = 0; r < 3; ++r)
+          for (int cc = 0; cc < 4; ++cc)
+            w.kt[r * 4 + cc] = (K[r * 3 + 0] * T[cc * 4 + 0] + K[r * 3 + 1] * T[cc * 4 + 1]) + K[r * 3 + 2] * T[cc * 4 + 2];
       }
       hipError_t e = launch_tick(ta, proto.res_phys, ctx->stream, e0, e1);  // stamped by the dispatch itself
       if (e != hipSuccess) return fail_hip("launch_tick", e);
@@ -1898,9 +1970,17 @@ int dvo_amd_bench_residual_pass(dvo_amd_context *ctx, dvo_amd_pyramid *reference
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   if (avg_ms) *avg_ms = total_ms / reps;
-  if (alg_bytes) *alg_bytes = 56.0 * (double)reference->selections[sel].count[level] * n_items;
+  if (alg_bytes) *alg_bytes = 56.0 * px;
   if (n_launches) *n_launches = launches;
   return DVO_AMD_OK;
+}
+
+int dvo_amd_bench_residual_pass(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, int level,
+                                const float *T, int n_items, int rounds, int reps, double *avg_ms, double *alg_bytes,
+                                int *n_launches) {
+  if (n_items < 1 || n_items > 1024) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  std::vector<dvo_amd_pyramid *> r((size_t)n_items, reference), c((size_t)n_items, current);
+  return dvo_amd_bench_residual_pass_pairs(ctx, n_items, r.data(), c.data(), level, T, rounds, reps, avg_ms, alg_bytes, n_launches);
 }
 
 int dvo_amd_debug_finalize_stamps(dvo_amd_context *ctx, unsigned long long *stamps8) {

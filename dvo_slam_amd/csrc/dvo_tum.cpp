@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <new>
 #include <vector>
 
 #include "../../include/dvo_amd.h"
@@ -38,7 +39,7 @@ int paeth(int a, int b, int c) {
   return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
 
-int png_load(const char *path, bool header_only, Png *out) {
+int png_load_impl(const char *path, bool header_only, Png *out) {
   if (!path) return DVO_AMD_ERR_INVALID_ARGUMENT;
   FILE *f = std::fopen(path, "rb");
   if (!f) return DVO_AMD_ERR_IO;
@@ -64,7 +65,11 @@ int png_load(const char *path, bool header_only, Png *out) {
       out->bit_depth = data[8], out->color_type = data[9];
       interlace = data[12];
       out->channels = channels_of(out->color_type);
-      if (out->width <= 0 || out->height <= 0 || out->channels == 0 || data[10] != 0 || data[11] != 0) return DVO_AMD_ERR_FORMAT;
+      // sensor frames are a few thousand pixels a side: anything beyond 16384 is a corrupt or hostile header, and the cap keeps
+      // (stride + 1) * height far inside size_t
+      if (out->width <= 0 || out->height <= 0 || out->width > 16384 || out->height > 16384 || out->channels == 0 ||
+          data[10] != 0 || data[11] != 0)
+        return DVO_AMD_ERR_FORMAT;
       const int bd = out->bit_depth;
       const bool ok = (out->color_type == 0 && (bd == 1 || bd == 2 || bd == 4 || bd == 8 || bd == 16)) ||
                       (out->color_type == 3 && (bd == 1 || bd == 2 || bd == 4 || bd == 8)) ||
@@ -113,6 +118,17 @@ int png_load(const char *path, bool header_only, Png *out) {
     }
   }
   return DVO_AMD_OK;
+}
+
+// nothing may be thrown across the C ABI: allocation failures of the decoder come back as a status
+int png_load(const char *path, bool header_only, Png *out) {
+  try {
+    return png_load_impl(path, header_only, out);
+  } catch (const std::bad_alloc &) {
+    return DVO_AMD_ERR_OUT_OF_MEMORY;
+  } catch (...) {
+    return DVO_AMD_ERR_FORMAT;
+  }
 }
 
 // sample s of a scanline with bit depth < 8 (packed most significant bits first)

@@ -170,6 +170,13 @@ int dvo_amd_pyramid_select(dvo_amd_pyramid *p, int level, float intensity_thresh
 int dvo_amd_match(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, const double *T_init,
                   dvo_amd_result *result);
 
+/* DenseTracker::match(PointSelection& reference, RgbdImagePyramid& current, Result&), dense_tracking.cpp:131-376: the
+ * reference pixels are the ones the PointSelection's own predicate keeps (point_selection.h:49-67: z, zdx, zdy valid and a
+ * gradient above the thresholds; thresholds of -1 reproduce ValidPointPredicate), whatever thresholds the tracker's
+ * configuration holds.  Selections are cached per (pyramid, threshold pair), like a PointSelection caches per level. */
+int dvo_amd_match_selection(dvo_amd_context *ctx, dvo_amd_pyramid *reference, float intensity_threshold, float depth_threshold,
+                            dvo_amd_pyramid *current, const double *T_init, dvo_amd_result *result);
+
 /* n independent match() calls advanced in lock step on one GPU (the shape of LocalTracker::update's tbb::parallel_invoke,
  * local_tracker.cpp:184, and of the loop-closure validator's parallel_reduce, keyframe_graph.cpp:576-593).
  * T_inits: n x 16 doubles or NULL.  Results are identical to n dvo_amd_match() calls. */
@@ -343,8 +350,11 @@ typedef struct {
   float loglik;           /* what computeCompleteDataLogLikelihood returns */
   float reserved_f;
 } dvo_amd_iteration_probe;
+/* precision_eval (column-major 2x2, may be NULL): evaluate information / rhs / loglik with this precision instead of the one the
+ * probe computed itself (out->precision is the computed one either way) */
 int dvo_amd_debug_iteration(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, int level,
-                            const float *T, const float *precision_in, dvo_amd_iteration_probe *out);
+                            const float *T, const float *precision_in, const float *precision_eval,
+                            dvo_amd_iteration_probe *out);
 /* DenseTracker::computeIntensityErrorImage, dense_tracking.cpp:378-444: |intensity residual| per reference pixel, 0 elsewhere */
 int dvo_amd_error_image(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, const double *T,
                         int level, float *image);
@@ -357,6 +367,12 @@ int dvo_amd_error_image(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_am
 int dvo_amd_bench_residual_pass(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, int level,
                                 const float *T, int n_items, int rounds, int reps, double *avg_ms, double *alg_bytes,
                                 int *n_launches);
+
+/* the same over n_items DIFFERENT (reference, current) pairs (same size): no two items of a launch read the same planes, so
+ * nothing is deduplicated by the caches */
+int dvo_amd_bench_residual_pass_pairs(dvo_amd_context *ctx, int n_items, dvo_amd_pyramid *const *references,
+                                      dvo_amd_pyramid *const *currents, int level, const float *T, int rounds, int reps,
+                                      double *avg_ms, double *alg_bytes, int *n_launches);
 
 /* Diagnostic: with DVO_AMD_FIN_STAMPS=1 in the environment the finalize kernel records 8 shader-clock stamps of its phases
  * (block 0 of the most recent launch); this reads them back. */

@@ -4,7 +4,10 @@
 //   dvo::core::IntrinsicMatrix        dvo_core/include/dvo/core/intrinsic_matrix.h:33-64
 //   dvo::core::RgbdCameraPyramid      dvo_core/include/dvo/core/rgbd_image.h:127-144
 //   dvo::core::RgbdImagePyramid       dvo_core/include/dvo/core/rgbd_image.h:242-262
-//   dvo::DenseTracker {Config, TerminationCriteria, IterationStats, LevelStats, Stats, Result, configure, match}
+//   dvo::core::RgbdImage (level(i))   dvo_core/include/dvo/core/rgbd_image.h:146-240 (what callers of the hot path touch)
+//   dvo::core::PointSelection + predicates   dvo_core/include/dvo/core/point_selection.h:32-117
+//   dvo::DenseTracker {Config, TerminationCriteria, IterationStats, LevelStats, Stats, Result, configure, match x4,
+//                      computeIntensityErrorImage}
 //                                     dvo_core/include/dvo/dense_tracking.h:39-213
 // so that dvo_ros / dvo_slam / dvo_benchmark call sites (camera_dense_tracking.cpp:243-276, local_tracker.cpp:157-213,
 // constraint_proposal_validator.cpp:132-166, benchmark_slam.cpp:352-547) compile against it unchanged apart from the
@@ -134,6 +137,30 @@ class IntrinsicMatrix {
 };
 
 class RgbdCameraPyramid;
+class RgbdImagePyramid;
+
+// rgbd_image.h:146-240, as far as callers of the hot path use it: LocalTracker::update pre-builds the point cloud and the
+// 8-channel acceleration structure of every level (local_tracker.cpp:163-169).  Here every level, its derivative planes,
+// rays and gather layout are built on the GPU by RgbdImagePyramid::build, so these members have nothing left to do.
+class RgbdImage {
+ public:
+  RgbdImage() : width(0), height(0), owner_(nullptr), level_(0) {}
+  size_t width, height;
+  IntrinsicMatrix intrinsics;  // of this level (RgbdCamera::intrinsics())
+  void initialize() {}
+  void calculateDerivatives() {}
+  bool calculateIntensityDerivatives() { return false; }
+  void calculateDepthDerivatives() {}
+  void buildPointCloud() {}
+  void buildAccelerationStructure() {}
+  // host copy of one plane of this level: 0 intensity, 1 depth, 2 intensity_dx, 3 intensity_dy, 4 depth_dx, 5 depth_dy
+  inline std::vector<float> plane(int which) const;
+
+ private:
+  friend class RgbdImagePyramid;
+  const RgbdImagePyramid *owner_;
+  int level_;
+};
 
 // rgbd_image.h:242-262.  The reference extends a pyramid lazily, level by level; here the base planes are kept on the host
 // until the first build(n), then the device pyramid is (re)built with max(n, levels so far) levels in one go.
@@ -169,6 +196,22 @@ class RgbdImagePyramid {
     levels_ = want;
   }
 
+  // rgbd_image.h:256: builds up to idx + 1 levels on demand, like the reference
+  RgbdImage &level(size_t idx) {
+    if (idx >= (size_t)DVO_AMD_MAX_LEVELS) throw DvoAmdError(DVO_AMD_ERR_INVALID_ARGUMENT, "RgbdImagePyramid::level");
+    build(idx + 1);
+    RgbdImage &img = level_views_[idx];  // fixed storage: a reference handed out stays valid, as in the reference
+    if (img.owner_ != this || img.level_ != (int)idx || img.width == 0) {
+      int w = 0, h = 0;
+      float k[4];
+      detail::check(dvo_amd_pyramid_level_info(handle_, (int)idx, &w, &h, k), "RgbdImagePyramid::level");
+      img.width = (size_t)w, img.height = (size_t)h;
+      img.intrinsics = IntrinsicMatrix::create(k[0], k[1], k[2], k[3]);
+      img.owner_ = this, img.level_ = (int)idx;
+    }
+    return img;
+  }
+
   double timestamp() const { return timestamp_; }
   int width() const { return width_; }
   int height() const { return height_; }
@@ -182,8 +225,189 @@ class RgbdImagePyramid {
   std::vector<float> intensity_, depth_;
   dvo_amd_pyramid *handle_;
   int levels_;
+  RgbdImage level_views_[DVO_AMD_MAX_LEVELS];
 };
 typedef RgbdImagePyramid::Ptr RgbdImagePyramidPtr;
+
+inline std::vector<float> RgbdImage::plane(int which) const {
+  if (!owner_) throw DvoAmdError(DVO_AMD_ERR_INVALID_ARGUMENT, "RgbdImage::plane");
+  std::vector<float> out(width * height);
+  detail::check(dvo_amd_pyramid_download_plane(owner_->handle(), level_, which, out.data()), "RgbdImage::plane");
+  return out;
+}
+
+// rgbd_image.h:39-89: the 48-byte record PointSelection::select hands out ({x, y, z, 1; I, Z, Ix, Iy, Zx, Zy, 0, 0})
+struct PointWithIntensityAndDepth {
+  union Point {
+    float data[4];
+    struct {
+      float x, y, z;
+    };
+  };
+  union IntensityAndDepth {
+    float data[8];
+    struct {
+      float i, z, idx, idy, zdx, zdy, time_interpolation;
+    };
+  };
+  typedef std::vector<PointWithIntensityAndDepth> VectorType;
+  Point point;
+  IntensityAndDepth intensity_and_depth;
+};
+
+// point_selection.h:32-67.  The selection runs on the GPU, so a predicate must be expressible as the two gradient thresholds
+// of the reference's own predicates; deviceThresholds() says how.  A user-defined predicate with other logic cannot run on
+// the device: PointSelection throws DvoAmdError for it instead of silently selecting something else.
+class PointSelectionPredicate {
+ public:
+  virtual ~PointSelectionPredicate() {}
+  virtual bool isPointOk(const size_t &x, const size_t &y, const float &z, const float &idx, const float &idy, const float &zdx,
+                         const float &zdy) const = 0;
+  virtual bool deviceThresholds(float &intensity_threshold, float &depth_threshold) const {
+    (void)intensity_threshold, (void)depth_threshold;
+    return false;
+  }
+};
+
+class ValidPointPredicate : public PointSelectionPredicate {
+ public:
+  virtual ~ValidPointPredicate() {}
+  virtual bool isPointOk(const size_t &, const size_t &, const float &z, const float &, const float &, const float &zdx,
+                         const float &zdy) const {
+    return z == z && zdx == zdx && zdy == zdy;
+  }
+  // |zdx| > -1 holds for every non-NaN zdx: thresholds of -1 leave exactly the validity part of the test
+  virtual bool deviceThresholds(float &ti, float &td) const {
+    ti = -1.0f, td = -1.0f;
+    return true;
+  }
+};
+
+class ValidPointAndGradientThresholdPredicate : public PointSelectionPredicate {
+ public:
+  float intensity_threshold;
+  float depth_threshold;
+  ValidPointAndGradientThresholdPredicate() : intensity_threshold(0.0f), depth_threshold(0.0f) {}
+  virtual ~ValidPointAndGradientThresholdPredicate() {}
+  virtual bool isPointOk(const size_t &, const size_t &, const float &z, const float &idx, const float &idy, const float &zdx,
+                         const float &zdy) const {
+    return z == z && zdx == zdx && zdy == zdy &&
+           (std::abs(idx) > intensity_threshold || std::abs(idy) > intensity_threshold || std::abs(zdx) > depth_threshold ||
+            std::abs(zdy) > depth_threshold);
+  }
+  virtual bool deviceThresholds(float &ti, float &td) const {
+    ti = intensity_threshold, td = depth_threshold;
+    return true;
+  }
+};
+
+// point_selection.h:70-117.  The reference caches the compacted 48-byte records per level until setRgbdImagePyramid(); here
+// the selection lives with the device pyramid (a NaN-masked depth plane per threshold pair, cached for the pyramid's
+// lifetime), so this class only carries the pyramid pointer and the predicate.  select() materialises host records for
+// callers that want to look at them; match() never does.
+class PointSelection {
+ public:
+  typedef PointWithIntensityAndDepth::VectorType PointVector;
+  typedef PointVector::iterator PointIterator;
+
+  explicit PointSelection(const PointSelectionPredicate &predicate) : pyramid_(nullptr), predicate_(predicate), debug_(false) {}
+  PointSelection(RgbdImagePyramid &pyramid, const PointSelectionPredicate &predicate)
+      : pyramid_(&pyramid), predicate_(predicate), debug_(false) {}
+  virtual ~PointSelection() {}
+
+  RgbdImagePyramid &getRgbdImagePyramid() {
+    if (!pyramid_) throw DvoAmdError(DVO_AMD_ERR_INVALID_ARGUMENT, "PointSelection::getRgbdImagePyramid");  // assert(pyramid_ != 0)
+    return *pyramid_;
+  }
+  void setRgbdImagePyramid(RgbdImagePyramid &pyramid) {
+    pyramid_ = &pyramid;
+    storage_.clear();  // point_selection.cpp:51-59: the cache belongs to the previous pyramid
+  }
+  void recycle(RgbdImagePyramid &pyramid) { setRgbdImagePyramid(pyramid); }
+
+  // point_selection.cpp:68-71
+  size_t getMaximumNumberOfPoints(const size_t &level) {
+    RgbdImagePyramid &p = getRgbdImagePyramid();
+    return size_t((double)((size_t)p.width() * (size_t)p.height()) * std::pow(0.25, double(level)));
+  }
+
+  // the thresholds the device selection runs with (throws for a predicate the device cannot evaluate)
+  void thresholds(float &ti, float &td) const {
+    if (!predicate_.deviceThresholds(ti, td))
+      throw DvoAmdError(DVO_AMD_ERR_INVALID_ARGUMENT, "PointSelection: predicate has no device form (deviceThresholds)");
+  }
+
+  // number of selected pixels of a level (the distance last_point - first_point of select())
+  size_t size(const size_t &level) {
+    RgbdImagePyramid &p = getRgbdImagePyramid();
+    p.build(level + 1);
+    float ti, td;
+    thresholds(ti, td);
+    int count = 0;
+    detail::check(dvo_amd_pyramid_select(p.handle(), (int)level, ti, td, &count, nullptr), "PointSelection::size");
+    return (size_t)count;
+  }
+
+  // point_selection.cpp:89-152: row-major scan, predicate, 48-byte records.  Host copy, built on demand and cached per level.
+  void select(const size_t &level, PointIterator &first_point, PointIterator &last_point) {
+    RgbdImagePyramid &p = getRgbdImagePyramid();
+    RgbdImage &img = p.level(level);
+    if (storage_.size() < level + 1) storage_.resize(level + 1);
+    Storage &st = storage_[level];
+    if (!st.is_cached || debug_) {
+      float ti, td;
+      thresholds(ti, td);
+      const size_t n = img.width * img.height;
+      std::vector<unsigned char> mask(n);
+      int count = 0;
+      detail::check(dvo_amd_pyramid_select(p.handle(), (int)level, ti, td, &count, mask.data()), "PointSelection::select");
+      std::vector<float> pl[6];
+      for (int k = 0; k < 6; ++k) pl[k] = img.plane(k);
+      st.points.assign((size_t)count, PointWithIntensityAndDepth());
+      const float fx = img.intrinsics.fx(), fy = img.intrinsics.fy(), ox = img.intrinsics.ox(), oy = img.intrinsics.oy();
+      size_t o = 0;
+      for (size_t y = 0; y < img.height; ++y)
+        for (size_t x = 0; x < img.width; ++x) {
+          const size_t i = y * img.width + x;
+          if (!mask[i]) continue;
+          PointWithIntensityAndDepth &q = st.points[o++];
+          const float z = pl[1][i];
+          // RgbdCamera's ray template ((x - ox) / fx, (y - oy) / fy, 1, 0) times depth, w = 1 (rgbd_image.cpp:198-199,245-262)
+          q.point.data[0] = (((float)x - ox) / fx) * z, q.point.data[1] = (((float)y - oy) / fy) * z;
+          q.point.data[2] = z, q.point.data[3] = 1.0f;
+          for (int k = 0; k < 6; ++k) q.intensity_and_depth.data[k] = pl[k][i];
+          q.intensity_and_depth.data[6] = q.intensity_and_depth.data[7] = 0.0f;
+        }
+      if (debug_) st.debug_idx.swap(mask);
+      st.is_cached = true;
+    }
+    first_point = st.points.begin();
+    last_point = st.points.end();
+  }
+
+  // point_selection.cpp:74-86 (a row-major 0/1 byte per pixel instead of a cv::Mat)
+  bool getDebugIndex(const size_t &level, std::vector<unsigned char> &dbg_idx) {
+    if (debug_ && storage_.size() > level) {
+      dbg_idx = storage_[level].debug_idx;
+      return !dbg_idx.empty();
+    }
+    return false;
+  }
+  void debug(bool v) { debug_ = v; }
+  bool debug() const { return debug_; }
+
+ private:
+  struct Storage {
+    PointVector points;
+    bool is_cached;
+    std::vector<unsigned char> debug_idx;
+    Storage() : is_cached(false) {}
+  };
+  RgbdImagePyramid *pyramid_;
+  std::vector<Storage> storage_;
+  const PointSelectionPredicate &predicate_;
+  bool debug_;
+};
 
 // rgbd_image.h:127-144
 class RgbdCameraPyramid {
@@ -319,15 +543,20 @@ class DenseTracker {
     return c;
   }
 
-  explicit DenseTracker(const Config &config = getDefaultConfig(), int device = 0) : ctx_(nullptr), device_(device) {
+  explicit DenseTracker(const Config &config = getDefaultConfig(), int device = 0)
+      : ctx_(nullptr), device_(device), reference_selection_(selection_predicate_) {
     dvo_amd_config c = to_c(config);
     detail::check(dvo_amd_context_create(device, &c, &ctx_), "DenseTracker::DenseTracker");
     cfg = config;
+    selection_predicate_.intensity_threshold = cfg.IntensityDerivativeThreshold;
+    selection_predicate_.depth_threshold = cfg.DepthDerivativeThreshold;
   }
-  DenseTracker(const DenseTracker &other) : ctx_(nullptr), device_(other.device_) {
+  DenseTracker(const DenseTracker &other) : ctx_(nullptr), device_(other.device_), reference_selection_(selection_predicate_) {
     dvo_amd_config c = to_c(other.cfg);
     detail::check(dvo_amd_context_create(device_, &c, &ctx_), "DenseTracker::DenseTracker");
     cfg = other.cfg;
+    selection_predicate_.intensity_threshold = cfg.IntensityDerivativeThreshold;
+    selection_predicate_.depth_threshold = cfg.DepthDerivativeThreshold;
   }
   DenseTracker &operator=(const DenseTracker &) = delete;
   ~DenseTracker() { dvo_amd_context_destroy(ctx_); }
@@ -338,6 +567,8 @@ class DenseTracker {
     dvo_amd_config c = to_c(config);
     detail::check(dvo_amd_configure(ctx_, &c), "DenseTracker::configure");  // assert(config.IsSane()) in the reference
     cfg = config;
+    selection_predicate_.intensity_threshold = cfg.IntensityDerivativeThreshold;  // dense_tracking.cpp:76-77
+    selection_predicate_.depth_threshold = cfg.DepthDerivativeThreshold;
   }
 
   // dense_tracking.cpp:99-109
@@ -349,10 +580,29 @@ class DenseTracker {
     return success;
   }
 
-  // dense_tracking.cpp:123-376
+  // dense_tracking.cpp:111-121
+  bool match(core::PointSelection &reference, core::RgbdImagePyramid &current, core::AffineTransformd &transformation) {
+    Result result;
+    result.Transformation = transformation;
+    const bool success = match(reference, current, result);
+    transformation = result.Transformation;
+    return success;
+  }
+
+  // dense_tracking.cpp:123-129
   bool match(core::RgbdImagePyramid &reference, core::RgbdImagePyramid &current, Result &result) {
     reference.compute(cfg.getNumLevels());
+    reference_selection_.setRgbdImagePyramid(reference);
+    return match(reference_selection_, current, result);
+  }
+
+  // dense_tracking.cpp:131-376: the reference pixels are the ones `reference`'s predicate keeps
+  bool match(core::PointSelection &reference, core::RgbdImagePyramid &current, Result &result) {
+    core::RgbdImagePyramid &ref_pyramid = reference.getRgbdImagePyramid();
+    ref_pyramid.compute(cfg.getNumLevels());
     current.compute(cfg.getNumLevels());
+    float ti = 0.0f, td = 0.0f;
+    reference.thresholds(ti, td);
     const int cap = (cfg.FirstLevel - cfg.LastLevel + 1) * (cfg.MaxIterationsPerLevel + 1);
     std::vector<dvo_amd_iteration_stats> its((size_t)cap);
     dvo_amd_result r;
@@ -361,11 +611,13 @@ class DenseTracker {
     r.iterations_capacity = cap;
     double T0[16];
     std::memcpy(T0, core::data(result.Transformation), sizeof(T0));
-    detail::check(dvo_amd_match(ctx_, reference.handle(), current.handle(), cfg.UseInitialEstimate ? T0 : nullptr, &r),
+    detail::check(dvo_amd_match_selection(ctx_, ref_pyramid.handle(), ti, td, current.handle(),
+                                          cfg.UseInitialEstimate ? T0 : nullptr, &r),
                   "DenseTracker::match");
     std::memcpy(core::data(result.Transformation), r.transformation, sizeof(r.transformation));
     std::memcpy(core::data(result.Information), r.information, sizeof(r.information));
     result.LogLikelihood = r.loglik;
+    result.Statistics.Levels.clear();
     for (int l = 0; l < r.n_levels; ++l) {
       LevelStats ls;
       ls.Id = (size_t)r.levels[l].id;
@@ -389,6 +641,42 @@ class DenseTracker {
     return true;  // the reference's `success` is constant true (dense_tracking.cpp:135,375)
   }
 
+  // dense_tracking.cpp:378-444 (caller: keyframe_graph.cpp:354): |intensity residual| per reference pixel of `level`, 0 where
+  // the pixel is not selected or its warp is invalid; CV_32FC1 where OpenCV is available, else ErrorImage
+  struct ErrorImage {
+    int rows, cols;
+    std::vector<float> data;
+    float &at(int y, int x) { return data[(size_t)y * cols + x]; }
+    float at(int y, int x) const { return data[(size_t)y * cols + x]; }
+  };
+  ErrorImage computeIntensityErrorImageRaw(core::RgbdImagePyramid &reference, core::RgbdImagePyramid &current,
+                                           const core::AffineTransformd &transformation, size_t level = 0) {
+    reference.compute(level + 1);
+    current.compute(level + 1);
+    core::RgbdImage &img = reference.level(level);
+    ErrorImage out;
+    out.rows = (int)img.height, out.cols = (int)img.width;
+    out.data.resize(img.width * img.height);
+    detail::check(dvo_amd_error_image(ctx_, reference.handle(), current.handle(), core::data(transformation), (int)level,
+                                      out.data.data()),
+                  "DenseTracker::computeIntensityErrorImage");
+    return out;
+  }
+#ifdef DVO_AMD_HAVE_OPENCV
+  cv::Mat computeIntensityErrorImage(core::RgbdImagePyramid &reference, core::RgbdImagePyramid &current,
+                                     const core::AffineTransformd &transformation, size_t level = 0) {
+    ErrorImage e = computeIntensityErrorImageRaw(reference, current, transformation, level);
+    cv::Mat m(e.rows, e.cols, CV_32FC1);
+    for (int y = 0; y < e.rows; ++y) std::memcpy(m.ptr<float>(y), &e.data[(size_t)y * e.cols], sizeof(float) * (size_t)e.cols);
+    return m;
+  }
+#else
+  ErrorImage computeIntensityErrorImage(core::RgbdImagePyramid &reference, core::RgbdImagePyramid &current,
+                                        const core::AffineTransformd &transformation, size_t level = 0) {
+    return computeIntensityErrorImageRaw(reference, current, transformation, level);
+  }
+#endif
+
   dvo_amd_context *handle() const { return ctx_; }
 
  private:
@@ -404,6 +692,8 @@ class DenseTracker {
   Config cfg;
   dvo_amd_context *ctx_;
   int device_;
+  core::ValidPointAndGradientThresholdPredicate selection_predicate_;  // dense_tracking.h:199-200
+  core::PointSelection reference_selection_;
 };
 
 }  // namespace dvo

@@ -1,17 +1,24 @@
 #!/bin/bash
 # The judged profile set of a round: kernel stats of exactly the driver's command, the PMC traffic passes on the same
-# workload, the issue counts.  Usage: scripts/profile_bench.sh OUTDIR   (writes under gpurun_out/OUTDIR)
-out=gpurun_out/$1
+# workload, the issue counts.  Usage: scripts/profile_bench.sh OUTDIR [steps: default|pmc|issue|stats|stats1 ...]
+out=gpurun_out/$1; shift
+steps=${@:-default pmc issue stats1 stats}
 R=$GRAFT_REPO_ROOT
 mkdir -p "$R/$out"
 cd /tmp && export TMPDIR=/tmp
-python3 "$R/bench.py" --steps 20 --warmup 5 > "$R/$out/bench_default.json" 2> "$R/$out/bench_default.err" &&
-rocprofv3 --kernel-trace --stats -d "$R/$out/stats" -o bench --output-format csv -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-extras --no-cpu-baseline > "$R/$out/bench_stats.json" 2> "$R/$out/bench_stats.err" &&
-rocprofv3 --kernel-trace --stats -d "$R/$out/stats_t1" -o bench --output-format csv -- python3 "$R/bench.py" --threads 1 --batch 72 --in-flight 36 --steps 10 --warmup 2 --no-extras --no-cpu-baseline > "$R/$out/bench_t1.json" 2> "$R/$out/bench_t1.err" &&
-rocprofv3 --pmc FETCH_SIZE -d "$R/$out/pmc_fetch" -o pmc --output-format csv -- python3 "$R/bench.py" --steps 2 --warmup 1 --prime 1 --no-extras --no-cpu-baseline > "$R/$out/pmc_fetch.json" 2> "$R/$out/pmc_fetch.err" &&
-rocprofv3 --pmc WRITE_SIZE -d "$R/$out/pmc_write" -o pmc --output-format csv -- python3 "$R/bench.py" --steps 2 --warmup 1 --prime 1 --no-extras --no-cpu-baseline > "$R/$out/pmc_write.json" 2> "$R/$out/pmc_write.err" &&
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA -d "$R/$out/pmc_issue" -o pmc --output-format csv -- python3 "$R/scripts/issue_counts.py" run "$R/$out/issue_run.json" > "$R/$out/issue.log" 2>&1 &&
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA -d "$R/$out/pmc_issue_iso" -o pmc --output-format csv -- python3 "$R/scripts/kernel_one.py" 0 36 0 10 > "$R/$out/issue_iso.log" 2>&1
+for s in $steps; do
+  case $s in
+    default) python3 "$R/bench.py" --steps 20 --warmup 5 > "$R/$out/bench_default.json" 2> "$R/$out/bench_default.err" || exit 1 ;;
+    pmc)
+      rocprofv3 --pmc FETCH_SIZE -d "$R/$out/pmc_fetch" -o pmc --output-format csv -- python3 "$R/bench.py" --steps 2 --warmup 1 --prime 1 --no-extras --no-cpu-baseline > "$R/$out/pmc_fetch.json" 2> "$R/$out/pmc_fetch.err" || exit 1
+      rocprofv3 --pmc WRITE_SIZE -d "$R/$out/pmc_write" -o pmc --output-format csv -- python3 "$R/bench.py" --steps 2 --warmup 1 --prime 1 --no-extras --no-cpu-baseline > "$R/$out/pmc_write.json" 2> "$R/$out/pmc_write.err" || exit 1 ;;
+    issue)
+      rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA -d "$R/$out/pmc_issue" -o pmc --output-format csv -- python3 "$R/scripts/issue_counts.py" run "$R/$out/issue_run.json" > "$R/$out/issue.log" 2>&1 || exit 1
+      rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA -d "$R/$out/pmc_issue_iso" -o pmc --output-format csv -- python3 "$R/scripts/kernel_one.py" 0 36 0 10 > "$R/$out/issue_iso.log" 2>&1 || exit 1 ;;
+    stats1) rocprofv3 --kernel-trace --stats -d "$R/$out/stats_t1" -o bench --output-format csv -- python3 "$R/bench.py" --threads 1 --batch 72 --in-flight 36 --steps 10 --warmup 2 --no-extras --no-cpu-baseline > "$R/$out/bench_t1.json" 2> "$R/$out/bench_t1.err" || exit 1 ;;
+    stats) rocprofv3 --kernel-trace --stats -d "$R/$out/stats" -o bench --output-format csv -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-extras --no-cpu-baseline > "$R/$out/bench_stats.json" 2> "$R/$out/bench_stats.err" || exit 1 ;;
+  esac
+done
 # the per-dispatch traces are large: keep the stats and drop the traces unless asked
 find "$R/$out" -name '*kernel_trace.csv' -size +20M -delete
 ls -la "$R/$out"

@@ -437,3 +437,29 @@ def test_iteration_probe_reproduces_the_iterations_of_match(orc, synth, small_pa
         assert np.array_equal(it["b"].astype(np.float64), its[k]["rhs"])
         T = orc.se3_exp(its[k]["increment"]) @ T  # estimate = inc * estimate (dense_tracking.cpp:261)
         prec = it["precision"]
+
+
+def test_float64_restatement_brackets_the_oracles_sequential_fp32_sums(orc, synth):
+    """tests/stage_f64.py restates one iteration body a third time (numpy, float64 sums, on the oracle's bit-exact residual
+    records).  The oracle -- like the reference -- accumulates scale, A and b sequentially in fp32; this pins how far that
+    alone is from the exact sums (the error bars the GPU stage tests grant the reference, tests/test_gpu_parity.py REF_*)."""
+    from stage_f64 import f64_iteration
+
+    (Ir, Zr), (Ic, Zc), Tgt = synth.make_pair(320, 240)
+    K = synth.intrinsics_for(320, 240)
+    pr, pc = orc.Pyramid(Ir, Zr, K, 3), orc.Pyramid(Ic, Zc, K, 3)
+    ro = orc.match(orc.default_config(first_level=2, last_level=0, rcp_mode=orc.RCP_EXACT), pr, pc)
+    worst = dict(scale=0.0, A=0.0, b=0.0, ll=0.0)
+    for L in ro["levels"]:
+        prec = None
+        for it in L["iterations"]:
+            n, cov, A, b, cs, ll = f64_iteration(orc, pr, pc, L["id"], it["estimate"], prec, it["precision"])
+            assert n == it["valid_constraints"]
+            worst["scale"] = max(worst["scale"], np.abs(cov - it["scale"]).max() / np.abs(cov).max())
+            worst["ll"] = max(worst["ll"], abs(-ll - it["tdist_loglik"]) / abs(ll))
+            if it["has_increment"]:
+                worst["A"] = max(worst["A"], np.abs(A - it["information"]).max() / np.abs(A).max())
+                worst["b"] = max(worst["b"], (np.abs(b - it["rhs"]) / cs).max())
+            prec = it["precision"]
+    assert worst["scale"] <= 1e-3 and worst["A"] <= 3e-4 and worst["b"] <= 3e-5 and worst["ll"] <= 2e-6, worst
+    assert worst["scale"] >= 1e-7  # it is an fp32 sum: if this ever reads 0 the comparison has stopped comparing

@@ -127,6 +127,28 @@ def test_png_reader_rejects_broken_files(tmp_path, tum):
         tum.png_info(str(tmp_path / "notpng.png"))
 
 
+def test_png_reader_rejects_absurd_header_dimensions(tmp_path, tum):
+    """a crafted IHDR (width / height up to 2^31 - 1) must come back as a format error, never as an overflowing size
+    computation or an exception thrown through the C ABI"""
+    import struct
+    import zlib
+
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body) & 0xFFFFFFFF)
+
+    for w, h in ((0x7FFFFFFF, 0x7FFFFFFF), (65536, 65536), (16385, 4), (4, 16385)):
+        path = str(tmp_path / f"huge_{w}_{h}.png")
+        with open(path, "wb") as fh:
+            fh.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 0, 0, 0, 0)))
+            fh.write(chunk(b"IDAT", zlib.compress(b"\x00" * 64)))
+            fh.write(chunk(b"IEND", b""))
+        with pytest.raises(Exception) as e:
+            tum.png_info(path)
+        assert getattr(e.value, "status", 12) == 12  # DVO_AMD_ERR_FORMAT
+        with pytest.raises(Exception):
+            tum.imread_depth(path)
+
+
 def test_trajectory_line_known_answers_and_oracle(tum, otum, synth):
     # a double holds a 2011 time stamp to ~2.4e-7 s: ros::Time::fromSec turns the parsed 1305031102.175304 into ...175303936 ns
     assert tum.format_trajectory_line(1305031102.175304, np.eye(4)) == "1305031102.175303936 0 0 0 0 0 0 1 \n"
