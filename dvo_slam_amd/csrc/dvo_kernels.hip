@@ -137,15 +137,6 @@ struct LevelPairDesc {
 // residual pass
 // ------------------------------------------------------------------------------------------------------------------
 
-struct PixelIn {   // live across the RN -> RTZ switch
-  float x[kPxPerLane], y[kPxPerLane], z[kPxPerLane];
-  float ri[kPxPerLane], rix[kPxPerLane], riy[kPxPerLane];
-};
-struct PixelOut {  // live across the RTZ -> RN switch
-  float r0[kPxPerLane], r1[kPxPerLane], e2[kPxPerLane], e3[kPxPerLane], e4[kPxPerLane], e5[kPxPerLane];
-  bool valid[kPxPerLane];
-};
-
 // computeResidualsSse for one reference pixel, dense_tracking_impl.cpp:171-294, split in three so that the 24 gather
 // loads of a round (4 pixels x 6) are issued back to back instead of one pixel's loads waiting behind the previous
 // pixel's arithmetic.  All three parts run in round-toward-zero.
@@ -259,9 +250,8 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
   const int wave = threadIdx.x >> 6;
   const int seg = lb * kWavesPerBlock + wave;
   const int w = d.w;
-  const int res_rounds = item_res_rounds(it);
-  const int steps = res_rounds * kPxPerLane;  // a segment is res_rounds * 256 pixels = steps * 64
-  unsigned idx = (unsigned)(seg * (kSegPxPerRound * res_rounds) + lane);
+  const int steps = item_res_steps(it);  // a segment is steps * 64 pixels
+  unsigned idx = (unsigned)(seg * (kStepPx * steps) + lane);
   unsigned prow = idx / (unsigned)w;
   unsigned pcol = idx - prow * (unsigned)w;
 
@@ -535,12 +525,16 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
   };
   // the last pair of steps is peeled so that "is there a next step to prefetch" is a compile-time fact in every copy
   if (!(DVO_ABLATE & 16)) {  // (ablation 16: prologue + epilogue only)
-    for (int step = 0; step + 2 < steps; step += 2) {
-      do_step(step, 0, true);
-      do_step(step + 1, 1, true);
+    if (steps == 1) {
+      do_step(0, 1, false);  // a one-step segment stages into buffer 1, which the epilogue consumes
+    } else {
+      for (int step = 0; step + 2 < steps; step += 2) {
+        do_step(step, 0, true);
+        do_step(step + 1, 1, true);
+      }
+      do_step(steps - 2, 0, true);
+      do_step(steps - 1, 1, false);
     }
-    do_step(steps - 2, 0, true);
-    do_step(steps - 1, 1, false);
   }
 
   if (DVO_ABLATE & 32) {  // (ablation 32: no epilogue -- keep the accumulators alive, write nothing)
@@ -703,20 +697,22 @@ __device__ void loglik_pass(const TickItem &it, const LevelPairDesc &d, const in
   const unsigned long long below = (1ull << lane) - 1ull;
   double total = 0.0;
   if (seg_before < cut_rank) {
-    const int ll_rounds = item_ll_rounds(it);
-    const int steps = ll_rounds * kPxPerLane;
-    const DVO_GLOBAL v2f *src = (const DVO_GLOBAL v2f *)((it.flags & kItemLlBuf) ? d.res[1] : d.res[0]) + seg * (kSegPxPerRound * ll_rounds) + lane;
+    const int steps = item_ll_steps(it);
+    const DVO_GLOBAL v2f *src = (const DVO_GLOBAL v2f *)((it.flags & kItemLlBuf) ? d.res[1] : d.res[0]) + seg * (kStepPx * steps) + lane;
     int run_count = seg_before;
-    // four steps (256 pixels) per trip; one log per lane of the product of up to 16 terms (four trips), like the
+    // up to four steps (256 pixels) per trip; one log per lane of the product of up to 16 terms (four trips), like the
     // reference takes one log per 50 residuals (dense_tracking_impl.cpp:415-419): a term is 1 + 0.2 r^T P r >= 1, and
     // sixteen of them stay far below the double range
     double prod = 1.0;
+    const int per_trip = steps < 4 ? steps : 4;
     for (int step = 0; step < steps; step += 4) {
       v2f r[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) r[k] = src[(step + k) * kWave];
+      for (int k = 0; k < 4; ++k)
+        if (k < per_trip) r[k] = src[(step + k) * kWave];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
+        if (k >= per_trip) break;
         const bool valid = r[k].x == r[k].x;
         const unsigned long long b = __ballot(valid);
         const int rank = run_count + __popcll(b & below);
@@ -797,7 +793,7 @@ __global__ __launch_bounds__(kBlockThreads, OCC) void k_tick_table(const TickIte
   TickItem it;
   it.ref = p->ref, it.cur = p->cur, it.slot = p->slot;
   it.res_blocks = p->res_blocks, it.ll_blocks = p->ll_blocks, it.res_first = p->res_first, it.ll_first = p->ll_first;
-  it.rounds_log2 = p->rounds_log2, it.flags = p->flags, it.res_phys = p->res_phys;
+  it.steps_log2 = p->steps_log2, it.flags = p->flags, it.res_phys = p->res_phys;
   it.ll_cut_rank = p->ll_cut_rank;
 #pragma unroll
   for (int i = 0; i < 12; ++i) it.kt[i] = p->kt[i];
@@ -928,15 +924,25 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const FinArgs args) {
     SegRec r;
     r.c = 0, r.first_w = 0.0f, r.l0 = r.l1 = 0.0f;
     for (int i = 0; i < 3; ++i) r.s0[i] = r.s1[i] = 0.0;
-    for (int b = t * per; b < (t + 1) * per && b < nb; ++b) {
-      const gcf4 hp = reinterpret_cast<gcf4>(recs + (size_t)b * kRecStride);
-      const v4f h0 = hp[0], h1 = hp[1], h2 = hp[2];
-      SegRec q;
-      q.c = (int)f2u(h0.x);
-      q.first_w = h0.y, q.l0 = h0.z, q.l1 = h0.w;
-      q.s0[0] = h1.x, q.s0[1] = h1.y, q.s0[2] = h1.z;
-      q.s1[0] = h1.w, q.s1[1] = h2.x, q.s1[2] = h2.y;
-      r = seg_combine(r, q);
+    const int b_end = (t + 1) * per < nb ? (t + 1) * per : nb;
+    for (int b0 = t * per; b0 < b_end; b0 += 4) {  // four records' headers in flight at a time
+      v4f h0[4], h1[4], h2[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (b0 + k < b_end) {
+          const gcf4 hp = reinterpret_cast<gcf4>(recs + (size_t)(b0 + k) * kRecStride);
+          h0[k] = hp[0], h1[k] = hp[1], h2[k] = hp[2];
+        }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (b0 + k < b_end) {
+          SegRec q;
+          q.c = (int)f2u(h0[k].x);
+          q.first_w = h0[k].y, q.l0 = h0[k].z, q.l1 = h0[k].w;
+          q.s0[0] = h1[k].x, q.s0[1] = h1[k].y, q.s0[2] = h1[k].z;
+          q.s1[0] = h1[k].w, q.s1[1] = h2[k].x, q.s1[2] = h2[k].y;
+          r = seg_combine(r, q);
+        }
     }
     const int own_total = r.c;
     sh_seg[t] = r;
@@ -966,14 +972,23 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const FinArgs args) {
       // rank to honour the V % 50 cut (Q6)
       int prefix = sh_cnt[t] - own_total;  // valid pixels before this lane's blocks
       DVO_GLOBAL int *sp = (DVO_GLOBAL int *)it.seg_prefix_out + (size_t)it.block_first * kWavesPerBlock;
-      for (int b = t * per; b < (t + 1) * per && b < nb; ++b) {
-        const v4f h2 = reinterpret_cast<gcf4>(recs + (size_t)b * kRecStride)[2];
-        const v4f h3 = reinterpret_cast<gcf4>(recs + (size_t)b * kRecStride)[3];
-        const int cw[4] = {(int)f2u(h2.z), (int)f2u(h2.w), (int)f2u(h3.x), (int)f2u(h3.y)};
-        for (int k = 0; k < 4; ++k) {
-          sp[b * kWavesPerBlock + k] = prefix;
-          prefix += cw[k];
-        }
+      for (int b0 = t * per; b0 < b_end; b0 += 4) {
+        v4f h2[4], h3[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (b0 + k < b_end) {
+            const gcf4 hp = reinterpret_cast<gcf4>(recs + (size_t)(b0 + k) * kRecStride);
+            h2[k] = hp[2], h3[k] = hp[3];
+          }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (b0 + k < b_end) {
+            const int cw[4] = {(int)f2u(h2[k].z), (int)f2u(h2[k].w), (int)f2u(h3[k].x), (int)f2u(h3[k].y)};
+            for (int wv = 0; wv < 4; ++wv) {
+              sp[(b0 + k) * kWavesPerBlock + wv] = prefix;
+              prefix += cw[wv];
+            }
+          }
       }
     } else if (t == 0) {
       sh_out.valid = 0;

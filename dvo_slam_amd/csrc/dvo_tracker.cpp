@@ -418,6 +418,8 @@ struct dvo_amd_context {
   ncclResult_t (*p_allgather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*p_comm_destroy)(ncclComm_t) = nullptr;
   unsigned tick_seq = 0;
+  long long steps_at[4] = {2048, 8192, 32768, 262144};  // wave-step counts from which a tick takes 2 / 4 / 8 / 16 steps per wave
+                                                         // (DVO_AMD_STEPS_AT="a,b,c,d", read when the context is created)
   int fault_slot_alloc = -1;           // DVO_AMD_FAULT_SLOT_ALLOC: fail the allocation of this slot once (tests of the error path)
   bool fin_stamps = false;             // DVO_AMD_FIN_STAMPS=1: k_finalize records phase stamps (diagnostic)
   bool poll = true;                    // wait for a tick by polling the records' sequence words instead of hipStreamSynchronize
@@ -439,7 +441,7 @@ constexpr int kMaxBands = 16;
 struct IterCtx {
   int k = 0;
   int buf = 0;
-  int rounds = 1;
+  int steps = 4;  // 64-pixel steps per wave segment of this iteration's residual pass
   int n_blocks = 0;
   SE3 inc;
   SE3 initial_before, estimate_before;
@@ -612,8 +614,8 @@ void make_kt(const LevelData &C, const SE3 &estimate, float kt[12]) {
       kt[i * 4 + c] = (K[i * 3 + 0] * T[c * 4 + 0] + K[i * 3 + 1] * T[c * 4 + 1]) + K[i * 3 + 2] * T[c * 4 + 2];
 }
 
-int blocks_for(int n, int rounds) {
-  const int px_per_block = kSegPxPerRound * kWavesPerBlock * rounds;
+int blocks_for(int n, int steps) {
+  const int px_per_block = kStepPx * kWavesPerBlock * steps;
   return (n + px_per_block - 1) / px_per_block;
 }
 
@@ -733,7 +735,7 @@ void process_loglik(Job &j, const FinOut *outs) {
     end_level(j);
     if (spec && !j.done && j.have_b) {
       // the next level's first residual pass ran in this tick with exactly the state start_level() has just set up
-      j.b.rounds = spec_b.rounds, j.b.n_blocks = spec_b.n_blocks;
+      j.b.steps = spec_b.steps, j.b.n_blocks = spec_b.n_blocks;
       IterCtx b = j.b;
       process_residual(j, b, o);
     }
@@ -774,7 +776,7 @@ int ensure_slots_impl(dvo_amd_context *ctx, int n_jobs, int n_pad) {
     HIP_TRY(hipMemset(ctx->tickets, 0, sizeof(unsigned) * 16 * kMaxTickStreams));
   }
   std::vector<SlotDesc> slot_host((size_t)n_slots);
-  const int max_blocks = new_pad / (kSegPxPerRound * kWavesPerBlock);
+  const int max_blocks = new_pad / (kStepPx * kWavesPerBlock);  // one-step segments: the most blocks a level can have
   const size_t b_res = align_up(sizeof(float2) * new_pad, 256);
   const size_t b_rec = align_up(sizeof(float) * kRecStride * max_blocks, 256);
   const size_t b_ll = align_up(sizeof(double) * max_blocks, 256);
@@ -822,18 +824,15 @@ int ensure_slots(dvo_amd_context *ctx, int n_jobs, int n_pad) {
   return rc;
 }
 
-int pick_rounds(long long total_px) {
-  // The Gram-matrix (MFMA) form has no per-wave reduction to amortise, so short segments (many waves) are best for the
-  // residual pass itself (1 vs 2 rounds: within 4 %).  Longer segments mean fewer per-block records for k_finalize to
-  // read, which matters once many pairs are resident.
-  const long long waves1 = total_px / kSegPxPerRound;
-  static long long t2 = -1, t4 = -1;
-  if (t2 < 0) {  // DVO_AMD_ROUNDS_AT="waves_for_2,waves_for_4" (tuning)
-    long long a = 8192, b = 65536;
-    if (const char *e = getenv("DVO_AMD_ROUNDS_AT")) (void)sscanf(e, "%lld,%lld", &a, &b);
-    t4 = b, t2 = a;
-  }
-  return waves1 >= t4 ? 4 : waves1 >= t2 ? 2 : 1;
+int pick_steps(const dvo_amd_context *ctx, long long total_px) {
+  // Steps per wave segment for a tick whose residual passes cover total_px pixels.  A step is a dependent chain (reference
+  // scalars -> projection -> gathers -> arithmetic -> staging), ~1.5 us when nothing else hides it, so a launch that does
+  // not fill the GPU's 4096 wave slots anyway runs one or two steps per wave: a 4 800-pixel level is 75 waves instead of 19
+  // and its chain a quarter as long.  Saturating launches take 8 or 16 steps per wave: the per-wave epilogue (seven wave
+  // reductions, the Gram tile) is amortised and k_finalize reads fewer per-block records.
+  const long long waves = total_px / kStepPx;
+  const long long *t = ctx->steps_at;
+  return waves >= t[3] ? 16 : waves >= t[2] ? 8 : waves >= t[1] ? 4 : waves >= t[0] ? 2 : 1;
 }
 
 // a pair of events for the next timed launch; the launch itself stamps them (begin / end of that dispatch)
@@ -943,7 +942,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
     if (j.have_b) total_px += j.ref->lv[j.level].n;
     if (wants_spec(j)) total_px += j.ref->lv[j.level - 1].n;
   }
-  const int rounds_now = pick_rounds(total_px);
+  const int steps_now = pick_steps(ctx, total_px);
   const unsigned seq = ++ctx->tick_seq;
   grp.seq = seq;
 
@@ -959,7 +958,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
     const size_t slot_index = (size_t)(j.slot - ctx->slots.data());
     TickItem w;
     std::memset(&w, 0, sizeof(w));
-    int res_rounds = 1, ll_rounds = 1;
+    int res_steps = 1, ll_steps = 1;
     w.ref = j.sel->ref_desc + j.level;
     w.cur = j.cur->cur_desc + j.level;
     w.slot = ctx->slot_desc + slot_index;
@@ -969,19 +968,19 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
     f.seg_prefix_out = j.slot->seg_prefix[0], f.out = j.slot->out, f.out_dev = nullptr, f.seq = seq, f.pad = 0;
     if (j.have_a) {
       w.ll_blocks = (uint16_t)j.a.n_blocks;
-      ll_rounds = j.a.rounds;
+      ll_steps = j.a.steps;
       if (j.a.buf) w.flags |= kItemLlBuf;
       w.ll_cut_rank = j.a.cut_rank;
       f.n_ll_blocks = w.ll_blocks;
       j.sub_ll = true;
     }
     if (j.have_b) {
-      j.b.rounds = rounds_now;
-      while (j.b.rounds < kMaxRounds && blocks_for(j.ref->lv[j.level].n, j.b.rounds) > 2048) j.b.rounds *= 2;
-      j.b.n_blocks = blocks_for(j.ref->lv[j.level].n, j.b.rounds);
+      j.b.steps = steps_now;
+      while (j.b.steps < kMaxSteps && blocks_for(j.ref->lv[j.level].n, j.b.steps) > 2048) j.b.steps *= 2;
+      j.b.n_blocks = blocks_for(j.ref->lv[j.level].n, j.b.steps);
       w.res_blocks = (uint16_t)j.b.n_blocks;
       w.res_phys = w.res_blocks;
-      res_rounds = j.b.rounds;
+      res_steps = j.b.steps;
       if (j.b.buf) w.flags |= kItemResBuf;
       if (j.b.k == 0) w.flags |= kItemUnitWeights;  // dense_tracking.cpp:286-293
       make_kt(j.cur->lv[j.level], j.b.estimate_after, w.kt);
@@ -996,14 +995,14 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
       // iteration a ends its level whatever its likelihood says: start the next level in this tick, assuming acceptance
       const int nl = j.level - 1;
       speculate_next_level(j, j.spec_b);
-      j.spec_b.rounds = rounds_now;
-      while (j.spec_b.rounds < kMaxRounds && blocks_for(j.ref->lv[nl].n, j.spec_b.rounds) > 2048) j.spec_b.rounds *= 2;
-      j.spec_b.n_blocks = blocks_for(j.ref->lv[nl].n, j.spec_b.rounds);
+      j.spec_b.steps = steps_now;
+      while (j.spec_b.steps < kMaxSteps && blocks_for(j.ref->lv[nl].n, j.spec_b.steps) > 2048) j.spec_b.steps *= 2;
+      j.spec_b.n_blocks = blocks_for(j.ref->lv[nl].n, j.spec_b.steps);
       w.ref = j.sel->ref_desc + nl;  // the likelihood pass only uses the slot's buffers
       w.cur = j.cur->cur_desc + nl;
       w.res_blocks = (uint16_t)j.spec_b.n_blocks;
       w.res_phys = w.res_blocks;
-      res_rounds = j.spec_b.rounds;
+      res_steps = j.spec_b.steps;
       if (j.spec_b.buf) w.flags |= kItemResBuf;
       w.flags |= kItemUnitWeights;
       make_kt(j.cur->lv[nl], j.spec_b.estimate_after, w.kt);
@@ -1019,7 +1018,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
     // the likelihood of iteration k and the weights of iteration k+1 both use the precision of iteration k (a's); without a
     // pending likelihood the weights use the job's current precision (unused at the first iteration of a level)
     std::memcpy(w.P, j.have_a ? j.a.P : j.precision, sizeof(w.P));
-    item_set_rounds(w, res_rounds, ll_rounds);
+    item_set_steps(w, res_steps, ll_steps);
     items.push_back(w);
     fin_items.push_back(f);
     j.result->n_ticks++;
@@ -1080,8 +1079,8 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
       double rb = 0, lb = 0, px = 0, res_steps = 0, ll_steps = 0;
       for (int i = 0; i < n_here; ++i) {
         rb += stage[i].res_blocks, lb += stage[i].ll_blocks;
-        res_steps += (double)stage[i].res_blocks * kWavesPerBlock * kPxPerLane * item_res_rounds(stage[i]);
-        ll_steps += (double)stage[i].ll_blocks * kWavesPerBlock * kPxPerLane * item_ll_rounds(stage[i]);
+        res_steps += (double)stage[i].res_blocks * kWavesPerBlock * item_res_steps(stage[i]);
+        ll_steps += (double)stage[i].ll_blocks * kWavesPerBlock * item_ll_steps(stage[i]);
       }
       for (size_t ji = grp.lo, k = 0; ji < grp.hi; ++ji) {
         const Job &j = jobs[ji];
@@ -1195,7 +1194,7 @@ void combine_bands(const FinOut *const *recs, int n, FinOut &out) {
 int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, int n_local, bool exchange) {
   const unsigned seq = ++ctx->tick_seq;
   if (!j.have_a && !j.have_b) return DVO_AMD_OK;
-  const int nb_level = blocks_for(j.ref->lv[j.level].n, 1);  // one round per wave: identical segments for every band count
+  const int nb_level = blocks_for(j.ref->lv[j.level].n, 4);  // four steps per wave: identical segments for every band count
   TickArgs ta;
   FinArgs fa;
   std::memset(&ta, 0, sizeof(ta));
@@ -1203,7 +1202,7 @@ int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, i
   fa.ticket = ctx->tickets;
   j.sub_ll = j.have_a, j.sub_res = j.have_b;
   if (j.have_b) {
-    j.b.rounds = 1, j.b.n_blocks = nb_level;
+    j.b.steps = 4, j.b.n_blocks = nb_level;
     j.result->n_residual_passes++;
     j.alg_px += (double)j.sel->count[j.level];
   }
@@ -1244,6 +1243,7 @@ int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, i
       f.seg_prefix_out = ctx->slots[0].seg_prefix[j.b.buf];
     }
     std::memcpy(w.P, j.have_a ? j.a.P : j.precision, sizeof(w.P));
+    item_set_steps(w, 4, 4);  // the band geometry is fixed (nb_level above)
     max_blocks = std::max(max_blocks, w.res_blocks + w.ll_blocks);
   }
   ta.n_items = n_local, fa.n_items = n_local;
@@ -1399,6 +1399,8 @@ int dvo_amd_context_create(int device, const dvo_amd_config *cfg, dvo_amd_contex
   ctx->host_prof = hp && hp[0] == '1';
   if (const char *sl = getenv("DVO_AMD_SPEC_LEVELS")) ctx->spec_levels = sl[0] == '1';
   if (const char *fs2 = getenv("DVO_AMD_FAULT_SLOT_ALLOC")) ctx->fault_slot_alloc = atoi(fs2);
+  if (const char *sa = getenv("DVO_AMD_STEPS_AT"))
+    (void)sscanf(sa, "%lld,%lld,%lld,%lld", &ctx->steps_at[0], &ctx->steps_at[1], &ctx->steps_at[2], &ctx->steps_at[3]);
   if (const char *pb = getenv("DVO_AMD_PHYS_BLOCKS")) {
     const int v = atoi(pb);
     if (v >= 64) ctx->phys_block_target = v;
@@ -1776,10 +1778,10 @@ int single_tick(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyrami
   w.ref = sel->ref_desc + level;
   w.cur = current->cur_desc + level;
   w.slot = ctx->slot_desc;
-  int rounds = 1;
-  while (rounds < kMaxRounds && blocks_for(R.n, rounds) > 2048) rounds *= 2;
-  item_set_rounds(w, rounds, rounds);
-  const int nb = blocks_for(R.n, rounds);
+  int steps = pick_steps(ctx, R.n);
+  while (steps < kMaxSteps && blocks_for(R.n, steps) > 2048) steps *= 2;
+  item_set_steps(w, steps, steps);
+  const int nb = blocks_for(R.n, steps);
   if (unit_weights) w.flags |= kItemUnitWeights;
   if (P) std::memcpy(w.P, P, sizeof(w.P));
   FinArgs fa;
@@ -1922,13 +1924,14 @@ int dvo_amd_bench_residual_pass_pairs(dvo_amd_context *ctx, int n_items, dvo_amd
   const LevelData &R = references[0]->lv[level];
   int rc = ensure_slots(ctx, n_items, R.n_pad);
   if (rc) return rc;
-  if (rounds <= 0) rounds = pick_rounds((long long)R.n * n_items);
-  if (rounds != 1 && rounds != 2 && rounds != 4 && rounds != 8 && rounds != 16) return DVO_AMD_ERR_INVALID_ARGUMENT;
-  while (rounds < kMaxRounds && blocks_for(R.n, rounds) > 2048) rounds *= 2;
+  // `rounds` of the public interface = 256-pixel rounds per wave segment (four steps each); 0 = the driver's choice
+  if (rounds != 0 && rounds != 1 && rounds != 2 && rounds != 4 && rounds != 8 && rounds != 16) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  int steps = rounds <= 0 ? pick_steps(ctx, (long long)R.n * n_items) : rounds * 4;
+  while (steps < kMaxSteps && blocks_for(R.n, steps) > 2048) steps *= 2;
   TickItem proto;
   std::memset(&proto, 0, sizeof(proto));
-  item_set_rounds(proto, rounds, 1);
-  proto.res_blocks = (uint16_t)blocks_for(R.n, rounds);
+  item_set_steps(proto, steps, 1);
+  proto.res_blocks = (uint16_t)blocks_for(R.n, steps);
   {
     const long long total = (long long)proto.res_blocks * std::min(n_items, kMaxItemsPerLaunch);
     const int walk = (int)std::min<long long>(8, std::max<long long>(1, total / ctx->phys_block_target));

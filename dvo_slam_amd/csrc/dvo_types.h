@@ -7,15 +7,16 @@ namespace dvo_amd {
 
 // ---- geometry of one residual pass -------------------------------------------------------------------------------
 // A level's pixels are processed in row-major scan order (the order PointSelection::selectPointsFromImage walks them,
-// point_selection.cpp:128-149).  A wave owns one contiguous "segment" of kSegPxPerRound*rounds pixels, a 256-thread
-// block four consecutive segments; lane l of round r handles the 4 consecutive pixels seg_start + 256 r + 4 l ... +3.
+// point_selection.cpp:128-149).  A wave owns one contiguous "segment" of kStepPx * steps pixels and walks it in steps of 64
+// consecutive pixels, one per lane; a 256-thread block owns four consecutive segments.  steps is a power of two chosen per
+// tick: 1 for small launches (every step of a wave is a dependent chain of memory round trips, so short segments spread a
+// coarse level over many waves), 8 or 16 when the launch saturates the GPU anyway (fewer per-block records to reduce).
 constexpr int kWave = 64;
 constexpr int kBlockThreads = 256;
 constexpr int kWavesPerBlock = kBlockThreads / kWave;
-constexpr int kPxPerLane = 4;
-constexpr int kSegPxPerRound = kWave * kPxPerLane;            // 256
-constexpr int kMaxRounds = 16;
-constexpr int kPlanePad = kSegPxPerRound * kMaxRounds * kWavesPerBlock;  // 16384: planes are padded to a multiple of this
+constexpr int kStepPx = kWave;
+constexpr int kMaxSteps = 64;
+constexpr int kPlanePad = kStepPx * kMaxSteps * kWavesPerBlock;  // 16384: planes are padded to a multiple of this
 
 // ---- per-block record written by the residual pass ----------------------------------------------------------------
 // [0] count (int bits)  [1] first_w  [2] last_r0  [3] last_r1
@@ -61,7 +62,7 @@ struct TickItem {
   const SlotDesc *slot;
   uint16_t res_blocks, ll_blocks;  // blocks this item runs (a band of the level when the pair is sharded), <= 2048 each
   uint16_t res_first, ll_first;    // first logical block of the band (0 for the whole level)
-  uint8_t rounds_log2;             // rounds per wave, log2: low nibble residual pass, high nibble log-likelihood pass
+  uint8_t steps_log2;              // 64-pixel steps per wave, log2: low nibble residual pass, high nibble log-likelihood pass
   uint8_t flags;                   // kItem* bits
   uint16_t res_phys;               // physical blocks of the residual pass: block b walks logical blocks b, b + res_phys, ...
   int ll_cut_rank;                 // log-likelihood pass: keep valid pixels whose rank within the band is below this (Q6)
@@ -69,13 +70,13 @@ struct TickItem {
   float P[4];                      // column-major 2x2 precision: of the iteration whose likelihood is evaluated, which is
                                    // also the one the residual pass of the next iteration takes its weights from
 };
-__host__ __device__ inline int item_res_rounds(const TickItem &it) { return 1 << (it.rounds_log2 & 15); }
-__host__ __device__ inline int item_ll_rounds(const TickItem &it) { return 1 << (it.rounds_log2 >> 4); }
-inline void item_set_rounds(TickItem &it, int res_rounds, int ll_rounds) {
+__host__ __device__ inline int item_res_steps(const TickItem &it) { return 1 << (it.steps_log2 & 15); }
+__host__ __device__ inline int item_ll_steps(const TickItem &it) { return 1 << (it.steps_log2 >> 4); }
+inline void item_set_steps(TickItem &it, int res_steps, int ll_steps) {
   int a = 0, b = 0;
-  while ((1 << a) < res_rounds) ++a;
-  while ((1 << b) < ll_rounds) ++b;
-  it.rounds_log2 = (uint8_t)(a | (b << 4));
+  while ((1 << a) < res_steps) ++a;
+  while ((1 << b) < ll_steps) ++b;
+  it.steps_log2 = (uint8_t)(a | (b << 4));
 }
 constexpr unsigned kItemResBuf = 1;       // which residual buffer the residual pass writes
 constexpr unsigned kItemLlBuf = 2;        // which residual buffer the log-likelihood pass reads

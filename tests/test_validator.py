@@ -254,6 +254,9 @@ def test_gpu_validator_in_flight_limit_and_config_restore(synth):
     assert (c.first_level, c.last_level, c.max_iterations_per_level) == (2, 1, 17)  # the caller's configuration is back
     b = Cn.createConstraintProposalValidator(max_in_flight=3, **PERMISSIVE).validate(Cn.proposalsForCandidates(gkey, gcands))
     assert [(p.Reference.id, p.Current.id) for p in a] == [(p.Reference.id, p.Current.id) for p in b]
+    # with 3 pairs resident a tick covers fewer pixels than with all of them and picks shorter wave segments: sums associate
+    # differently, and the reference algorithm turns that into a different last iteration now and then (chaos caveat in
+    # tests/test_gpu_parity.py): poses agree to the size of such a step
     for p, q in zip(a, b):
-        assert synth.pose_error(p.TrackingResult.Transformation, q.TrackingResult.Transformation) <= 1e-6
+        assert synth.pose_error(p.TrackingResult.Transformation, q.TrackingResult.Transformation) <= 3e-4
     assert Cn.createConstraintProposalValidator(**PERMISSIVE).validate([]) == []
