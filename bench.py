@@ -425,10 +425,20 @@ def tile_shard_bench(args, capi, synth, sharding, dist, rank, world, device, ref
     ref = capi.RgbdImagePyramid(ref_frame[0], ref_frame[1], K, levels, device=device)
     curs = [capi.RgbdImagePyramid(f[0], f[1], K, levels, device=device) for f in cur_frames]
     trk = capi.DenseTracker(capi.Config(FirstLevel=first_level, LastLevel=0), device=device)
-    ids = [capi.comm_unique_id() if rank == 0 else None]
-    if dist is not None:
-        dist.broadcast_object_list(ids, src=0)
-    trk.comm_create(ids[0], world, rank)
+    exchange = os.environ.get("DVO_AMD_EXCHANGE", "peer")
+    if exchange == "peer":
+        # one-hop exchange: every rank maps every peer's exchange buffer (hipIpc); handles all-gathered here
+        handle = trk.exchange_create(world, rank)
+        handles = [handle]
+        if dist is not None:
+            handles = [None] * world
+            dist.all_gather_object(handles, handle)
+        trk.exchange_attach(handles)
+    else:
+        ids = [capi.comm_unique_id() if rank == 0 else None]
+        if dist is not None:
+            dist.broadcast_object_list(ids, src=0)
+        trk.comm_create(ids[0], world, rank)
     pairs_per_step = 8
     for _ in range(args.warmup + 1):
         for i in range(pairs_per_step):
@@ -458,9 +468,11 @@ def tile_shard_bench(args, capi, synth, sharding, dist, rank, world, device, ref
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"ONE synthetic {args.width}x{args.height} pair at a time, every pyramid level tile-sharded "
-                                   f"over {world} GPU(s) (bands of scan-order blocks), per-tick RCCL all-gather of the "
-                                   f"784-byte band records, {pairs_per_step} pairs per step",
-                       "sharding": "tile-shard with per-iteration all-gather (BASELINE config 4)"},
+                                   f"over {world} GPU(s) (bands of scan-order blocks), per-tick "
+                                   + ("one-hop peer exchange (mapped exchange buffers, k_exchange)" if exchange == "peer" else
+                                      "RCCL all-gather") + f" of the 784-byte band records, {pairs_per_step} pairs per step",
+                       "exchange": exchange,
+                       "sharding": "tile-shard with per-iteration exchange of the band records (BASELINE config 4)"},
             "us_per_tick": elapsed * 1e6 / max(ticks, 1),
         }), flush=True)
     if dist is not None:

@@ -32,6 +32,7 @@ EXPORTS = [
     "dvo_amd_default_validator_stages", "dvo_amd_proposals_for_candidates", "dvo_amd_validate_proposals",
     "dvo_amd_track_frame", "dvo_amd_png_info", "dvo_amd_png_read_bgr8", "dvo_amd_png_read_gray16",
     "dvo_amd_format_trajectory_line", "dvo_amd_debug_tick_log", "dvo_amd_debug_iteration", "dvo_amd_match_selection", "dvo_amd_bench_residual_pass_pairs",
+    "dvo_amd_exchange_create", "dvo_amd_exchange_attach", "dvo_amd_exchange_destroy",
 ]
 
 
@@ -155,6 +156,10 @@ def lib():
     L.dvo_amd_comm_create.argtypes = [vp, C.POINTER(C.c_ubyte), C.c_int, C.c_int]
     L.dvo_amd_comm_destroy.argtypes = [vp]
     L.dvo_amd_comm_destroy.restype = None
+    L.dvo_amd_exchange_create.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_ubyte)]
+    L.dvo_amd_exchange_attach.argtypes = [vp, C.POINTER(C.c_ubyte)]
+    L.dvo_amd_exchange_destroy.argtypes = [vp]
+    L.dvo_amd_exchange_destroy.restype = None
     L.dvo_amd_match_sharded.argtypes = [vp, vp, vp, dp, C.POINTER(CResult)]
     L.dvo_amd_match_banded.argtypes = [vp, vp, vp, dp, C.POINTER(CResult), C.c_int]
     L.dvo_amd_debug_combine_bands.argtypes = [C.c_int, dp, dp]
@@ -445,6 +450,18 @@ class DenseTracker:
         """Attach an RCCL communicator (one rank per GPU) for match_sharded."""
         buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
         _check(lib().dvo_amd_comm_create(self._h, buf, nranks, rank), "dvo_amd_comm_create")
+
+    def exchange_create(self, nranks: int, rank: int) -> bytes:
+        """Allocate this rank's exchange buffer of the one-hop peer exchange; returns its 64-byte IPC handle."""
+        buf = (C.c_ubyte * 64)()
+        _check(lib().dvo_amd_exchange_create(self._h, nranks, rank, buf), "dvo_amd_exchange_create")
+        return bytes(buf)
+
+    def exchange_attach(self, handles):
+        """handles: the 64-byte handles of all ranks in rank order (as all-gathered by the caller)."""
+        blob = b"".join(handles)
+        buf = (C.c_ubyte * len(blob)).from_buffer_copy(blob)
+        _check(lib().dvo_amd_exchange_attach(self._h, buf), "dvo_amd_exchange_attach")
 
     def match_sharded(self, reference: RgbdImagePyramid, current: RgbdImagePyramid, T_init=None) -> Result:
         """One pair tile-sharded over the communicator's ranks; every rank calls this with the same arguments."""

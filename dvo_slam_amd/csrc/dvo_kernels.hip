@@ -17,6 +17,7 @@
 // (deterministic run to run).
 //
 // This file is compiled with -ffp-contract=off: every a*b+c that may fuse is written as __builtin_fmaf explicitly.
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 
@@ -904,6 +905,39 @@ __device__ unsigned long long g_fin_stamps[8];
   } while (0)
 
 
+// The one-hop exchange of a tile-sharded pair, run by the waves of k_finalize once the rank's record stands in LDS: wave
+// (p mod n_waves) pushes it into rank p's exchange buffer (payload, system-scope release, sequence word), waits -- bounded --
+// for rank p's record of this tick to land in the local buffer and forwards it to the host.  Returns false on a timeout.
+__device__ bool exchange_records(const ExchangeArgs &a, const unsigned *own_record, unsigned seq, int wave, int n_waves, int lane) {
+  constexpr int kWords = (int)(sizeof(FinOut) / 4);
+  constexpr int kSeqWord = (int)(offsetof(FinOut, seq) / 4);
+  const int slot = (int)(seq & 1u) * a.n_ranks;
+  bool ok = true;
+  for (int p = wave; p < a.n_ranks; p += n_waves) {
+    unsigned *dst = reinterpret_cast<unsigned *>(a.peers[p] + slot + a.rank);
+    for (int w = lane; w < kWords; w += kWave)
+      if (w != kSeqWord) __hip_atomic_store(dst + w, own_record[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: the payload is visible before the sequence word
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(dst + kSeqWord, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  for (int p = wave; p < a.n_ranks; p += n_waves) {
+    const unsigned *in = reinterpret_cast<const unsigned *>(a.local + slot + p);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(in + kSeqWord, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+      __builtin_amdgcn_s_sleep(8);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)a.timeout_ticks) {
+        ok = false;
+        break;
+      }
+    }
+    // every word read at system scope: nothing of an older generation may be served from a cache
+    unsigned *out = reinterpret_cast<unsigned *>(a.host_records + p);
+    for (int w = lane; w < kWords; w += kWave) out[w] = __hip_atomic_load(in + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  return ok;
+}
+
 // One block per job.  Wave 0 folds the ordered part of the block records (count, S under both start parities, boundary
 // residual / weight) left to right and locates the log-likelihood cut; threads 256.. sum the 87 moments and the
 // log-likelihood partials in fp64 with 16-byte loads, four in flight per thread.  Two block barriers in all; the record is
@@ -1044,6 +1078,25 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const FinArgs args) {
   __syncthreads();
   DVO_FIN_STAMP(2);
 
+  // ---- tile-sharded pair: the record goes to the peers instead, theirs come back to the host (see exchange_records)
+  if (args.exchange && blockIdx.x == 0) {
+    __shared__ int sh_bad;
+    if (t == 0) sh_bad = 0;
+    __syncthreads();
+    const DVO_CONST ExchangeArgs *xp = (const DVO_CONST ExchangeArgs *)args.exchange;
+    ExchangeArgs xa;
+#pragma unroll
+    for (int i = 0; i < kMaxExchangeRanks; ++i) xa.peers[i] = xp->peers[i];
+    xa.local = xp->local, xa.host_records = xp->host_records, xa.host_seq = xp->host_seq;
+    xa.n_ranks = xp->n_ranks, xa.rank = xp->rank, xa.timeout_ticks = xp->timeout_ticks;
+    if (!exchange_records(xa, reinterpret_cast<const unsigned *>(&sh_out), args.xseq, t >> 6, kFinThreads / kWave, t & (kWave - 1)))
+      atomicOr(&sh_bad, 1);
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0)
+      __hip_atomic_store(xa.host_seq, sh_bad ? (args.xseq | 0x80000000u) : args.xseq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
   // ---- publish: wave 0 copies the record to the pinned host buffer, one system-scope fence, then the sequence word
   if (t < 64) {
     constexpr int kPieces = (int)(sizeof(FinOut) / 16);

@@ -415,6 +415,15 @@ struct dvo_amd_context {
   ncclComm_t comm = nullptr;
   int comm_ranks = 0, comm_rank = 0;
   FinOut *gather_dev = nullptr, *gather_host = nullptr;
+  // one-hop peer exchange (replaces the all-gather + D2H copy + stream sync of a tick when attached)
+  FinOut *xbuf = nullptr;                       // own exchange buffer: 2 generations x n ranks, fine-grained device memory
+  FinOut *xpeers[kMaxExchangeRanks] = {};       // every rank's buffer as mapped into this process (own one included)
+  bool xpeer_opened[kMaxExchangeRanks] = {};    // mapped with hipIpcOpenMemHandle (to be closed)
+  int x_ranks = 0, x_rank = 0;
+  FinOut *x_host = nullptr;                     // pinned: the records of a tick in rank order
+  unsigned *x_host_seq = nullptr;               // pinned: sequence word the exchange kernel writes last
+  unsigned x_seq = 0;
+  ExchangeArgs *x_args_dev = nullptr;           // device copy of the exchange description k_finalize reads
   ncclResult_t (*p_allgather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*p_comm_destroy)(ncclComm_t) = nullptr;
   unsigned tick_seq = 0;
@@ -1100,6 +1109,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
       fa.n_items = std::min(kMaxFinItems, n_here - f0);
       fa.pad = ctx->fin_stamps ? 0x57A3 : 0;
       fa.ticket = ctx->tickets + 16 * stream_slot;  // one counter per stream
+      fa.exchange = nullptr, fa.xseq = 0, fa.pad2 = 0;
       for (int i = 0; i < fa.n_items; ++i) fa.items[i] = fin_items[first + (size_t)f0 + (size_t)i];
       e = launch_finalize(fa, st);
       if (e != hipSuccess) return fail_hip("launch_finalize", e);
@@ -1194,7 +1204,10 @@ void combine_bands(const FinOut *const *recs, int n, FinOut &out) {
 int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, int n_local, bool exchange) {
   const unsigned seq = ++ctx->tick_seq;
   if (!j.have_a && !j.have_b) return DVO_AMD_OK;
-  const int nb_level = blocks_for(j.ref->lv[j.level].n, 4);  // four steps per wave: identical segments for every band count
+  // segment length as the unsharded driver picks it for one pair of this level: the same for every band count and rank
+  int steps_level = pick_steps(ctx, j.ref->lv[j.level].n);
+  while (steps_level < kMaxSteps && blocks_for(j.ref->lv[j.level].n, steps_level) > 2048) steps_level *= 2;
+  const int nb_level = blocks_for(j.ref->lv[j.level].n, steps_level);
   TickArgs ta;
   FinArgs fa;
   std::memset(&ta, 0, sizeof(ta));
@@ -1202,7 +1215,7 @@ int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, i
   fa.ticket = ctx->tickets;
   j.sub_ll = j.have_a, j.sub_res = j.have_b;
   if (j.have_b) {
-    j.b.steps = 4, j.b.n_blocks = nb_level;
+    j.b.steps = steps_level, j.b.n_blocks = nb_level;
     j.result->n_residual_passes++;
     j.alg_px += (double)j.sel->count[j.level];
   }
@@ -1218,7 +1231,7 @@ int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, i
     f.ll_partials = ctx->slots[0].ll_partials;
     f.seg_prefix_out = ctx->slots[0].seg_prefix[0];
     f.out = ctx->slots[(size_t)li].out;
-    f.out_dev = exchange ? ctx->slots[(size_t)li].out_dev : nullptr;
+    f.out_dev = exchange ? ctx->slots[(size_t)li].out_dev : nullptr;  // device copy: source of the all-gather / peer exchange
     f.seq = seq;
     if (j.have_a) {
       int first = 0, count = 0;
@@ -1243,17 +1256,41 @@ int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, i
       f.seg_prefix_out = ctx->slots[0].seg_prefix[j.b.buf];
     }
     std::memcpy(w.P, j.have_a ? j.a.P : j.precision, sizeof(w.P));
-    item_set_steps(w, 4, 4);  // the band geometry is fixed (nb_level above)
+    item_set_steps(w, steps_level, j.have_a ? j.a.steps : steps_level);
     max_blocks = std::max(max_blocks, w.res_blocks + w.ll_blocks);
   }
   ta.n_items = n_local, fa.n_items = n_local;
+  if (exchange && ctx->x_ranks > 0) fa.exchange = ctx->x_args_dev, fa.xseq = ++ctx->x_seq;  // the tail of k_finalize exchanges
   hipError_t e = launch_tick(ta, std::max(max_blocks, 1), ctx->stream);
   if (e != hipSuccess) return fail_hip("launch_tick", e);
   e = launch_finalize(fa, ctx->stream);
   if (e != hipSuccess) return fail_hip("launch_finalize", e);
 
   const FinOut *recs[kMaxBands];
-  if (exchange) {
+  if (exchange && ctx->x_ranks > 0) {
+    // one hop: every rank's finalize record goes straight into every peer's mapped exchange buffer; the same kernel waits
+    // for the peers' records and forwards them to pinned host memory, which the host polls (no collective, no copy, no
+    // stream synchronisation)
+    const unsigned xseq = ctx->x_seq;  // k_finalize of this tick carried it (set below, before the launch)
+    unsigned long long spins = 0;
+    unsigned got;
+    while (((got = __atomic_load_n(ctx->x_host_seq, __ATOMIC_ACQUIRE)) & 0x7fffffffu) != xseq) {
+#if defined(__x86_64__) || defined(__i386__)
+      __builtin_ia32_pause();
+#endif
+      if ((++spins & 0xFFFFF) == 0) {
+        const hipError_t q = hipStreamQuery(ctx->stream);
+        if (q != hipErrorNotReady && q != hipSuccess) return fail_hip("stream died while waiting for the exchange", q);
+        if (q == hipSuccess && (__atomic_load_n(ctx->x_host_seq, __ATOMIC_ACQUIRE) & 0x7fffffffu) != xseq)
+          return fail_hip("exchange finished without publishing", hipErrorUnknown);
+      }
+    }
+    if (got & 0x80000000u) {
+      g_last_error = "peer exchange timed out: a rank did not publish its band record";
+      return DVO_AMD_ERR_COMM;
+    }
+    for (int b = 0; b < n_bands; ++b) recs[b] = ctx->x_host + b;
+  } else if (exchange) {
     // per-iteration RCCL all-gather of the band records over xGMI, then one D2H copy of all of them
     if (ctx->p_allgather(ctx->slots[0].out_dev, ctx->gather_dev, sizeof(FinOut), ncclChar, ctx->comm, ctx->stream) != ncclSuccess) {
       g_last_error = "ncclAllGather failed";
@@ -1424,6 +1461,7 @@ void dvo_amd_context_destroy(dvo_amd_context *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   dvo_amd_comm_destroy(ctx);
+  dvo_amd_exchange_destroy(ctx);
   for (hipStream_t st : ctx->extra_streams) {
     (void)hipStreamSynchronize(st);
     (void)hipStreamDestroy(st);
@@ -1717,9 +1755,97 @@ void dvo_amd_comm_destroy(dvo_amd_context *ctx) {
   ctx->gather_dev = nullptr, ctx->gather_host = nullptr;
 }
 
+int dvo_amd_exchange_create(dvo_amd_context *ctx, int nranks, int rank, unsigned char *handle64) {
+  if (!ctx || !handle64 || nranks < 1 || nranks > kMaxExchangeRanks || rank < 0 || rank >= nranks) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  if (ctx->xbuf) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t bytes = sizeof(FinOut) * 2 * (size_t)nranks;
+  // fine-grained device memory: writes of other agents become visible to a running kernel (coarse-grained memory is only
+  // coherent at kernel boundaries)
+  hipError_t e = hipExtMallocWithFlags((void **)&ctx->xbuf, bytes, hipDeviceMallocFinegrained);
+  if (e != hipSuccess) {
+    ctx->xbuf = nullptr;
+    (void)hipGetLastError();
+    e = hipMalloc((void **)&ctx->xbuf, bytes);
+  }
+  if (e == hipSuccess) e = hipMemset(ctx->xbuf, 0, bytes);
+  if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->x_host, sizeof(FinOut) * kMaxExchangeRanks, hipHostMallocMapped | hipHostMallocCoherent);
+  if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->x_host_seq, 64, hipHostMallocMapped | hipHostMallocCoherent);
+  hipIpcMemHandle_t h;
+  std::memset(&h, 0, sizeof(h));
+  if (e == hipSuccess && nranks > 1) e = hipIpcGetMemHandle(&h, ctx->xbuf);
+  if (e != hipSuccess) {
+    dvo_amd_exchange_destroy(ctx);
+    return fail_hip("exchange buffer", e);
+  }
+  *ctx->x_host_seq = 0;
+  std::memcpy(handle64, &h, 64);
+  ctx->x_rank = rank;
+  ctx->x_ranks = -nranks;  // created, not attached yet
+  return DVO_AMD_OK;
+}
+
+int dvo_amd_exchange_attach(dvo_amd_context *ctx, const unsigned char *handles) {
+  if (!ctx || !ctx->xbuf || ctx->x_ranks >= 0) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  const int n = -ctx->x_ranks;
+  if (n > 1 && !handles) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(ctx->device));
+  for (int r = 0; r < n; ++r) {
+    if (r == ctx->x_rank) {
+      ctx->xpeers[r] = ctx->xbuf;
+      continue;
+    }
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handles + 64 * (size_t)r, 64);
+    void *p = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      dvo_amd_exchange_destroy(ctx);
+      return fail_hip("hipIpcOpenMemHandle", e);
+    }
+    ctx->xpeers[r] = (FinOut *)p;
+    ctx->xpeer_opened[r] = true;
+  }
+  ExchangeArgs xa;
+  std::memset(&xa, 0, sizeof(xa));
+  for (int r = 0; r < n; ++r) xa.peers[r] = ctx->xpeers[r];
+  xa.local = ctx->xbuf;
+  hipError_t e = hipHostGetDevicePointer((void **)&xa.host_records, ctx->x_host, 0);
+  if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&xa.host_seq, ctx->x_host_seq, 0);
+  xa.n_ranks = n, xa.rank = ctx->x_rank;
+  xa.timeout_ticks = 500000000u;  // 5 s
+  if (e == hipSuccess) e = hipMalloc((void **)&ctx->x_args_dev, sizeof(xa));
+  if (e == hipSuccess) e = hipMemcpy(ctx->x_args_dev, &xa, sizeof(xa), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    dvo_amd_exchange_destroy(ctx);
+    return fail_hip("exchange description", e);
+  }
+  ctx->x_ranks = n;
+  ctx->comm_ranks = n, ctx->comm_rank = ctx->x_rank;
+  return DVO_AMD_OK;
+}
+
+void dvo_amd_exchange_destroy(dvo_amd_context *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (int r = 0; r < kMaxExchangeRanks; ++r) {
+    if (ctx->xpeer_opened[r] && ctx->xpeers[r]) (void)hipIpcCloseMemHandle(ctx->xpeers[r]);
+    ctx->xpeers[r] = nullptr, ctx->xpeer_opened[r] = false;
+  }
+  if (ctx->xbuf) (void)hipFree(ctx->xbuf);
+  if (ctx->x_args_dev) (void)hipFree(ctx->x_args_dev);
+  ctx->x_args_dev = nullptr;
+  if (ctx->x_host) (void)hipHostFree(ctx->x_host);
+  if (ctx->x_host_seq) (void)hipHostFree(ctx->x_host_seq);
+  ctx->xbuf = nullptr, ctx->x_host = nullptr, ctx->x_host_seq = nullptr;
+  ctx->x_ranks = 0, ctx->x_seq = 0;
+}
+
 int dvo_amd_match_sharded(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, const double *T_init,
                           dvo_amd_result *result) {
-  if (!ctx || !ctx->comm) return DVO_AMD_ERR_COMM;
+  if (!ctx || (!ctx->comm && ctx->x_ranks <= 0)) return DVO_AMD_ERR_COMM;
   return match_one_banded(ctx, reference, current, T_init, result, ctx->comm_ranks, ctx->comm_rank, 1, true);
 }
 

@@ -105,6 +105,23 @@ struct FinOut {
 };
 static_assert(sizeof(FinOut) % 16 == 0, "FinOut is copied to the host in 16-byte pieces");
 
+// ---- one-hop exchange of band records between the GPUs of a node (tile-sharded pairs) ------------------------------------
+// Every rank owns an exchange buffer of 2 x n_ranks record slots in fine-grained device memory that its peers have mapped
+// (hipIpc).  Per tick (sequence number q) rank r writes its band record into slot (q & 1) * n_ranks + r of EVERY rank's
+// buffer, payload first, the record's sequence word last; every rank waits until the n_ranks slots of generation q & 1 carry
+// q and forwards them to its own host.  All of it happens in the tail of k_finalize (no extra launch).  A peer can be at most one tick ahead (it needs this rank's record of tick q to
+// finish tick q, and only then publishes q + 1), so two generations never collide.
+constexpr int kMaxExchangeRanks = 16;
+struct ExchangeArgs {                 // constant per context once the peers are attached; lives in device memory
+  FinOut *peers[kMaxExchangeRanks];   // exchange buffers of all ranks as mapped here (own one included)
+  const FinOut *local;                // this rank's own exchange buffer
+  FinOut *host_records;               // pinned host memory, n_ranks records in rank order
+  unsigned *host_seq;                 // pinned host word: q once all records have landed, q | 0x80000000 on a timeout
+  int n_ranks, rank;
+  unsigned timeout_ticks;             // bound on the wait in units of 10 ns (s_memrealtime)
+  unsigned pad;
+};
+
 struct FinItem {
   const float *records;   // residual-pass block records (or null), indexed by logical block of the level
   int n_blocks, block_first;      // the band this item reduces
@@ -121,6 +138,9 @@ struct FinArgs {
   int n_items;
   int pad;
   unsigned *ticket;       // device word, zero between launches: arrival counter of this launch's blocks
+  const struct ExchangeArgs *exchange;  // tile-sharded pair: push item 0's record to the peers, gather theirs (else null)
+  unsigned xseq;          // sequence number of this tick's exchange
+  unsigned pad2;
   FinItem items[kMaxFinItems];
 };
 static_assert(sizeof(FinArgs) <= 3800, "kernel argument block too large");

@@ -49,3 +49,34 @@ def split_for_threads(items: Sequence, n_threads: int) -> List[list]:
     """Deal a rank's items over its host threads (one tracker / HIP stream each)."""
     n_threads = max(1, min(n_threads, max(1, len(items))))
     return [list(items[t::n_threads]) for t in range(n_threads)]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# One-hop exchange of band records (tile-sharded pairs): the slot / sequence protocol of k_exchange (csrc/dvo_kernels.hip),
+# restated on the host so that its ordering rules can be exercised without GPUs (tests/test_distributed.py).
+# ---------------------------------------------------------------------------------------------------------------------
+def exchange_slot(seq: int, n_ranks: int, rank: int) -> int:
+    """Slot of `rank`'s record of tick `seq` in every rank's exchange buffer: two generations of n_ranks slots."""
+    return (seq & 1) * n_ranks + rank
+
+
+class ExchangeBuffer:
+    """One rank's exchange buffer over any writable (2 * n_ranks, words) uint32 array (shared memory in the tests, fine-grained
+    device memory mapped by the peers on the GPUs).  Word 0 of a slot is the sequence word, written last."""
+
+    def __init__(self, array, n_ranks: int):
+        self.a = array
+        self.n = n_ranks
+        assert array.shape[0] == 2 * n_ranks
+
+    def publish(self, seq: int, rank: int, payload):
+        row = self.a[exchange_slot(seq, self.n, rank)]
+        row[1:1 + len(payload)] = payload  # payload first ...
+        row[0] = seq                       # ... the sequence word last
+
+    def ready(self, seq: int) -> bool:
+        return all(int(self.a[exchange_slot(seq, self.n, r), 0]) == seq for r in range(self.n))
+
+    def collect(self, seq: int, words: int):
+        """the n records of tick `seq` in rank order (call once ready(seq))"""
+        return [self.a[exchange_slot(seq, self.n, r), 1:1 + words].copy() for r in range(self.n)]

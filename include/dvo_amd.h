@@ -201,6 +201,16 @@ int dvo_amd_match_many(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *refe
 int dvo_amd_comm_unique_id(unsigned char *id128);
 int dvo_amd_comm_create(dvo_amd_context *ctx, const unsigned char *id128, int nranks, int rank);
 void dvo_amd_comm_destroy(dvo_amd_context *ctx);
+/* The same exchange without a collective (SURVEY.md 8e "implementation note"): every rank maps every peer's exchange buffer
+ * (hipIpc, fine-grained device memory) and its finalize record of a tick is written straight into all of them over xGMI,
+ * payload first, a sequence word last; one small kernel per tick pushes, waits (bounded) for the peers' records and forwards
+ * them to pinned host memory the host polls: one hop, no D2H copy, no stream synchronisation, deterministic fold in rank
+ * order.  dvo_amd_exchange_create on every rank returns the 64-byte handle of its buffer; the caller all-gathers the handles
+ * (torch.distributed, MPI, a file ...) and passes all nranks x 64 bytes, in rank order, to dvo_amd_exchange_attach.  Once
+ * attached, dvo_amd_match_sharded uses this path; the RCCL communicator above stays available as the fallback. */
+int dvo_amd_exchange_create(dvo_amd_context *ctx, int nranks, int rank, unsigned char *handle64);
+int dvo_amd_exchange_attach(dvo_amd_context *ctx, const unsigned char *handles);
+void dvo_amd_exchange_destroy(dvo_amd_context *ctx);
 int dvo_amd_match_sharded(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, const double *T_init,
                           dvo_amd_result *result);
 int dvo_amd_match_banded(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, const double *T_init,

@@ -203,3 +203,140 @@ def test_bench_pair_index_covers_every_combination_before_repeating():
     assert len(set(pairs)) == 1152 and all(0 <= r < 12 and 0 <= c < 96 for r, c in pairs)
     # any 36 consecutive pairs (one launch's worth) are distinct combinations
     assert all(len(set(pairs[i:i + 36])) == 36 for i in range(0, 1152, 36))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# one-hop peer exchange: slot / generation / sequence protocol (host model of k_exchange) with 2 gloo ranks, then for
+# real with two processes on one GPU
+# ---------------------------------------------------------------------------------------------------------------------
+def test_exchange_slots_never_collide_within_one_tick_of_lead():
+    from dvo_slam_amd import sharding
+
+    n = 4
+    for seq in range(1, 50):
+        mine = {sharding.exchange_slot(seq, n, r) for r in range(n)}
+        nxt = {sharding.exchange_slot(seq + 1, n, r) for r in range(n)}
+        assert len(mine) == n and not (mine & nxt)  # a peer one tick ahead writes the other generation
+        assert mine == {sharding.exchange_slot(seq + 2, n, r) for r in range(n)}  # ... and two ticks ahead cannot happen
+
+
+def _exchange_worker(rank, world, port, shm_paths, out_q):
+    import time
+
+    import numpy as np
+    import torch.distributed as dist
+
+    from dvo_slam_amd import capi, sharding
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    words = 10
+    # every rank's buffer lives in its own shared-memory file; every rank maps all of them (hipIpcOpenMemHandle on the GPUs)
+    bufs = [sharding.ExchangeBuffer(np.memmap(pth, dtype=np.float64, mode="r+", shape=(2 * world, 1 + words)), world)
+            for pth in shm_paths]
+    rng = np.random.default_rng(5)
+    combined = []
+    for seq in range(1, 9):
+        n = 400 + 37 * seq
+        r = rng.normal(size=(n, 2)) * [0.02, 0.05]  # same data on every rank, each reports its own band
+        w = rng.uniform(0.2, 1.4, size=n)
+        lo, hi = n * rank // world, n * (rank + 1) // world
+        mine = _band_record(r[lo:hi], w[lo:hi])
+        if rank == 1 and seq % 3 == 0:
+            time.sleep(0.05)  # the straggler: rank 0 gets a tick ahead in its publishing, never two
+        for b in bufs:
+            b.publish(seq, rank, mine)
+        t0 = time.time()
+        while not bufs[rank].ready(seq):
+            assert time.time() - t0 < 30.0, "bounded wait"
+            time.sleep(0.0005)
+        recs = np.stack(bufs[rank].collect(seq, words))
+        out = capi.combine_bands(recs)  # the ordered fold every rank runs on identical inputs
+        ref = _pair_scale_reference(r, w)
+        assert out[0] == n and np.allclose(out[1:4], ref, rtol=1e-6, atol=1e-12)
+        combined.append(out)
+    dist.barrier()
+    out_q.put((rank, np.stack(combined)))
+    dist.destroy_process_group()
+
+
+def test_two_gloo_ranks_run_the_exchange_protocol(tmp_path):
+    import numpy as np
+    import torch.multiprocessing as mp
+
+    world = 2
+    paths = []
+    for r in range(world):
+        pth = str(tmp_path / f"xbuf{r}.bin")
+        np.zeros((2 * world, 11), np.float64).tofile(pth)
+        paths.append(pth)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, paths, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(results[0], results[1])  # every rank folded the identical records in the identical order
+
+
+def _gpu_exchange_worker(rank, world, conns, out_q):
+    """one process per rank, all on GPU 0 (the box has one): the IPC mapping, k_exchange and the band pipeline for real"""
+    import numpy as np
+
+    from dvo_slam_amd import capi, synth
+
+    (Ir, Zr), (Ic, Zc), _ = synth.make_pair(640, 480)
+    K = synth.intrinsics_for(640, 480)
+    ref, cur = capi.RgbdImagePyramid(Ir, Zr, K, 4), capi.RgbdImagePyramid(Ic, Zc, K, 4)
+    trk = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0))
+    handle = trk.exchange_create(world, rank)
+    # all-gather of the handles over pipes (torch.distributed in bench.py)
+    for c in conns:
+        c.send(handle)
+    handles = [None] * world
+    handles[rank] = handle
+    others = [r for r in range(world) if r != rank]
+    for c, r in zip(conns, others):
+        handles[r] = c.recv()
+    trk.exchange_attach(handles)
+    out = [trk.match_sharded(ref, cur), trk.match_sharded(cur, ref)]
+    out_q.put((rank, [o.Transformation for o in out], [[len(L["Iterations"]) for L in o.Levels] for o in out],
+               [o.n_ticks for o in out]))
+
+
+@pytest.mark.gpu
+def test_two_processes_exchange_band_records_through_mapped_buffers(monkeypatch):
+    import numpy as np
+    import torch.multiprocessing as mp
+
+    from dvo_slam_amd import capi, synth
+
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    a, b = ctx.Pipe()
+    procs = [ctx.Process(target=_gpu_exchange_worker, args=(0, world, [a], q)),
+             ctx.Process(target=_gpu_exchange_worker, args=(1, world, [b], q))]
+    for p in procs:
+        p.start()
+    results = dict((r[0], r[1:]) for r in (q.get(timeout=300) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # every rank ran the identical state machine on identical records: identical results
+    for k in range(2):
+        assert np.array_equal(results[0][0][k], results[1][0][k]) and results[0][1][k] == results[1][1][k]
+    # and they equal the two-band pipeline on one GPU (same segment geometry, same fold)
+    (Ir, Zr), (Ic, Zc), _ = synth.make_pair(640, 480)
+    K = synth.intrinsics_for(640, 480)
+    ref, cur = capi.RgbdImagePyramid(Ir, Zr, K, 4), capi.RgbdImagePyramid(Ic, Zc, K, 4)
+    trk = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0))
+    for k, (r, c) in enumerate(((ref, cur), (cur, ref))):
+        banded = trk.match_banded(r, c, 2)
+        assert [len(L["Iterations"]) for L in banded.Levels] == results[0][1][k]
+        assert synth.pose_error(banded.Transformation, results[0][0][k]) <= 1e-7

@@ -827,11 +827,9 @@ def test_track_frame_equals_oracle_and_two_single_matches(capi, orc, synth):
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n_bands", [1, 2, 3, 8])
 def test_banded_pipeline_equals_unsharded(capi, synth, pair640, n_bands, monkeypatch):
-    # the band pipeline runs four 64-pixel steps per wave whatever the launch size; pin the unsharded tracker to the same
-    # segment length so that both sum in the same order (the option is read when a tracker is created)
-    monkeypatch.setenv("DVO_AMD_STEPS_AT", "0,0,1000000000000,1000000000000")
+    # the band pipeline cuts a level into the same wave segments as the unsharded driver does for one pair, whatever the band
+    # count: both sum in the same order
     trk = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0))
-    monkeypatch.delenv("DVO_AMD_STEPS_AT")
     whole = trk.match(pair640["gr"], pair640["gc"])
     banded = trk.match_banded(pair640["gr"], pair640["gc"], n_bands)
     assert [L["ValidPixels"] for L in banded.Levels] == [L["ValidPixels"] for L in whole.Levels]
@@ -848,12 +846,19 @@ def test_sharded_match_with_single_rank_communicator(capi, synth, pair640, monke
     trk = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0))
     trk.comm_create(capi.comm_unique_id(), 1, 0)
     sharded = trk.match_sharded(pair640["gr"], pair640["gc"])
-    monkeypatch.setenv("DVO_AMD_STEPS_AT", "0,0,1000000000000,1000000000000")  # the band pipeline's segment length
-    whole_trk = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0))
-    monkeypatch.delenv("DVO_AMD_STEPS_AT")
-    whole = whole_trk.match(pair640["gr"], pair640["gc"])
+    whole = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0)).match(pair640["gr"], pair640["gc"])
     assert synth.pose_error(whole.Transformation, sharded.Transformation) <= 1e-7
     assert [len(L["Iterations"]) for L in sharded.Levels] == [len(L["Iterations"]) for L in whole.Levels]
+
+
+def test_sharded_match_with_single_rank_peer_exchange(capi, synth, pair640, monkeypatch):
+    """the one-hop exchange (exchange buffer, k_exchange, pinned forward) with one rank: equals the band pipeline"""
+    trk = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0))
+    trk.exchange_attach([trk.exchange_create(1, 0)])
+    sharded = trk.match_sharded(pair640["gr"], pair640["gc"])
+    banded = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0)).match_banded(pair640["gr"], pair640["gc"], 1)
+    assert np.array_equal(banded.Transformation, sharded.Transformation)
+    assert [len(L["Iterations"]) for L in sharded.Levels] == [len(L["Iterations"]) for L in banded.Levels]
 
 
 # ---------------------------------------------------------------------------------------------------------------------
