@@ -659,6 +659,34 @@ def test_odometry_over_a_frame_stream_composes_to_ground_truth(capi, synth):
         assert synth.pose_error(r.Transformation, hops[t + 1].Transformation @ hops[t].Transformation) < 6e-5
 
 
+def test_config4_full_size_120_frame_stream(capi, synth):
+    """BASELINE config 4 at its stated size: the 120-frame trajectory xi(t) = t * xi_step, frame-to-frame odometry
+    (ref = t - 1, cur = t) as one batch; every hop against ground truth, the chained pose against the end pose, and on a
+    sample of frames the tile-shard band pipeline (2 / 8 bands) against the unsharded alignment."""
+    n, w, h = 120, 640, 480
+    K = synth.intrinsics_for(w, h)
+    poses = synth.stream_poses(n)
+    pyr = [capi.RgbdImagePyramid(*synth.render(w, h, poses[t], frame_id=t), K, 4) for t in range(n)]
+    trk = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0))
+    hops = trk.match_batch(pyr[:-1], pyr[1:], stats=False, in_flight=72)
+    acc = np.eye(4)
+    errs = []
+    for t, r in enumerate(hops):
+        assert not r.isNaN()
+        errs.append(synth.pose_error(r.Transformation, poses[t + 1] @ np.linalg.inv(poses[t])))
+        acc = r.Transformation @ acc
+    # against GROUND TRUTH (not the oracle): the estimator's own accuracy on this scene, 1e-5 .. 1e-4 depending on the view
+    assert np.median(errs) < 5e-5 and max(errs) < 3e-4, (np.median(errs), max(errs))
+    assert synth.pose_error(acc, poses[-1]) < 2e-3  # 119 hops chained
+    for t in (0, 17, 59, 118):
+        whole = trk.match(pyr[t], pyr[t + 1])
+        for n_bands in (2, 8):
+            banded = trk.match_banded(pyr[t], pyr[t + 1], n_bands)
+            assert [[it["ValidConstraints"] for it in L["Iterations"]] for L in banded.Levels] == \
+                   [[it["ValidConstraints"] for it in L["Iterations"]] for L in whole.Levels]
+            assert synth.pose_error(whole.Transformation, banded.Transformation) <= 1e-7
+
+
 def test_speculative_level_start_gives_the_same_results(capi, synth, pair640, monkeypatch):
     """DVO_AMD_SPEC_LEVELS=1 (next level started in the tick of a level's last likelihood): fewer ticks, identical
     iteration paths and poses (the option is read when a tracker is created)."""

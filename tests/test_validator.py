@@ -243,6 +243,72 @@ def test_gpu_validator_equals_oracle(orc, V, synth, kind):
 
 
 @pytest.mark.gpu
+def test_config5_full_size_32_candidates_against_the_oracle(orc, V, synth):
+    """BASELINE config 5 at its stated size: one keyframe against 32 candidate frames, two proposals each = 64 proposals,
+    both stages, every alignment FirstLevel 3 -> LastLevel 0 (the metric's configuration), decisions and poses against
+    oracle/validator.py (the oracle side is ~200 CPU alignments)."""
+    from dvo_slam_amd import capi, constraints as Cn
+
+    n_cand = 32
+    key, cands = synth.loop_closure_scenario(640, 480, n_cand, decoys=False)
+    K = synth.intrinsics_for(640, 480)
+    cfg = dict(FirstLevel=3, LastLevel=0)
+    ocfg = orc.default_config(first_level=3, last_level=0, rcp_mode=orc.RCP_EXACT)
+    trk = capi.DenseTracker(capi.Config(**cfg))
+
+    def both(e):
+        gp, op = capi.RgbdImagePyramid(e["frame"][0], e["frame"][1], K, 4), orc.Pyramid(e["frame"][0], e["frame"][1], K, 4)
+        nb = S.neighbour_frame(synth, e, 640, 480)
+        gk = Cn.Keyframe(e["id"], gp, e["pose"], Cn.LogLikelihoodTrackingResultEvaluation(trk.match(gp, capi.RgbdImagePyramid(nb[0], nb[1], K, 4))))
+        ok = V.Keyframe(e["id"], op, e["pose"], V.LogLikelihoodTrackingResultEvaluation(orc.match(ocfg, op, orc.Pyramid(nb[0], nb[1], K, 4))))
+        return gk, ok
+
+    gkey, okey = both(key)
+    pairs = [both(c) for c in cands]
+    gcands, ocands = [p[0] for p in pairs], [p[1] for p in pairs]
+    gprops, oprops = Cn.proposalsForCandidates(gkey, gcands), V.proposals_for_candidates(okey, ocands)
+    assert len(gprops) == len(oprops) == 64
+    th = dict(min_constraint_ratio=0.2, ratio_coarse=-1e300, ratio_fine=-1e300)
+    gv = Cn.createConstraintProposalValidator(tracker=trk, max_in_flight=72, **th)
+    ov = V.create_constraint_proposal_validator(**th)
+    for st in gv.stages:  # "all First=3, Last=0 for the metric" (SURVEY.md 8d config 5)
+        st.TrackingConfig.FirstLevel, st.TrackingConfig.LastLevel = 3, 0
+    for st in ov.stages:
+        st.TrackingConfig.first_level, st.TrackingConfig.last_level = 3, 0
+    g, o = gv.validate(gprops), ov.validate(oprops)
+    assert len(g) == len(o) == n_cand  # keepBest: one constraint per candidate survives
+    # keepBest chooses between a proposal and its cross-validation inverse by a likelihood-ratio score; the two scores of a
+    # pair are within ~1 % of each other and GPU / oracle likelihoods differ by that much when their last iterations differ
+    # (chaos caveat), so the surviving DIRECTION may differ: compare per unordered pair, inverting where it does
+    og = {frozenset((p.Reference.id, p.Current.id)): p for p in o}
+    assert {frozenset((p.Reference.id, p.Current.id)) for p in g} == set(og)
+    # (likewise which of the two initialisations of a direction survives.)  Different survivors are different alignments of
+    # the same pair: they agree to the estimator's accuracy (2e-3 here), identical survivors to the forked-path bound.
+    same_direction = close = 0
+    for p in g:
+        q = og[frozenset((p.Reference.id, p.Current.id))]
+        assert [v.Decision for v in p.Votes] == [v.Decision for v in q.Votes]
+        Tq = q.TrackingResult["T"]
+        if (p.Reference.id, p.Current.id) == (q.Reference.id, q.Current.id):
+            same_direction += 1
+        else:
+            Tq = np.linalg.inv(Tq)
+        err = synth.pose_error(p.TrackingResult.Transformation, Tq)
+        assert err <= 2e-3
+        close += err <= DIVERGED_PATH_TOL
+        # (the scores themselves are likelihood ratios taken at level 0, where the noise-free synthetic depth makes the
+        #  likelihood move by 10 % and more with a 1e-7 change of the pose -- tests/test_gpu_parity.py, DRIFT tolerances --
+        #  so only the decisions they lead to are compared here; the 6-candidate tests above compare the values at levels 3..1)
+    assert same_direction >= n_cand // 2 and close >= n_cand // 2, (same_direction, close)
+    truth = {c["id"]: c["pose_true"] for c in cands}
+    truth[key["id"]] = np.eye(4)
+    for p in g:  # and every kept constraint is the right relative pose (cur <- ref, dense_tracking.cpp:371)
+        assert not p.TrackingResult.isNaN()
+        want = truth[p.Current.id] @ np.linalg.inv(truth[p.Reference.id])
+        assert synth.pose_error(want, p.TrackingResult.Transformation) < 2e-3
+
+
+@pytest.mark.gpu
 def test_gpu_validator_in_flight_limit_and_config_restore(synth):
     from dvo_slam_amd import capi, constraints as Cn
 
