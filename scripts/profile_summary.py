@@ -42,11 +42,17 @@ def main():
         # whose reads are a mix of 16-byte gathers and 4-byte streaming loads); WRITE_SIZE is exact for streaming stores
         out["traffic_bytes_per_launch"] = (2.0 * out["FETCH_SIZE_kb_avg_per_launch"] + out["WRITE_SIZE_kb_avg_per_launch"]) * 1024.0
         out["traffic_bytes_per_launch_uncorrected"] = (out["FETCH_SIZE_kb_avg_per_launch"] + out["WRITE_SIZE_kb_avg_per_launch"]) * 1024.0
-        out["command"] = "python bench.py --steps 2 --warmup 1 --prime 1 --no-extras --no-cpu-baseline (one rocprofv3 --pmc pass per counter)"
+        out["command"] = ("python bench.py --steps 2 --warmup 1 --prime 1 --no-extras --no-cpu-baseline under rocprofv3 --pmc "
+                          "FETCH_SIZE and --pmc WRITE_SIZE (one pass each)")
         out["bench_value_under_pmc"] = bench["value"]
-        out["note"] = ("average over every k_tick dispatch of the run; the 9 pyramids of the bench (180 MB) and the residual "
-                       "buffers stay resident in the 256 MiB Infinity Cache / L2, so most algorithmic bytes never reach the "
-                       "memory-side counters")
+        out["alg_bytes_per_launch"] = bench["roofline"]["alg_bytes_per_launch"]
+        out["note"] = ("average over every k_tick dispatch of the run (default workload: every pair of a step a different "
+                       "(keyframe, frame) combination, 108 pyramids = 2.1 GB, far beyond the 256 MiB Infinity Cache).  FETCH_SIZE "
+                       "counts 64 B per 128-B request of a wide coalesced read on gfx950, so the corrected figure (2 x FETCH + "
+                       "WRITE) is an upper bound for this kernel's mix of 16-byte gathers and 4-byte streaming loads and the "
+                       "uncorrected one a lower bound; alg_bytes_per_launch is the algorithmic figure (56 B per selected pixel) of "
+                       "the single-stream timing pass of the same run.  Traffic <= algorithmic bytes: no wasted re-reads; the "
+                       "residual spill / re-read (16 of the 56 B) mostly stays in L2 / Infinity Cache.")
         print(json.dumps(out, indent=1))
 
 
