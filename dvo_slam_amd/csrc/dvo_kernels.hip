@@ -775,8 +775,7 @@ __device__ __forceinline__ LevelPairDesc load_desc(const TickItem &it) {
 }
 
 template <int RMODE, int ACC>
-__device__ __forceinline__ void tick_body(const TickItem &it) {
-  const int bx = (int)blockIdx.x;
+__device__ __forceinline__ void tick_body(const TickItem &it, const int bx) {
   const int rp = it.res_phys;
   if (bx >= rp + it.ll_blocks) return;
   const LevelPairDesc d = load_desc(it);
@@ -794,7 +793,17 @@ __device__ __forceinline__ void tick_body(const TickItem &it) {
 
 template <int RMODE, int ACC, int OCC>
 __global__ __launch_bounds__(kBlockThreads, OCC) void k_tick(const TickArgs args) {
-  tick_body<RMODE, ACC>(args.items[blockIdx.y]);
+  if (args.compact) {
+    // one-dimensional grid: which item owns this block?  Lanes 0 .. n_items look at the items' first block groups; the
+    // owner is the last item that starts at or before this block's group (every wave finds the same one).
+    const int lane = threadIdx.x & (kWave - 1);
+    const unsigned g = blockIdx.x >> 3;
+    const unsigned first = lane <= args.n_items ? (unsigned)args.group_first[lane < kMaxItemsPerLaunch + 4 ? lane : 0] : 0xFFFFFFFFu;
+    const int idx = __builtin_amdgcn_readfirstlane(__popcll(__ballot(first <= g)) - 1);
+    tick_body<RMODE, ACC>(args.items[idx], (int)blockIdx.x - ((int)args.group_first[idx] << 3));
+  } else {
+    tick_body<RMODE, ACC>(args.items[blockIdx.y], (int)blockIdx.x);
+  }
 }
 
 // The same tick with the items in a device-resident table (uploaded in-stream before the launch): for launches with more
@@ -811,7 +820,7 @@ __global__ __launch_bounds__(kBlockThreads, OCC) void k_tick_table(const TickIte
   for (int i = 0; i < 12; ++i) it.kt[i] = p->kt[i];
 #pragma unroll
   for (int i = 0; i < 4; ++i) it.P[i] = p->P[i];
-  tick_body<RMODE, ACC>(it);
+  tick_body<RMODE, ACC>(it, (int)blockIdx.x);
 }
 
 static int g_reduce_mode = -1;  // DVO_AMD_REDUCE=0: ds_bpermute butterfly instead of DPP (debug cross-check)
@@ -835,10 +844,31 @@ static TickKernel pick_tick_kernel() {
   return g_occ == 3 ? k_tick<1, 2, 3> : g_occ == 5 ? k_tick<1, 2, 5> : k_tick<1, 2, 4>;
 }
 
+// A tick's items are at different pyramid levels: the two-dimensional grid (blocks of the largest item x items) launches
+// mostly blocks that return at once, and the dispatcher starts only ~4 of them per nanosecond.  When more than half of the
+// grid would be such blocks the launch goes out one-dimensional with every item's blocks back to back.
+int tick_args_layout(TickArgs &args, int max_blocks) {
+  unsigned groups = 0;
+  for (int i = 0; i < args.n_items; ++i) {
+    args.group_first[i] = (uint16_t)groups;
+    groups += ((unsigned)args.items[i].res_phys + args.items[i].ll_blocks + 7u) >> 3;
+  }
+  for (int i = args.n_items; i < kMaxItemsPerLaunch + 4; ++i) args.group_first[i] = (uint16_t)groups;
+  const long long grid2d = (long long)((max_blocks + 7) & ~7) * args.n_items;
+  static int mode = -1;  // DVO_AMD_COMPACT_GRID=0 / 1 forces a layout (tuning)
+  if (mode < 0) {
+    const char *e = getenv("DVO_AMD_COMPACT_GRID");
+    mode = e ? (e[0] == '0' ? 0 : 1) : 2;
+  }
+  args.compact = groups > 0 && groups < 65536 && (mode == 1 || (mode == 2 && 2ll * 8 * groups < grid2d)) ? 1 : 0;
+  return (int)(groups * 8);
+}
+
 hipError_t launch_tick(const TickArgs &args, int max_blocks, hipStream_t stream, hipEvent_t t_start, hipEvent_t t_stop) {
   TickKernel kernel = pick_tick_kernel();
   if (args.n_items <= 0 || max_blocks <= 0) return hipSuccess;
   dim3 grid((unsigned)((max_blocks + 7) & ~7), (unsigned)args.n_items, 1);
+  if (args.compact) grid = dim3((unsigned)args.group_first[args.n_items] * 8u, 1, 1);
   if (t_start && t_stop) {
     void *kargs[] = {const_cast<TickArgs *>(&args)};
     const hipError_t e = hipExtLaunchKernel(reinterpret_cast<const void *>(kernel), grid, dim3(kBlockThreads), kargs, 0, stream,

@@ -1055,7 +1055,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
     const bool use_table = n_here > kMaxItemsPerLaunch;
     const size_t stream_slot = ctx->timing ? 0 : (grp.stream_first + launch_index) % kMaxTickStreams;
     ta.n_items = use_table ? 0 : n_here;
-    ta.pad = 0;
+    ta.compact = 0;
     int max_blocks = 0;
     TickItem *stage = use_table ? ctx->item_host + stream_slot * kMaxTableItems : ta.items;
     // Optionally (DVO_AMD_PHYS_BLOCKS) a physical block walks several logical ones, so that only the first pays the
@@ -1101,6 +1101,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
       ctx->tick_log_pending.insert(ctx->tick_log_pending.end(), rec, rec + kTickLogFields);
     }
     hipEvent_t t0 = ctx->timing ? ctx->events[ev].first : nullptr, t1 = ctx->timing ? ctx->events[ev].second : nullptr;
+    if (!use_table) (void)tick_args_layout(ta, max_blocks);
     hipError_t e = use_table ? launch_tick_table(ctx->item_dev + stream_slot * kMaxTableItems, n_here, max_blocks, st, t0, t1)
                              : launch_tick(ta, max_blocks, st, t0, t1);
     if (e != hipSuccess) return fail_hip("launch_tick", e);
@@ -2075,7 +2076,7 @@ int dvo_amd_bench_residual_pass_pairs(dvo_amd_context *ctx, int n_items, dvo_amd
     for (int first = 0; first < n_items; first += per) {
       TickArgs ta;
       ta.n_items = std::min(per, n_items - first);
-      ta.pad = 0;
+      ta.compact = 0;
       for (int i = 0; i < ta.n_items; ++i) {
         TickItem &w = ta.items[i];
         w = proto;

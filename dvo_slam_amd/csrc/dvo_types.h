@@ -86,10 +86,13 @@ static_assert(sizeof(TickItem) == 104, "TickItem is packed to fit many items int
 constexpr int kMaxItemsPerLaunch = 36;
 struct TickArgs {
   int n_items;
-  int pad;
+  int compact;  // 0: grid (blocks of the largest item, n_items); 1: one-dimensional grid without the blocks no item owns
+  // compact grid: item i owns block groups [group_first[i], group_first[i + 1]) of 8 blocks each (its blocks start on a
+  // multiple of 8, so that "blocks b and b + 8 share an XCD" holds inside every item)
+  uint16_t group_first[kMaxItemsPerLaunch + 4];
   TickItem items[kMaxItemsPerLaunch];
 };
-static_assert(sizeof(TickArgs) <= 3800, "kernel argument block too large");
+static_assert(sizeof(TickArgs) <= 3900, "kernel argument block too large");
 
 // what the finalize kernel hands to the host for one job (lives in pinned host memory)
 struct FinOut {
@@ -148,8 +151,11 @@ static_assert(sizeof(FinArgs) <= 3800, "kernel argument block too large");
 // ---- launch wrappers (dvo_kernels.hip) ----------------------------------------------------------------------------
 // t_start / t_stop (both or neither): events that receive the begin / end time stamps of this dispatch itself
 // (hipExtLaunchKernelGGL), i.e. the kernel's own duration without the launch latency an event pair around it would add
+// grid: args.compact ? (args.group_first[n_items] * 8) blocks : (max_blocks rounded up to 8, n_items)
 hipError_t launch_tick(const TickArgs &args, int max_blocks, hipStream_t stream, hipEvent_t t_start = nullptr,
                        hipEvent_t t_stop = nullptr);
+// fills group_first / compact from the items' block counts; returns the number of blocks of the compact grid
+int tick_args_layout(TickArgs &args, int max_blocks);
 // the same kernel reading its items from a device-resident table (more pairs per launch than the argument block holds)
 constexpr int kMaxTableItems = 288;
 hipError_t launch_tick_table(const TickItem *items_dev, int n_items, int max_blocks, hipStream_t stream,
