@@ -52,10 +52,16 @@ constexpr size_t kTickLogFields = 8;  // doubles per logged launch (dvo_amd_debu
 constexpr int kMaxTickStreams = 8;  // streams a context spreads the launches / pair groups of its ticks over
 
 // ---- per-device shared state: a prep stream and a pool of pyramid slabs ------------------------------------------
+// Level descriptors (pointers + intrinsics of a pyramid level, ~1 KB per pyramid) are read by every block of every launch
+// before it can touch a pixel.  Inside a pyramid's own 20 MB slab they would be a cold line in HBM each time a pair comes
+// back to it; kept together in a small arena per device they stay in L2 / Infinity Cache.
+constexpr size_t kDescEntryBytes = 1024;
+constexpr size_t kDescChunkEntries = 256;
 struct DeviceState {
   std::mutex mu;
   hipStream_t prep_stream = nullptr;
   std::vector<std::pair<size_t, void *>> free_slabs;
+  std::vector<void *> desc_chunks, desc_free;
 };
 constexpr int kMaxDevices = 16;
 DeviceState g_dev[kMaxDevices];
@@ -83,6 +89,27 @@ int slab_alloc(int device, size_t bytes, void **out) {
   return DVO_AMD_OK;
 }
 
+int desc_alloc(int device, void **out) {
+  DeviceState &d = g_dev[device];
+  std::lock_guard<std::mutex> lk(d.mu);
+  if (d.desc_free.empty()) {
+    void *chunk = nullptr;
+    HIP_TRY(hipMalloc(&chunk, kDescEntryBytes * kDescChunkEntries));
+    d.desc_chunks.push_back(chunk);
+    for (size_t i = kDescChunkEntries; i-- > 0;) d.desc_free.push_back((char *)chunk + i * kDescEntryBytes);
+  }
+  *out = d.desc_free.back();
+  d.desc_free.pop_back();
+  return DVO_AMD_OK;
+}
+
+void desc_free(int device, void *p) {
+  if (!p) return;
+  DeviceState &d = g_dev[device];
+  std::lock_guard<std::mutex> lk(d.mu);
+  d.desc_free.push_back(p);
+}
+
 void slab_free(int device, size_t bytes, void *p) {
   DeviceState &d = g_dev[device];
   std::lock_guard<std::mutex> lk(d.mu);
@@ -105,6 +132,7 @@ struct Selection {
   int count[DVO_AMD_MAX_LEVELS];  // PointSelection size (includes an odd trailing point)
   int last[DVO_AMD_MAX_LEVELS];   // index of the last selected pixel
   RefLevelDesc *ref_desc;         // device, [levels]
+  void *desc_entry = nullptr;     // arena entry holding ref_desc (null: shares the pyramid's entry)
   void *extra_slab;               // owned allocation (null for the selection carved from the pyramid slab)
   size_t extra_bytes;
 };
@@ -129,8 +157,9 @@ struct dvo_amd_pyramid {
   void *slab = nullptr;
   size_t slab_bytes = 0;
   int *counters = nullptr;  // device, [levels][2], inside the slab
-  CurLevelDesc *cur_desc = nullptr;   // device, [levels], inside the slab
-  RefLevelDesc *ref_desc0 = nullptr;  // device, [levels], inside the slab: room for the first selection's descriptors
+  void *desc_entry = nullptr;         // this pyramid's entry of the device's descriptor arena
+  CurLevelDesc *cur_desc = nullptr;   // device, [levels], in desc_entry
+  RefLevelDesc *ref_desc0 = nullptr;  // device, [levels], in desc_entry: room for the first selection's descriptors
   std::mutex mu;
   // entries are never moved or removed while the pyramid lives: a pointer handed out by pyramid_selection() stays valid and may
   // be read without the lock (only the vector itself needs `mu`)
@@ -160,9 +189,8 @@ size_t pyramid_layout(dvo_amd_pyramid *p, char *base) {
     L.ty = (float *)carve(sizeof(float) * L.h);
   }
   p->counters = (int *)carve(sizeof(int) * 2 * DVO_AMD_MAX_LEVELS);
-  p->cur_desc = (CurLevelDesc *)carve(sizeof(CurLevelDesc) * DVO_AMD_MAX_LEVELS);
-  p->ref_desc0 = (RefLevelDesc *)carve(sizeof(RefLevelDesc) * DVO_AMD_MAX_LEVELS);
-  (void)carve(8192);  // tail: the residual pass touches (prefetches) up to 2 KB past the planes it reads
+  static_assert(sizeof(CurLevelDesc) * DVO_AMD_MAX_LEVELS <= 640 && 640 + sizeof(RefLevelDesc) * DVO_AMD_MAX_LEVELS <= kDescEntryBytes,
+                "a pyramid's level descriptors fit one arena entry");
   return off;
 }
 
@@ -225,10 +253,19 @@ int pyramid_build(int device, const float *src_i, const float *src_z, const RawF
     return rc;
   }
   pyramid_layout(p, (char *)p->slab);
+  rc = desc_alloc(device, &p->desc_entry);
+  if (rc) {
+    slab_free(device, p->slab_bytes, p->slab);
+    delete p;
+    return rc;
+  }
+  p->cur_desc = (CurLevelDesc *)p->desc_entry;
+  p->ref_desc0 = (RefLevelDesc *)((char *)p->desc_entry + 640);
 
   // everything below is enqueued on the device's prep stream; the mutex serialises users of that stream's ordering needs
   auto bail = [&](int code) {
     slab_free(device, p->slab_bytes, p->slab);
+    desc_free(device, p->desc_entry);
     delete p;
     return code;
   };
@@ -324,13 +361,18 @@ int pyramid_selection(dvo_amd_pyramid *p, float ti, float td, const Selection **
     for (int l = 0; l < p->n_levels; ++l) s.zsel[l] = p->lv[l].zsel0;
     s.ref_desc = p->ref_desc0;
   } else {
-    size_t bytes = align_up(sizeof(RefLevelDesc) * DVO_AMD_MAX_LEVELS, 256);
+    size_t bytes = 0;
     for (int l = 0; l < p->n_levels; ++l) bytes += align_up(sizeof(float) * p->lv[l].n_pad, 256);
-    bytes += 8192;  // tail: the residual pass prefetches a little past the plane it reads
-    HIP_TRY(hipMalloc(&s.extra_slab, bytes));
+    rc = desc_alloc(p->device, &s.desc_entry);
+    if (rc) return rc;
+    const hipError_t em = hipMalloc(&s.extra_slab, bytes);
+    if (em != hipSuccess) {
+      desc_free(p->device, s.desc_entry);
+      return fail_hip("selection planes", em);
+    }
     s.extra_bytes = bytes;
-    s.ref_desc = (RefLevelDesc *)s.extra_slab;
-    size_t off = align_up(sizeof(RefLevelDesc) * DVO_AMD_MAX_LEVELS, 256);
+    s.ref_desc = (RefLevelDesc *)s.desc_entry;
+    size_t off = 0;
     for (int l = 0; l < p->n_levels; ++l) {
       s.zsel[l] = (float *)((char *)s.extra_slab + off);
       off += align_up(sizeof(float) * p->lv[l].n_pad, 256);
@@ -340,6 +382,7 @@ int pyramid_selection(dvo_amd_pyramid *p, float ti, float td, const Selection **
   auto fail = [&](const char *what, hipError_t e) {
     (void)hipStreamSynchronize(st);
     if (s.extra_slab) (void)hipFree(s.extra_slab);
+    desc_free(p->device, s.desc_entry);
     return fail_hip(what, e);
   };
   RefLevelDesc ref_host[DVO_AMD_MAX_LEVELS];
@@ -1524,8 +1567,11 @@ void dvo_amd_pyramid_release(dvo_amd_pyramid *p) {
   if (!p) return;
   if (p->refs.fetch_sub(1) != 1) return;
   (void)hipSetDevice(p->device);
-  for (auto &s : p->selections)
+  for (auto &s : p->selections) {
     if (s->extra_slab) (void)hipFree(s->extra_slab);
+    desc_free(p->device, s->desc_entry);
+  }
+  desc_free(p->device, p->desc_entry);
   slab_free(p->device, p->slab_bytes, p->slab);
   delete p;
 }
