@@ -48,6 +48,7 @@ int fail_hip(const char *what, hipError_t e) {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+constexpr int kSpecLevelsMaxPairs = 8;  // speculative level starts (context::spec_levels) up to this many resident pairs
 constexpr size_t kTickLogFields = 8;  // doubles per logged launch (dvo_amd_debug_tick_log)
 constexpr int kMaxTickStreams = 8;  // streams a context spreads the launches / pair groups of its ticks over
 
@@ -444,9 +445,11 @@ struct dvo_amd_context {
   TickItem *item_host = nullptr, *item_dev = nullptr;  // [kMaxTickStreams][kMaxTableItems]
   int stage_owner[kMaxTickStreams] = {0, 0, 0, 0, 0, 0, 0, 0};  // pair group (id + 1) whose table upload last used a staging slot
   int items_per_launch = kMaxItemsPerLaunch;           // DVO_AMD_ITEMS_PER_LAUNCH (<= kMaxTableItems)
-  bool spec_levels = false;                            // DVO_AMD_SPEC_LEVELS=1: start the next level speculatively in the tick of a
-                                                       // level's last likelihood (-2..3 ticks per pair, but a converged level's last
-                                                       // likelihood is rejected about half the time: +3 % residual work; off)
+  int spec_levels = -1;                                // start the next level speculatively in the tick of a level's last
+                                                       // likelihood: -2..3 ticks per pair, but a converged level's last likelihood is
+                                                       // rejected about half the time (+3 % residual work).  -1 (default): only
+                                                       // while at most kSpecLevelsMaxPairs pairs are resident in the tick (latency
+                                                       // matters, the GPU has room); DVO_AMD_SPEC_LEVELS=0 never, =1 always
   int phys_block_target = 1 << 30;                     // DVO_AMD_PHYS_BLOCKS=n: fold a launch's residual-pass blocks down to ~n
                                                        // physical blocks that walk several logical ones (measured: slower, off)
   // DVO_AMD_HOST_PROF=1: where the host thread spends its time (printed when the context is destroyed)
@@ -984,7 +987,9 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
   const double t_begin = ctx->host_prof ? now_ns() : 0.0;
   grp.in_flight = false;
   long long total_px = 0;
-  const bool speculate_levels = ctx->spec_levels;
+  int active_pairs = 0;
+  for (size_t ji = grp.lo; ji < grp.hi; ++ji) active_pairs += jobs[ji].done ? 0 : 1;
+  const bool speculate_levels = ctx->spec_levels == 1 || (ctx->spec_levels < 0 && active_pairs <= kSpecLevelsMaxPairs);
   auto wants_spec = [&](const Job &j) {
     return speculate_levels && j.have_a && !j.have_b && !j.a.cont && j.level > j.cfg->last_level;
   };
@@ -1478,7 +1483,7 @@ int dvo_amd_context_create(int device, const dvo_amd_config *cfg, dvo_amd_contex
   ctx->fin_stamps = fs && fs[0] == '1';
   const char *hp = getenv("DVO_AMD_HOST_PROF");
   ctx->host_prof = hp && hp[0] == '1';
-  if (const char *sl = getenv("DVO_AMD_SPEC_LEVELS")) ctx->spec_levels = sl[0] == '1';
+  if (const char *sl = getenv("DVO_AMD_SPEC_LEVELS")) ctx->spec_levels = sl[0] == '1' ? 1 : 0;
   if (const char *fs2 = getenv("DVO_AMD_FAULT_SLOT_ALLOC")) ctx->fault_slot_alloc = atoi(fs2);
   if (const char *sa = getenv("DVO_AMD_STEPS_AT"))
     (void)sscanf(sa, "%lld,%lld,%lld,%lld", &ctx->steps_at[0], &ctx->steps_at[1], &ctx->steps_at[2], &ctx->steps_at[3]);

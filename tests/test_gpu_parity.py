@@ -102,12 +102,16 @@ def test_residuals_and_validity_bit_exact(capi, orc, synth, pair640, level):
         assert np.array_equal(_bits(g[m]), _bits(o[m]))
 
 
-def test_error_image_matches_residuals(capi, pair640):
+def test_error_image_matches_the_oracle(capi, orc, pair640):
+    """computeIntensityErrorImage (dense_tracking.cpp:378-444): |intensity residual| at every selected reference pixel whose
+    warp is valid, 0 elsewhere -- against the oracle's residual stage, bit for bit"""
     trk = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0))
-    img = trk.computeIntensityErrorImage(pair640["gr"], pair640["gc"], pair640["Tgt"], level=1)
-    res, n = trk.residuals(pair640["gr"], pair640["gc"], 1, pair640["Tgt"])
-    assert np.array_equal(img, np.where(np.isnan(res[..., 0]), 0.0, np.abs(res[..., 0])).astype(np.float32))
-    assert (img > 0).sum() <= n
+    for level in (1, 3):
+        img = trk.computeIntensityErrorImage(pair640["gr"], pair640["gc"], pair640["Tgt"], level=level)
+        o, n = _oracle_residual_image(orc, pair640["orr"], pair640["occ"], level, pair640["Tgt"], img.shape)
+        want = np.where(np.isnan(o[..., 0]), 0.0, np.abs(o[..., 0])).astype(np.float32)
+        assert np.array_equal(_bits(img), _bits(want))
+        assert (img > 0).sum() <= n
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -688,13 +692,17 @@ def test_config4_full_size_120_frame_stream(capi, synth):
 
 
 def test_speculative_level_start_gives_the_same_results(capi, synth, pair640, monkeypatch):
-    """DVO_AMD_SPEC_LEVELS=1 (next level started in the tick of a level's last likelihood): fewer ticks, identical
-    iteration paths and poses (the option is read when a tracker is created)."""
+    """Speculative level starts (next level started in the tick of a level's last likelihood; always with
+    DVO_AMD_SPEC_LEVELS=1, by default while at most 8 pairs are resident): fewer ticks, identical iteration paths and poses
+    (the option is read when a tracker is created)."""
     cfg = capi.Config(FirstLevel=3, LastLevel=0)
+    monkeypatch.setenv("DVO_AMD_SPEC_LEVELS", "0")  # (the default speculates while at most 8 pairs are resident)
     plain = capi.DenseTracker(cfg)
     monkeypatch.setenv("DVO_AMD_SPEC_LEVELS", "1")
     spec = capi.DenseTracker(cfg)
     monkeypatch.delenv("DVO_AMD_SPEC_LEVELS")
+    auto = capi.DenseTracker(cfg)
+    assert auto.match(pair640["gr"], pair640["gc"]).n_ticks == spec.match(pair640["gr"], pair640["gc"]).n_ticks
     fewer = 0
     for ref, cur in ((pair640["gr"], pair640["gc"]), (pair640["gc"], pair640["gr"]), (pair640["gr"], pair640["gr"])):
         a, b = plain.match(ref, cur), spec.match(ref, cur)
