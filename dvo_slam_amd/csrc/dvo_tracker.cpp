@@ -1669,7 +1669,7 @@ int dvo_amd_match_many(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *refe
 
   // Pairs enter a free slot as soon as one opens up: the launch of every tick stays full although pairs need different
   // numbers of iterations.  A pair's state machine never looks at another pair, so results do not depend on the schedule
-  // (except through the rounds-per-wave choice, which only changes the order partial sums are taken in).
+  // (except through the wave-segment length a tick picks, which only changes the order partial sums are taken in).
   std::vector<Job> jobs((size_t)in_flight);
   std::vector<int> job_of_slot((size_t)in_flight, -1);
   for (Job &j : jobs) j.done = true;
