@@ -275,11 +275,23 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
 
   // K*T lives in vector registers: as scalars the 12 values do not fit next to the descriptors, and the compiler re-reads
   // them from the kernel arguments inside every step, with a full scalar-memory wait in front of the projection
+  // (ACC 2 is short of registers instead: there K*T sits in LDS, written once per block, and is fetched at the top of every
+  // step with three broadcast reads, so that it is not live while the gathers and the accumulators are)
+  constexpr bool kKtLds = ACC == 2;
+  constexpr bool kLatePrefetch = ACC == 2;  // ... and the next step's reference scalars are requested after the gathers have landed
+  __shared__ __attribute__((aligned(16))) float kt_lds[12];
   float kt[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) {
     kt[i] = it.kt[i];
-    DVO_OPAQUE(kt[i]);
+    if (!kKtLds) DVO_OPAQUE(kt[i]);
+  }
+  if (kKtLds) {
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) kt_lds[i] = kt[i];
+    }
+    __syncthreads();
   }
   const bool unit_w = (it.flags & kItemUnitWeights) != 0;
   const float P0 = it.P[0], P1 = it.P[1], P2 = it.P[2], P3 = it.P[3];
@@ -351,10 +363,19 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
     idx += kWave;
     pcol += kWave;
     while (pcol >= (unsigned)w) pcol -= (unsigned)w, ++prow;
-    if (prefetch) {
+    auto prefetch_next = [&]() __attribute__((always_inline)) {
       n_z = ld_off<float>(p_z, 4u * idx), n_i = ld_off<float>(p_i, 4u * idx), n_ix = ld_off<float>(p_ix, 4u * idx),
       n_iy = ld_off<float>(p_iy, 4u * idx);
       n_tx = ld_off<float>(p_tx, 4u * pcol), n_ty = ld_off<float>(p_ty, 4u * (prow < d.h ? prow : d.h - 1));
+    };
+    if (prefetch && !kLatePrefetch) prefetch_next();
+    float ktl[12];
+    if (kKtLds) {
+      const v4f *kp = reinterpret_cast<const v4f *>(kt_lds);
+      asm volatile("" : "+v"(kp));  // not loop invariant to the compiler: re-read every step
+      const v4f k0 = kp[0], k1 = kp[1], k2 = kp[2];
+      ktl[0] = k0.x, ktl[1] = k0.y, ktl[2] = k0.z, ktl[3] = k0.w, ktl[4] = k1.x, ktl[5] = k1.y, ktl[6] = k1.z, ktl[7] = k1.w;
+      ktl[8] = k2.x, ktl[9] = k2.y, ktl[10] = k2.z, ktl[11] = k2.w;
     }
 
     // ---- switch to round-toward-zero: every float that crosses is made opaque on both sides of the s_setreg
@@ -364,7 +385,7 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
     float r0, r1, e2, e3, e4, e5;
     bool ok;
     {
-      const Proj p = project_pixel_rtz(kt, d, x, y, z);
+      const Proj p = project_pixel_rtz(kKtLds ? ktl : kt, d, x, y, z);
       Gathered g;
       if (DVO_ABLATE & 2) {
         const v4f c = {p.u, 1.5f, p.v, 0.25f};
@@ -389,6 +410,7 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
     round_to_nearest();
     DVO_OPAQUE(r0); DVO_OPAQUE(r1); DVO_OPAQUE(e2); DVO_OPAQUE(e3); DVO_OPAQUE(e4); DVO_OPAQUE(e5);
     DVO_OPAQUE(x); DVO_OPAQUE(y); DVO_OPAQUE(z);
+    if (prefetch && kLatePrefetch) prefetch_next();
 
     // spill the residual of this iteration for the log-likelihood pass (NaN marks an invalid pixel)
     {
@@ -981,8 +1003,8 @@ __device__ bool exchange_records(const ExchangeArgs &a, const unsigned *own_reco
 
 // One block per job.  Wave 0 folds the ordered part of the block records (count, S under both start parities, boundary
 // residual / weight) left to right and locates the log-likelihood cut; waves 1.. sum the 87 moments and the
-// log-likelihood partials in fp64 with 16-byte loads, four in flight per thread.  Two block barriers in all; the record is
-// assembled in LDS and pushed to the pinned host buffer by wave 0 with one system-scope fence in front of the sequence word.
+// log-likelihood partials in fp64 with 16-byte loads, eight in flight per thread.  Two block barriers in all; the record is
+// assembled in LDS and pushed to the pinned host buffer as self-validating 16-byte pieces (FinWire): no fence, no ready word.
 __global__ __launch_bounds__(kFinThreads) void k_finalize(const FinArgs args) {
   const FinItem &it = args.items[blockIdx.x];
   const int t = threadIdx.x;
@@ -1150,21 +1172,22 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const FinArgs args) {
       __hip_atomic_store(xa.host_seq, sh_bad ? (args.xseq | 0x80000000u) : args.xseq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }
-  // ---- publish: wave 0 copies the record to the pinned host buffer, one system-scope fence, then the sequence word
-  if (t < 64) {
-    constexpr int kPieces = (int)(sizeof(FinOut) / 16);
-    static_assert(kPieces <= 64, "one wave copies the record");
-    const v4f *src = reinterpret_cast<const v4f *>(&sh_out);
-    v4f *dst = reinterpret_cast<v4f *>(it.out);
-    if (t >= 1 && t < kPieces) dst[t] = src[t];
-    if (t == 0) it.out->valid = sh_out.valid, it.out->has_res = sh_out.has_res, it.out->has_ll = sh_out.has_ll;
-    if (it.out_dev && t < kPieces) ((DVO_GLOBAL v4f *)it.out_dev)[t] = src[t];  // multi-GPU exchange buffer
-    DVO_FIN_STAMP(3);
-    __threadfence_system();
-    DVO_FIN_STAMP(4);
-    if (t == 0) __hip_atomic_store(&it.out->seq, it.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    DVO_FIN_STAMP(5);
+  // ---- publish: every piece of the record goes to the pinned host buffer with the tick's sequence number inside it, in one
+  // 16-byte system-scope store per lane.  The host validates piece by piece (FinWire), so nothing is fenced or ordered here.
+  if (t < kFinWirePieces) {
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const unsigned *src = reinterpret_cast<const unsigned *>(&sh_out);
+    v4u piece;
+    piece.x = src[3 * t];
+    piece.y = 3 * t + 1 < kFinWords ? src[3 * t + 1] : 0u;
+    piece.z = 3 * t + 2 < kFinWords ? src[3 * t + 2] : 0u;
+    piece.w = it.seq;
+    DVO_GLOBAL unsigned *dst = (DVO_GLOBAL unsigned *)it.out->piece[t];
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(piece) : "memory");
   }
+  if (it.out_dev && t < (int)(sizeof(FinOut) / 16))  // device copy for the collective fallback of a tile-sharded pair
+    ((DVO_GLOBAL v4f *)it.out_dev)[t] = reinterpret_cast<const v4f *>(&sh_out)[t];
+  DVO_FIN_STAMP(3);
 }
 
 hipError_t read_finalize_stamps(unsigned long long out[8]) {

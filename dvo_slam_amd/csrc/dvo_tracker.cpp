@@ -10,6 +10,7 @@
 // The 6x6 solve, SE(3) exp/log and the 2x2 inverse stay on the host (se3.h), as in the reference.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <emmintrin.h>  // the host side of the record hand-off takes 16 bytes at a time (x86-64 hosts)
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -423,7 +424,7 @@ struct JobSlot {
   float *records = nullptr;
   double *ll_partials = nullptr;
   int *seg_prefix[2] = {nullptr, nullptr};
-  FinOut *out = nullptr;      // pinned host memory, device-visible
+  FinWire *out = nullptr;     // pinned host memory as the device sees it: the record arrives here as tagged pieces
   FinOut *out_dev = nullptr;  // device staging of the record
   void *dev_block = nullptr;
 };
@@ -436,7 +437,9 @@ struct dvo_amd_context {
   hipEvent_t desc_ready = nullptr;
   std::vector<JobSlot> slots;
   int slot_n_pad = 0;  // capacity every slot was sized for
-  FinOut *out_host = nullptr;
+  FinWire *out_wire = nullptr;           // pinned, device-visible: one per slot, written by k_finalize
+  std::vector<FinOut> out_store;         // the records decoded from out_wire (plain host memory)
+  FinOut *out_host = nullptr;            // = out_store.data()
   int out_capacity = 0;
   SlotDesc *slot_desc = nullptr;       // device, [slot]
   unsigned *tickets = nullptr;         // device, one arrival counter per tick stream
@@ -819,12 +822,15 @@ int ensure_slots_impl(dvo_amd_context *ctx, int n_jobs, int n_pad) {
   release_slots(ctx);
   const int n_slots = std::max(n_jobs, 1);
   if (ctx->out_capacity < n_slots) {
-    if (ctx->out_host) (void)hipHostFree(ctx->out_host);
-    ctx->out_host = nullptr;
+    if (ctx->out_wire) (void)hipHostFree(ctx->out_wire);
+    ctx->out_wire = nullptr;
     ctx->out_capacity = 0;
-    HIP_TRY(hipHostMalloc((void **)&ctx->out_host, sizeof(FinOut) * n_slots, hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_TRY(hipHostMalloc((void **)&ctx->out_wire, sizeof(FinWire) * n_slots, hipHostMallocMapped | hipHostMallocCoherent));
     ctx->out_capacity = n_slots;
+    ctx->out_store.assign((size_t)n_slots, FinOut());
+    ctx->out_host = ctx->out_store.data();
   }
+  std::memset(ctx->out_wire, 0, sizeof(FinWire) * (size_t)n_slots);  // tick numbers restart below: no piece may carry an old one
   HIP_TRY(hipMalloc((void **)&ctx->slot_desc, sizeof(SlotDesc) * n_slots));
   if (!ctx->tickets) {
     HIP_TRY(hipMalloc((void **)&ctx->tickets, sizeof(unsigned) * 16 * kMaxTickStreams));
@@ -854,10 +860,9 @@ int ensure_slots_impl(dvo_amd_context *ctx, int n_jobs, int n_pad) {
     s.seg_prefix[0] = (int *)p, p += b_sp;
     s.seg_prefix[1] = (int *)p, p += b_sp;
     s.out_dev = (FinOut *)p, p += b_out;
-    FinOut *dev_out = nullptr;
-    HIP_TRY(hipHostGetDevicePointer((void **)&dev_out, ctx->out_host + i, 0));
+    FinWire *dev_out = nullptr;
+    HIP_TRY(hipHostGetDevicePointer((void **)&dev_out, ctx->out_wire + i, 0));
     s.out = dev_out;
-    ctx->out_host[i].seq = 0;
     SlotDesc &sd = slot_host[(size_t)i];
     sd.res[0] = s.res[0], sd.res[1] = s.res[1];
     sd.records = s.records, sd.ll_partials = s.ll_partials;
@@ -934,22 +939,50 @@ int timing_collect(dvo_amd_context *ctx) {
   return DVO_AMD_OK;
 }
 
+// Take the pieces of slot `slot`'s record that carry tick `seq` out of the pinned buffer into ctx->out_host[slot]; returns
+// the index of the first piece that is not there yet (kFinWirePieces when the record is complete).  A piece is one aligned
+// 16-byte load: payload and tag come from the same store of the device.
+int take_record(dvo_amd_context *ctx, size_t slot, unsigned seq, int from_piece) {
+  const FinWire *w = ctx->out_wire + slot;
+  unsigned *dst = reinterpret_cast<unsigned *>(ctx->out_host + slot);
+  for (int i = from_piece; i < kFinWirePieces; ++i) {
+    __asm__ __volatile__("" ::: "memory");
+    alignas(16) unsigned u[4];
+    _mm_store_si128(reinterpret_cast<__m128i *>(u), _mm_load_si128(reinterpret_cast<const __m128i *>(w->piece[i])));
+    if (u[3] != seq) return i;
+    for (int k = 0; k < 3 && 3 * i + k < kFinWords; ++k) dst[3 * i + k] = u[k];
+  }
+  ctx->out_host[slot].seq = seq;
+  return kFinWirePieces;
+}
+
+// after a stream synchronisation every piece must be there
+int take_record_synced(dvo_amd_context *ctx, size_t slot, unsigned seq) {
+  if (take_record(ctx, slot, seq, 0) != kFinWirePieces)
+    return fail_hip("tick finished without publishing its record", hipErrorUnknown);
+  return DVO_AMD_OK;
+}
+
 // wait until the finalize kernel has published this tick's record of every submitted job
 int wait_tick(dvo_amd_context *ctx, const std::vector<Job> &jobs, size_t lo, size_t hi, unsigned seq) {
-  if (!ctx->poll || ctx->timing) {
+  const bool synced = !ctx->poll || ctx->timing;
+  if (synced) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     for (hipStream_t s : ctx->extra_streams) HIP_TRY(hipStreamSynchronize(s));
-    return DVO_AMD_OK;
   }
   for (size_t ji = lo; ji < hi; ++ji) {
     const Job &j = jobs[ji];
     if (j.done || !(j.sub_ll || j.sub_res)) continue;
-    const volatile unsigned *p = &ctx->out_host[j.slot - ctx->slots.data()].seq;
+    const size_t slot = (size_t)(j.slot - ctx->slots.data());
+    if (synced) {
+      int rc = take_record_synced(ctx, slot, seq);
+      if (rc) return rc;
+      continue;
+    }
     unsigned long long spins = 0;
-    while (__atomic_load_n(p, __ATOMIC_ACQUIRE) != seq) {
-#if defined(__x86_64__) || defined(__i386__)
+    int have = 0;
+    while ((have = take_record(ctx, slot, seq, have)) != kFinWirePieces) {
       __builtin_ia32_pause();  // be polite to the sibling hardware thread while spinning
-#endif
       if ((++spins & 0xFFFFF) == 0) {  // every ~1M polls make sure the streams are still alive
         bool all_idle = true;
         for (size_t si = 0; si <= ctx->extra_streams.size(); ++si) {
@@ -960,7 +993,7 @@ int wait_tick(dvo_amd_context *ctx, const std::vector<Job> &jobs, size_t lo, siz
             return fail_hip("stream died while waiting for a tick", e);
           }
         }
-        if (all_idle && __atomic_load_n(p, __ATOMIC_ACQUIRE) != seq)
+        if (all_idle && (have = take_record(ctx, slot, seq, have)) != kFinWirePieces)
           return fail_hip("tick finished without publishing its record", hipErrorUnknown);
       }
     }
@@ -1350,7 +1383,11 @@ int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, i
     for (int b = 0; b < n_bands; ++b) recs[b] = ctx->gather_host + b;
   } else {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    for (int b = 0; b < n_bands; ++b) recs[b] = ctx->out_host + b;
+    for (int b = 0; b < n_bands; ++b) {
+      int rc = take_record_synced(ctx, (size_t)b, seq);
+      if (rc) return rc;
+      recs[b] = ctx->out_host + b;
+    }
   }
   FinOut comb;
   combine_bands(recs, n_bands, comb);
@@ -1517,7 +1554,7 @@ void dvo_amd_context_destroy(dvo_amd_context *ctx) {
   }
   if (ctx->desc_ready) (void)hipEventDestroy(ctx->desc_ready);
   release_slots(ctx);
-  if (ctx->out_host) (void)hipHostFree(ctx->out_host);
+  if (ctx->out_wire) (void)hipHostFree(ctx->out_wire);
   if (ctx->tickets) (void)hipFree(ctx->tickets);
   if (ctx->item_host) (void)hipHostFree(ctx->item_host);
   if (ctx->item_dev) (void)hipFree(ctx->item_dev);
@@ -2020,6 +2057,8 @@ int dvo_amd_residuals(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_
   if (residuals)
     HIP_TRY(hipMemcpyAsync(residuals, ctx->slots[0].res[0], sizeof(float2) * R.n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  rc = take_record_synced(ctx, 0, ctx->tick_seq);
+  if (rc) return rc;
   if (n_valid) *n_valid = ctx->out_host[0].valid;
   return DVO_AMD_OK;
 }
@@ -2042,6 +2081,8 @@ int dvo_amd_debug_iteration(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dv
   rc = single_tick(ctx, reference, current, level, sel, T, precision_in, precision_in == nullptr, true, false, 0);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  rc = take_record_synced(ctx, 0, ctx->tick_seq);
+  if (rc) return rc;
   const FinOut o = ctx->out_host[0];
   out->valid_constraints = o.valid;
   for (int i = 0; i < 3; ++i) out->scale_sums[i] = o.S[i];
@@ -2060,6 +2101,8 @@ int dvo_amd_debug_iteration(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dv
   rc = single_tick(ctx, reference, current, level, sel, T, P, false, false, true, 50 * (o.valid / 50));
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  rc = take_record_synced(ctx, 0, ctx->tick_seq);
+  if (rc) return rc;
   out->loglik_sum = ctx->out_host[0].ll_sum;
   out->loglik = loglik_from_sum(o.valid, P, out->loglik_sum);
   return DVO_AMD_OK;

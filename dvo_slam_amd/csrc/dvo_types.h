@@ -106,7 +106,17 @@ struct FinOut {
   double acc[kNumAcc];
   double ll_sum;   // sum of log(1 + 0.2 r^T P r) over the first 50*floor(V/50) valid residuals (Q6)
 };
-static_assert(sizeof(FinOut) % 16 == 0, "FinOut is copied to the host in 16-byte pieces");
+static_assert(sizeof(FinOut) % 16 == 0, "FinOut is copied in 16-byte pieces");
+
+// How a record travels to the host: 16-byte pieces of three payload words and the tick's sequence number as a tag, each
+// written by one store instruction of one lane.  The host takes a piece with one aligned 16-byte load and accepts it when
+// the tag is the tick it waits for, so the kernel needs neither a fence behind the payload nor a separate "ready" word
+// behind the fence (that dependent chain was a quarter of k_finalize).
+constexpr int kFinWords = (int)(sizeof(FinOut) / 4);
+constexpr int kFinWirePieces = (kFinWords + 2) / 3;
+struct alignas(16) FinWire {
+  unsigned piece[kFinWirePieces][4];  // {word 3i, word 3i+1, word 3i+2, tag}
+};
 
 // ---- one-hop exchange of band records between the GPUs of a node (tile-sharded pairs) ------------------------------------
 // Every rank owns an exchange buffer of 2 x n_ranks record slots in fine-grained device memory that its peers have mapped
@@ -131,7 +141,7 @@ struct FinItem {
   int n_ll_blocks, ll_first;
   const double *ll_partials;
   int *seg_prefix_out;    // per wave segment of the band: valid pixels before it (exclusive scan from the band start)
-  FinOut *out;            // host (pinned, device-visible): where the record is published
+  FinWire *out;           // host (pinned, device-visible): where the record is published, as tagged pieces
   FinOut *out_dev;        // optional device copy of the record (multi-GPU exchange), or null
   unsigned seq;
   unsigned pad;
