@@ -245,8 +245,12 @@ typedef float v4acc __attribute__((ext_vector_type(4)));
 //        v_mfma_f32_4x4x1_16B_f32 (16 independent 4x4 outer products per instruction, one pixel each) accumulates only the 9
 //        group pairs the 87 moments need (6 of the symmetric J J^T part + 3 J r^T): 36 instructions x 8 cycles per 64 pixels
 //        instead of 16 x 32, at the price of 36 accumulator registers and a 16-block reduction in the epilogue.
-template <int RMODE, int ACC>
+// LEAN: the build for five waves per SIMD.  One staging buffer instead of two (a wave's LDS queue is in order: the reads of
+//        what step n - 1 staged are issued before step n's writes), K*T in LDS instead of 12 registers, the next step's reference
+//        scalars requested after the gathers have landed instead of a whole step ahead.
+template <int RMODE, int ACC, bool LEAN>
 __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const int lb) {
+  constexpr int kBufs = LEAN ? 1 : 2;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
   const int seg = lb * kWavesPerBlock + wave;
@@ -261,7 +265,7 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
   for (int i = 0; i < (ACC == 0 ? kNumAcc : 1); ++i) acc[i] = 0.0f;
   v4acc gram_a = {0.0f, 0.0f, 0.0f, 0.0f}, gram_b = {0.0f, 0.0f, 0.0f, 0.0f};
   // staging for the MFMA operands: [wave][point = lane][16 components], 16-byte chunks XOR-swizzled by point
-  __shared__ __attribute__((aligned(16))) float stage[ACC >= 1 ? kWavesPerBlock * 2 * kWave * 16 : 4];
+  __shared__ __attribute__((aligned(16))) float stage[ACC >= 1 ? kWavesPerBlock * kBufs * kWave * 16 : 4];
   float S0[3] = {0.0f, 0.0f, 0.0f}, S1[3] = {0.0f, 0.0f, 0.0f};
   float first_w = 0.0f;
   int run_count = 0;                        // wave uniform
@@ -275,10 +279,10 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
 
   // K*T lives in vector registers: as scalars the 12 values do not fit next to the descriptors, and the compiler re-reads
   // them from the kernel arguments inside every step, with a full scalar-memory wait in front of the projection
-  // (ACC 2 is short of registers instead: there K*T sits in LDS, written once per block, and is fetched at the top of every
+  // (LEAN is short of registers instead: there K*T sits in LDS, written once per block, and is fetched at the top of every
   // step with three broadcast reads, so that it is not live while the gathers and the accumulators are)
-  constexpr bool kKtLds = ACC == 2;
-  constexpr bool kLatePrefetch = ACC == 2;  // ... and the next step's reference scalars are requested after the gathers have landed
+  constexpr bool kKtLds = LEAN;
+  constexpr bool kLatePrefetch = LEAN;
   __shared__ __attribute__((aligned(16))) float kt_lds[12];
   float kt[12];
 #pragma unroll
@@ -311,8 +315,8 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
   // (comp >> 2) ^ ((p >> 1) & 3) = cb for even m and cb ^ 2 for odd m (cb = (comp >> 2) ^ (l >> 5)): two lane-constant
   // offsets plus compile-time immediates, no per-step address arithmetic.
   const int g_comp = lane & 15, g_sub = lane >> 4, g_cb = (g_comp >> 2) ^ (g_sub >> 1);
-  const float *const g_even = stage + (wave * 2 * kWave + g_sub) * 16 + ((g_cb << 2) | (g_comp & 3));
-  const float *const g_odd = stage + (wave * 2 * kWave + g_sub) * 16 + (((g_cb ^ 2) << 2) | (g_comp & 3));
+  const float *const g_even = stage + (wave * kBufs * kWave + g_sub) * 16 + ((g_cb << 2) | (g_comp & 3));
+  const float *const g_odd = stage + (wave * kBufs * kWave + g_sub) * 16 + (((g_cb ^ 2) << 2) | (g_comp & 3));
   // 4x4-block form (ACC 2): MFMA m of a step covers the 16 pixels 16 m .. 16 m + 15, one per block; lane 4 b + i supplies
   // element i of a component group of pixel 16 m + b.  A group is exactly one 16-byte chunk of the staged row, at chunk position
   // g ^ ((p >> 1) & 3) = g ^ ((b >> 1) & 3): four lane-constant offsets, the rest are immediates.  Conflict free: within a
@@ -322,14 +326,14 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
 #pragma unroll
   for (int t = 0; t < (ACC == 2 ? kGram4Types : 1); ++t) g4[t] = v4acc{0.0f, 0.0f, 0.0f, 0.0f};
   const int b4 = lane >> 2, i4 = lane & 3, sw4 = (b4 >> 1) & 3;
-  const float *const g4_base = stage + (wave * 2 * kWave + b4) * 16 + i4;
+  const float *const g4_base = stage + (wave * kBufs * kWave + b4) * 16 + i4;
   auto gram_from_stage = [&](const int q) __attribute__((always_inline)) {
     if (ACC == 2) {
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         float R[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) R[g] = g4_base[((g ^ sw4) << 2) + q * kWave * 16 + m * 256];
+        for (int g = 0; g < 4; ++g) R[g] = g4_base[((g ^ sw4) << 2) + (q & (kBufs - 1)) * kWave * 16 + m * 256];
         g4[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(R[0], R[0], g4[0], 0, 0, 0);
         g4[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(R[0], R[1], g4[1], 0, 0, 0);
         g4[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(R[0], R[2], g4[2], 0, 0, 0);
@@ -344,8 +348,8 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
     }
 #pragma unroll
     for (int m = 0; m < 16; m += 2) {
-      const float va = g_even[q * kWave * 16 + 64 * m];
-      const float vb = g_odd[q * kWave * 16 + 64 * (m + 1)];
+      const float va = g_even[(q & (kBufs - 1)) * kWave * 16 + 64 * m];
+      const float vb = g_odd[(q & (kBufs - 1)) * kWave * 16 + 64 * (m + 1)];
       gram_a = __builtin_amdgcn_mfma_f32_16x16x4f32(va, va, gram_a, 0, 0, 0);
       gram_b = __builtin_amdgcn_mfma_f32_16x16x4f32(vb, vb, gram_b, 0, 0, 0);
     }
@@ -494,7 +498,7 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
     } else {
       // stage sqrt(w) * v for this lane's pixel; chunk c of point p sits at chunk position c ^ ((p >> 1) & 3).
       // Two buffers alternate: the matrix pipe consumes this one during the NEXT step (see above).
-      float *buf = stage + ((wave * 2 + q) * kWave) * 16;
+      float *buf = stage + ((wave * kBufs + (q & (kBufs - 1))) * kWave) * 16;
       v4f *row = reinterpret_cast<v4f *>(buf + lane * 16);
       const int swz = (lane >> 1) & 3;
       v4f c0 = {Ja[0], Ja[1], Ja[2], Ja[3]};  // the rows carry sqrt(w) already
@@ -572,7 +576,7 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
   // ACC 2: a wave's 4x4 block sums go to the start of its own staging area (its last reads of it are behind it in the wave's
   // in-order LDS queue): [row of 16 lanes][type][i][j], 576 floats
   constexpr int kG4Scratch = 4 * kGram4Types * 16;
-  static_assert(kG4Scratch <= 2 * kWave * 16, "the 4x4 block sums fit a wave's staging area");
+  static_assert(kG4Scratch <= kBufs * kWave * 16, "the 4x4 block sums fit a wave's staging area");
   if (ACC == 0) {
 #pragma unroll
     for (int i = 0; i < kNumAcc; ++i) {
@@ -582,7 +586,7 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
   } else if (ACC == 2) {
     // D of block b sits in lanes 4 b .. 4 b + 3 (column j), register i (row): first the four blocks of every 16-lane row
     // (two DPP row shifts leave the row's sum in its lanes 12..15), then one LDS word per (row, type, i, j)
-    float *scr = stage + wave * 2 * kWave * 16;
+    float *scr = stage + wave * kBufs * kWave * 16;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -597,7 +601,7 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
   } else {
     // C/D layout of the 16x16 MFMA: register r of lane l is G[row = (l>>4)*4 + r][col = l&15]
     // into the start of the wave's own staging area (its reads of it are behind it in the in-order LDS queue)
-    float *gsm = stage + wave * 2 * kWave * 16;
+    float *gsm = stage + wave * kBufs * kWave * 16;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -654,7 +658,7 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
           const int off = type * 16 + (r & 3) * 4 + (c & 3);
           float sum = 0.0f;
           for (int wv = 0; wv < kWavesPerBlock; ++wv) {
-            const float *scr = stage + wv * 2 * kWave * 16 + off;
+            const float *scr = stage + wv * kBufs * kWave * 16 + off;
             sum += (scr[0] + scr[kGram4Types * 16]) + (scr[2 * kGram4Types * 16] + scr[3 * kGram4Types * 16]);
           }
           return sum;
@@ -662,7 +666,7 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
         v = entry(e0);
         if (e1 >= 0) v += entry(e1);
       } else {
-        constexpr int kW = 2 * kWave * 16;  // floats between the staging areas of two waves
+        constexpr int kW = kBufs * kWave * 16;  // floats between the staging areas of two waves
         v = (stage[e0] + stage[kW + e0]) + (stage[2 * kW + e0] + stage[3 * kW + e0]);
         if (e1 >= 0) v += (stage[e1] + stage[kW + e1]) + (stage[2 * kW + e1] + stage[3 * kW + e1]);
       }
@@ -796,7 +800,7 @@ __device__ __forceinline__ LevelPairDesc load_desc(const TickItem &it) {
   return d;
 }
 
-template <int RMODE, int ACC>
+template <int RMODE, int ACC, bool LEAN>
 __device__ __forceinline__ void tick_body(const TickItem &it, const int bx) {
   const int rp = it.res_phys;
   if (bx >= rp + it.ll_blocks) return;
@@ -805,7 +809,7 @@ __device__ __forceinline__ void tick_body(const TickItem &it, const int bx) {
     // a physical block walks several logical blocks when the launch holds many more blocks than the GPU has slots: the
     // item and its descriptors are fetched once, and only the first logical block pays the dependent-load prologue
     for (int lb = bx; lb < it.res_blocks; lb += rp) {
-      residual_pass<RMODE, ACC>(it, d, it.res_first + xcd_contiguous_block(lb, it.res_blocks));
+      residual_pass<RMODE, ACC, LEAN>(it, d, it.res_first + xcd_contiguous_block(lb, it.res_blocks));
       __syncthreads();  // the reduction scratch in LDS is reused by the next logical block
     }
   } else {
@@ -822,9 +826,9 @@ __global__ __launch_bounds__(kBlockThreads, OCC) void k_tick(const TickArgs args
     const unsigned g = blockIdx.x >> 3;
     const unsigned first = lane <= args.n_items ? (unsigned)args.group_first[lane < kMaxItemsPerLaunch + 4 ? lane : 0] : 0xFFFFFFFFu;
     const int idx = __builtin_amdgcn_readfirstlane(__popcll(__ballot(first <= g)) - 1);
-    tick_body<RMODE, ACC>(args.items[idx], (int)blockIdx.x - ((int)args.group_first[idx] << 3));
+    tick_body<RMODE, ACC, (OCC >= 5 || ACC == 2)>(args.items[idx], (int)blockIdx.x - ((int)args.group_first[idx] << 3));
   } else {
-    tick_body<RMODE, ACC>(args.items[blockIdx.y], (int)blockIdx.x);
+    tick_body<RMODE, ACC, (OCC >= 5 || ACC == 2)>(args.items[blockIdx.y], (int)blockIdx.x);
   }
 }
 
@@ -842,7 +846,7 @@ __global__ __launch_bounds__(kBlockThreads, OCC) void k_tick_table(const TickIte
   for (int i = 0; i < 12; ++i) it.kt[i] = p->kt[i];
 #pragma unroll
   for (int i = 0; i < 4; ++i) it.P[i] = p->P[i];
-  tick_body<RMODE, ACC>(it, (int)blockIdx.x);
+  tick_body<RMODE, ACC, (OCC >= 5 || ACC == 2)>(it, (int)blockIdx.x);
 }
 
 static int g_reduce_mode = -1;  // DVO_AMD_REDUCE=0: ds_bpermute butterfly instead of DPP (debug cross-check)
@@ -1022,13 +1026,16 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const FinArgs args) {
     r.c = 0, r.first_w = 0.0f, r.l0 = r.l1 = 0.0f;
     for (int i = 0; i < 3; ++i) r.s0[i] = r.s1[i] = 0.0;
     const int b_end = (t + 1) * per < nb ? (t + 1) * per : nb;
-    for (int b0 = t * per; b0 < b_end; b0 += 4) {  // four records' headers in flight at a time
-      v4f h0[4], h1[4], h2[4];
+    // four records' headers (64 bytes each) in flight at a time; the per-wave counts of the first four are kept in registers
+    // for the prefix pass below, so a lane with at most four records (every level up to 256 blocks) reads its headers once
+    unsigned cw_first[4][4] = {};
+    for (int b0 = t * per; b0 < b_end; b0 += 4) {
+      v4f h0[4], h1[4], h2[4], h3[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (b0 + k < b_end) {
           const gcf4 hp = reinterpret_cast<gcf4>(recs + (size_t)(b0 + k) * kRecStride);
-          h0[k] = hp[0], h1[k] = hp[1], h2[k] = hp[2];
+          h0[k] = hp[0], h1[k] = hp[1], h2[k] = hp[2], h3[k] = hp[3];
         }
 #pragma unroll
       for (int k = 0; k < 4; ++k)
@@ -1039,14 +1046,16 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const FinArgs args) {
           q.s0[0] = h1[k].x, q.s0[1] = h1[k].y, q.s0[2] = h1[k].z;
           q.s1[0] = h1[k].w, q.s1[1] = h2[k].x, q.s1[2] = h2[k].y;
           r = seg_combine(r, q);
+          if (b0 == t * per) cw_first[k][0] = f2u(h2[k].z), cw_first[k][1] = f2u(h2[k].w), cw_first[k][2] = f2u(h3[k].x), cw_first[k][3] = f2u(h3[k].y);
         }
     }
     const int own_total = r.c;
     sh_seg[t] = r;
     sh_cnt[t] = r.c;
     DVO_WAVE_LDS_SYNC();
-    // ordered combine (tree) and inclusive scan of the per-lane valid counts, 6 wave-local steps
-    for (int stride = 1; stride < kFinSegThreads; stride <<= 1) {
+    // ordered combine (tree) and inclusive scan of the per-lane valid counts: wave-local steps over the lanes that hold records
+    const int used = per > 0 ? (nb + per - 1) / per : 0;
+    for (int stride = 1; stride < used; stride <<= 1) {
       SegRec merged;
       int add = 0;
       const bool do_merge = (t % (2 * stride)) == 0;
@@ -1069,7 +1078,16 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const FinArgs args) {
       // rank to honour the V % 50 cut (Q6)
       int prefix = sh_cnt[t] - own_total;  // valid pixels before this lane's blocks
       DVO_GLOBAL int *sp = (DVO_GLOBAL int *)it.seg_prefix_out + (size_t)it.block_first * kWavesPerBlock;
-      for (int b0 = t * per; b0 < b_end; b0 += 4) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (t * per + k < b_end) {
+#pragma unroll
+          for (int wv = 0; wv < 4; ++wv) {
+            sp[(t * per + k) * kWavesPerBlock + wv] = prefix;
+            prefix += (int)cw_first[k][wv];
+          }
+        }
+      for (int b0 = t * per + 4; b0 < b_end; b0 += 4) {  // levels with more than 256 blocks: the rest is read again
         v4f h2[4], h3[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
