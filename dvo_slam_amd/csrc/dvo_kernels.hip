@@ -972,35 +972,54 @@ __device__ unsigned long long g_fin_stamps[8];
   } while (0)
 
 
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+// one lane, one instruction, 16 bytes, system scope: the unit every record travels in (FinWire)
+// (s_nop: a store of more than 8 bytes reads its data registers over several cycles, and the compiler's hazard recogniser
+// does not see through inline assembly -- without it the next vector instruction may overwrite the tail of the data)
+__device__ __forceinline__ void st16_system(DVO_GLOBAL void *p, v4u v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ v4u ld16_system(const DVO_GLOBAL void *p) {
+  v4u v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ v4u wire_piece(const unsigned *record_words, int i, unsigned tag) {
+  v4u piece;
+  piece.x = record_words[3 * i];
+  piece.y = 3 * i + 1 < kFinWords ? record_words[3 * i + 1] : 0u;
+  piece.z = 3 * i + 2 < kFinWords ? record_words[3 * i + 2] : 0u;
+  piece.w = tag;
+  return piece;
+}
+
 // The one-hop exchange of a tile-sharded pair, run by the waves of k_finalize once the rank's record stands in LDS: wave
-// (p mod n_waves) pushes it into rank p's exchange buffer (payload, system-scope release, sequence word), waits -- bounded --
-// for rank p's record of this tick to land in the local buffer and forwards it to the host.  Returns false on a timeout.
+// (p mod n_waves) pushes it into rank p's exchange buffer as tagged 16-byte pieces, then every lane waits -- bounded -- for
+// "its" pieces of rank p's record of this tick to land in the local buffer and forwards them, tag included, to the host.
+// No fence and no ready word anywhere: a piece is valid when its tag is the tick.  Returns false on a timeout.
 __device__ bool exchange_records(const ExchangeArgs &a, const unsigned *own_record, unsigned seq, int wave, int n_waves, int lane) {
-  constexpr int kWords = (int)(sizeof(FinOut) / 4);
-  constexpr int kSeqWord = (int)(offsetof(FinOut, seq) / 4);
   const int slot = (int)(seq & 1u) * a.n_ranks;
   bool ok = true;
   for (int p = wave; p < a.n_ranks; p += n_waves) {
-    unsigned *dst = reinterpret_cast<unsigned *>(a.peers[p] + slot + a.rank);
-    for (int w = lane; w < kWords; w += kWave)
-      if (w != kSeqWord) __hip_atomic_store(dst + w, own_record[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: the payload is visible before the sequence word
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_store(dst + kSeqWord, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    FinWire *dst = a.peers[p] + slot + a.rank;
+    for (int i = lane; i < kFinWirePieces; i += kWave) st16_system((DVO_GLOBAL void *)dst->piece[i], wire_piece(own_record, i, seq));
   }
   for (int p = wave; p < a.n_ranks; p += n_waves) {
-    const unsigned *in = reinterpret_cast<const unsigned *>(a.local + slot + p);
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__hip_atomic_load(in + kSeqWord, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
-      __builtin_amdgcn_s_sleep(8);
-      if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)a.timeout_ticks) {
-        ok = false;
-        break;
+    const FinWire *in = a.local + slot + p;
+    FinWire *out = a.host_records + p;
+    for (int i = lane; i < kFinWirePieces; i += kWave) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      v4u piece = ld16_system((const DVO_GLOBAL void *)in->piece[i]);
+      while (piece.w != seq) {
+        __builtin_amdgcn_s_sleep(8);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)a.timeout_ticks) {
+          ok = false;
+          break;
+        }
+        piece = ld16_system((const DVO_GLOBAL void *)in->piece[i]);
       }
+      if (piece.w == seq) st16_system((DVO_GLOBAL void *)out->piece[i], piece);
     }
-    // every word read at system scope: nothing of an older generation may be served from a cache
-    unsigned *out = reinterpret_cast<unsigned *>(a.host_records + p);
-    for (int w = lane; w < kWords; w += kWave) out[w] = __hip_atomic_load(in + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   return ok;
 }
@@ -1184,25 +1203,14 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const FinArgs args) {
     xa.n_ranks = xp->n_ranks, xa.rank = xp->rank, xa.timeout_ticks = xp->timeout_ticks;
     if (!exchange_records(xa, reinterpret_cast<const unsigned *>(&sh_out), args.xseq, t >> 6, kFinThreads / kWave, t & (kWave - 1)))
       atomicOr(&sh_bad, 1);
-    __threadfence_system();
     __syncthreads();
-    if (t == 0)
-      __hip_atomic_store(xa.host_seq, sh_bad ? (args.xseq | 0x80000000u) : args.xseq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (t == 0 && sh_bad) __hip_atomic_store(xa.host_seq, args.xseq | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }
   // ---- publish: every piece of the record goes to the pinned host buffer with the tick's sequence number inside it, in one
   // 16-byte system-scope store per lane.  The host validates piece by piece (FinWire), so nothing is fenced or ordered here.
-  if (t < kFinWirePieces) {
-    typedef unsigned v4u __attribute__((ext_vector_type(4)));
-    const unsigned *src = reinterpret_cast<const unsigned *>(&sh_out);
-    v4u piece;
-    piece.x = src[3 * t];
-    piece.y = 3 * t + 1 < kFinWords ? src[3 * t + 1] : 0u;
-    piece.z = 3 * t + 2 < kFinWords ? src[3 * t + 2] : 0u;
-    piece.w = it.seq;
-    DVO_GLOBAL unsigned *dst = (DVO_GLOBAL unsigned *)it.out->piece[t];
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(piece) : "memory");
-  }
+  if (t < kFinWirePieces)
+    st16_system((DVO_GLOBAL void *)it.out->piece[t], wire_piece(reinterpret_cast<const unsigned *>(&sh_out), t, it.seq));
   if (it.out_dev && t < (int)(sizeof(FinOut) / 16))  // device copy for the collective fallback of a tile-sharded pair
     ((DVO_GLOBAL v4f *)it.out_dev)[t] = reinterpret_cast<const v4f *>(&sh_out)[t];
   DVO_FIN_STAMP(3);

@@ -465,12 +465,13 @@ struct dvo_amd_context {
   int comm_ranks = 0, comm_rank = 0;
   FinOut *gather_dev = nullptr, *gather_host = nullptr;
   // one-hop peer exchange (replaces the all-gather + D2H copy + stream sync of a tick when attached)
-  FinOut *xbuf = nullptr;                       // own exchange buffer: 2 generations x n ranks, fine-grained device memory
-  FinOut *xpeers[kMaxExchangeRanks] = {};       // every rank's buffer as mapped into this process (own one included)
+  FinWire *xbuf = nullptr;                      // own exchange buffer: 2 generations x n ranks, fine-grained device memory
+  FinWire *xpeers[kMaxExchangeRanks] = {};      // every rank's buffer as mapped into this process (own one included)
   bool xpeer_opened[kMaxExchangeRanks] = {};    // mapped with hipIpcOpenMemHandle (to be closed)
   int x_ranks = 0, x_rank = 0;
-  FinOut *x_host = nullptr;                     // pinned: the records of a tick in rank order
-  unsigned *x_host_seq = nullptr;               // pinned: sequence word the exchange kernel writes last
+  FinWire *x_host = nullptr;                    // pinned: the records of a tick in rank order, as tagged pieces
+  FinOut x_store[kMaxExchangeRanks];            // ... decoded
+  unsigned *x_host_seq = nullptr;               // pinned: tick | 0x80000000 when the exchange kernel gave up waiting for a peer
   unsigned x_seq = 0;
   ExchangeArgs *x_args_dev = nullptr;           // device copy of the exchange description k_finalize reads
   ncclResult_t (*p_allgather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
@@ -939,12 +940,11 @@ int timing_collect(dvo_amd_context *ctx) {
   return DVO_AMD_OK;
 }
 
-// Take the pieces of slot `slot`'s record that carry tick `seq` out of the pinned buffer into ctx->out_host[slot]; returns
-// the index of the first piece that is not there yet (kFinWirePieces when the record is complete).  A piece is one aligned
-// 16-byte load: payload and tag come from the same store of the device.
-int take_record(dvo_amd_context *ctx, size_t slot, unsigned seq, int from_piece) {
-  const FinWire *w = ctx->out_wire + slot;
-  unsigned *dst = reinterpret_cast<unsigned *>(ctx->out_host + slot);
+// Take the pieces of a record that carry tick `seq` out of a pinned buffer into *dst; returns the index of the first piece
+// that is not there yet (kFinWirePieces when the record is complete).  A piece is one aligned 16-byte load: payload and tag
+// come from the same store of the device.
+int take_wire(const FinWire *w, FinOut *dst_record, unsigned seq, int from_piece) {
+  unsigned *dst = reinterpret_cast<unsigned *>(dst_record);
   for (int i = from_piece; i < kFinWirePieces; ++i) {
     __asm__ __volatile__("" ::: "memory");
     alignas(16) unsigned u[4];
@@ -952,8 +952,11 @@ int take_record(dvo_amd_context *ctx, size_t slot, unsigned seq, int from_piece)
     if (u[3] != seq) return i;
     for (int k = 0; k < 3 && 3 * i + k < kFinWords; ++k) dst[3 * i + k] = u[k];
   }
-  ctx->out_host[slot].seq = seq;
+  dst_record->seq = seq;
   return kFinWirePieces;
+}
+int take_record(dvo_amd_context *ctx, size_t slot, unsigned seq, int from_piece) {
+  return take_wire(ctx->out_wire + slot, ctx->out_host + slot, seq, from_piece);
 }
 
 // after a stream synchronisation every piece must be there
@@ -1353,25 +1356,25 @@ int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, i
     // one hop: every rank's finalize record goes straight into every peer's mapped exchange buffer; the same kernel waits
     // for the peers' records and forwards them to pinned host memory, which the host polls (no collective, no copy, no
     // stream synchronisation)
-    const unsigned xseq = ctx->x_seq;  // k_finalize of this tick carried it (set below, before the launch)
-    unsigned long long spins = 0;
-    unsigned got;
-    while (((got = __atomic_load_n(ctx->x_host_seq, __ATOMIC_ACQUIRE)) & 0x7fffffffu) != xseq) {
-#if defined(__x86_64__) || defined(__i386__)
-      __builtin_ia32_pause();
-#endif
-      if ((++spins & 0xFFFFF) == 0) {
-        const hipError_t q = hipStreamQuery(ctx->stream);
-        if (q != hipErrorNotReady && q != hipSuccess) return fail_hip("stream died while waiting for the exchange", q);
-        if (q == hipSuccess && (__atomic_load_n(ctx->x_host_seq, __ATOMIC_ACQUIRE) & 0x7fffffffu) != xseq)
-          return fail_hip("exchange finished without publishing", hipErrorUnknown);
+    const unsigned xseq = ctx->x_seq;  // k_finalize of this tick carried it (set above, before the launch)
+    for (int b = 0; b < n_bands; ++b) {
+      unsigned long long spins = 0;
+      int have = 0;
+      while ((have = take_wire(ctx->x_host + b, ctx->x_store + b, xseq, have)) != kFinWirePieces) {
+        __builtin_ia32_pause();
+        if (__atomic_load_n(ctx->x_host_seq, __ATOMIC_ACQUIRE) == (xseq | 0x80000000u)) {
+          g_last_error = "peer exchange timed out: a rank did not publish its band record";
+          return DVO_AMD_ERR_COMM;
+        }
+        if ((++spins & 0xFFFFF) == 0) {
+          const hipError_t q = hipStreamQuery(ctx->stream);
+          if (q != hipErrorNotReady && q != hipSuccess) return fail_hip("stream died while waiting for the exchange", q);
+          if (q == hipSuccess && (have = take_wire(ctx->x_host + b, ctx->x_store + b, xseq, have)) != kFinWirePieces)
+            return fail_hip("exchange finished without publishing", hipErrorUnknown);
+        }
       }
+      recs[b] = ctx->x_store + b;
     }
-    if (got & 0x80000000u) {
-      g_last_error = "peer exchange timed out: a rank did not publish its band record";
-      return DVO_AMD_ERR_COMM;
-    }
-    for (int b = 0; b < n_bands; ++b) recs[b] = ctx->x_host + b;
   } else if (exchange) {
     // per-iteration RCCL all-gather of the band records over xGMI, then one D2H copy of all of them
     if (ctx->p_allgather(ctx->slots[0].out_dev, ctx->gather_dev, sizeof(FinOut), ncclChar, ctx->comm, ctx->stream) != ncclSuccess) {
@@ -1849,7 +1852,7 @@ int dvo_amd_exchange_create(dvo_amd_context *ctx, int nranks, int rank, unsigned
   if (ctx->xbuf) return DVO_AMD_ERR_INVALID_ARGUMENT;
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
   HIP_TRY(hipSetDevice(ctx->device));
-  const size_t bytes = sizeof(FinOut) * 2 * (size_t)nranks;
+  const size_t bytes = sizeof(FinWire) * 2 * (size_t)nranks;
   // fine-grained device memory: writes of other agents become visible to a running kernel (coarse-grained memory is only
   // coherent at kernel boundaries)
   hipError_t e = hipExtMallocWithFlags((void **)&ctx->xbuf, bytes, hipDeviceMallocFinegrained);
@@ -1859,7 +1862,8 @@ int dvo_amd_exchange_create(dvo_amd_context *ctx, int nranks, int rank, unsigned
     e = hipMalloc((void **)&ctx->xbuf, bytes);
   }
   if (e == hipSuccess) e = hipMemset(ctx->xbuf, 0, bytes);
-  if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->x_host, sizeof(FinOut) * kMaxExchangeRanks, hipHostMallocMapped | hipHostMallocCoherent);
+  if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->x_host, sizeof(FinWire) * kMaxExchangeRanks, hipHostMallocMapped | hipHostMallocCoherent);
+  if (e == hipSuccess) std::memset(ctx->x_host, 0, sizeof(FinWire) * kMaxExchangeRanks);
   if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->x_host_seq, 64, hipHostMallocMapped | hipHostMallocCoherent);
   hipIpcMemHandle_t h;
   std::memset(&h, 0, sizeof(h));
@@ -1893,7 +1897,7 @@ int dvo_amd_exchange_attach(dvo_amd_context *ctx, const unsigned char *handles) 
       dvo_amd_exchange_destroy(ctx);
       return fail_hip("hipIpcOpenMemHandle", e);
     }
-    ctx->xpeers[r] = (FinOut *)p;
+    ctx->xpeers[r] = (FinWire *)p;
     ctx->xpeer_opened[r] = true;
   }
   ExchangeArgs xa;

@@ -121,15 +121,15 @@ struct alignas(16) FinWire {
 // ---- one-hop exchange of band records between the GPUs of a node (tile-sharded pairs) ------------------------------------
 // Every rank owns an exchange buffer of 2 x n_ranks record slots in fine-grained device memory that its peers have mapped
 // (hipIpc).  Per tick (sequence number q) rank r writes its band record into slot (q & 1) * n_ranks + r of EVERY rank's
-// buffer, payload first, the record's sequence word last; every rank waits until the n_ranks slots of generation q & 1 carry
-// q and forwards them to its own host.  All of it happens in the tail of k_finalize (no extra launch).  A peer can be at most one tick ahead (it needs this rank's record of tick q to
+// buffer as 16-byte pieces that carry q as their tag (FinWire: no fence, no ready word); every rank waits until all pieces of
+// the n_ranks slots of generation q & 1 carry q and forwards them, still tagged, to its own host.  All of it happens in the tail of k_finalize (no extra launch).  A peer can be at most one tick ahead (it needs this rank's record of tick q to
 // finish tick q, and only then publishes q + 1), so two generations never collide.
 constexpr int kMaxExchangeRanks = 16;
 struct ExchangeArgs {                 // constant per context once the peers are attached; lives in device memory
-  FinOut *peers[kMaxExchangeRanks];   // exchange buffers of all ranks as mapped here (own one included)
-  const FinOut *local;                // this rank's own exchange buffer
-  FinOut *host_records;               // pinned host memory, n_ranks records in rank order
-  unsigned *host_seq;                 // pinned host word: q once all records have landed, q | 0x80000000 on a timeout
+  FinWire *peers[kMaxExchangeRanks];  // exchange buffers of all ranks as mapped here (own one included)
+  const FinWire *local;               // this rank's own exchange buffer
+  FinWire *host_records;              // pinned host memory, n_ranks records in rank order (tagged pieces, like every record)
+  unsigned *host_seq;                 // pinned host word: q | 0x80000000 when the wait for a peer's record of tick q timed out
   int n_ranks, rank;
   unsigned timeout_ticks;             // bound on the wait in units of 10 ns (s_memrealtime)
   unsigned pad;

@@ -52,7 +52,7 @@ def split_for_threads(items: Sequence, n_threads: int) -> List[list]:
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# One-hop exchange of band records (tile-sharded pairs): the slot / sequence protocol of k_exchange (csrc/dvo_kernels.hip),
+# One-hop exchange of band records (tile-sharded pairs): the slot / tag protocol of exchange_records (csrc/dvo_kernels.hip),
 # restated on the host so that its ordering rules can be exercised without GPUs (tests/test_distributed.py).
 # ---------------------------------------------------------------------------------------------------------------------
 def exchange_slot(seq: int, n_ranks: int, rank: int) -> int:
@@ -61,22 +61,38 @@ def exchange_slot(seq: int, n_ranks: int, rank: int) -> int:
 
 
 class ExchangeBuffer:
-    """One rank's exchange buffer over any writable (2 * n_ranks, words) uint32 array (shared memory in the tests, fine-grained
-    device memory mapped by the peers on the GPUs).  Word 0 of a slot is the sequence word, written last."""
+    """One rank's exchange buffer over any writable (2 * n_ranks, pieces, 4) array (shared memory in the tests, fine-grained
+    device memory mapped by the peers on the GPUs).  A record travels as pieces of three payload words plus the tick number
+    as a tag, each piece written in one go: a piece is valid when its tag is the tick, so there is no "ready" word and no
+    ordering between the pieces (csrc/dvo_types.h: FinWire)."""
+
+    PAYLOAD = 3
 
     def __init__(self, array, n_ranks: int):
         self.a = array
         self.n = n_ranks
-        assert array.shape[0] == 2 * n_ranks
+        assert array.shape[0] == 2 * n_ranks and array.shape[2] == self.PAYLOAD + 1
 
-    def publish(self, seq: int, rank: int, payload):
+    @classmethod
+    def pieces_for(cls, words: int) -> int:
+        return (words + cls.PAYLOAD - 1) // cls.PAYLOAD
+
+    def publish(self, seq: int, rank: int, payload, order=None):
+        """`order`: the order the pieces are written in (any order is fine; the tests write them backwards)"""
         row = self.a[exchange_slot(seq, self.n, rank)]
-        row[1:1 + len(payload)] = payload  # payload first ...
-        row[0] = seq                       # ... the sequence word last
+        n = self.pieces_for(len(payload))
+        for i in (range(n) if order is None else order):
+            piece = [0] * (self.PAYLOAD + 1)
+            chunk = payload[self.PAYLOAD * i:self.PAYLOAD * (i + 1)]
+            piece[:len(chunk)] = chunk
+            piece[self.PAYLOAD] = seq
+            row[i] = piece  # one store per piece
 
-    def ready(self, seq: int) -> bool:
-        return all(int(self.a[exchange_slot(seq, self.n, r), 0]) == seq for r in range(self.n))
+    def ready(self, seq: int, words: int) -> bool:
+        n = self.pieces_for(words)
+        return all(all(int(t) == seq for t in self.a[exchange_slot(seq, self.n, r), :n, self.PAYLOAD]) for r in range(self.n))
 
     def collect(self, seq: int, words: int):
-        """the n records of tick `seq` in rank order (call once ready(seq))"""
-        return [self.a[exchange_slot(seq, self.n, r), 1:1 + words].copy() for r in range(self.n)]
+        """the n records of tick `seq` in rank order (call once ready(seq, words))"""
+        n = self.pieces_for(words)
+        return [self.a[exchange_slot(seq, self.n, r), :n, :self.PAYLOAD].reshape(-1)[:words].copy() for r in range(self.n)]

@@ -233,7 +233,8 @@ def _exchange_worker(rank, world, port, shm_paths, out_q):
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     words = 10
     # every rank's buffer lives in its own shared-memory file; every rank maps all of them (hipIpcOpenMemHandle on the GPUs)
-    bufs = [sharding.ExchangeBuffer(np.memmap(pth, dtype=np.float64, mode="r+", shape=(2 * world, 1 + words)), world)
+    pieces = sharding.ExchangeBuffer.pieces_for(words)
+    bufs = [sharding.ExchangeBuffer(np.memmap(pth, dtype=np.float64, mode="r+", shape=(2 * world, pieces, 4)), world)
             for pth in shm_paths]
     rng = np.random.default_rng(5)
     combined = []
@@ -246,9 +247,9 @@ def _exchange_worker(rank, world, port, shm_paths, out_q):
         if rank == 1 and seq % 3 == 0:
             time.sleep(0.05)  # the straggler: rank 0 gets a tick ahead in its publishing, never two
         for b in bufs:
-            b.publish(seq, rank, mine)
+            b.publish(seq, rank, mine, order=reversed(range(pieces)) if seq % 2 else None)  # no order between the pieces
         t0 = time.time()
-        while not bufs[rank].ready(seq):
+        while not bufs[rank].ready(seq, words):
             assert time.time() - t0 < 30.0, "bounded wait"
             time.sleep(0.0005)
         recs = np.stack(bufs[rank].collect(seq, words))
@@ -269,7 +270,7 @@ def test_two_gloo_ranks_run_the_exchange_protocol(tmp_path):
     paths = []
     for r in range(world):
         pth = str(tmp_path / f"xbuf{r}.bin")
-        np.zeros((2 * world, 11), np.float64).tofile(pth)
+        np.zeros((2 * world, 4, 4), np.float64).tofile(pth)  # 10 words = 4 pieces of 3 + tag
         paths.append(pth)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
