@@ -28,7 +28,7 @@ EXPORTS = [
     "dvo_amd_residuals", "dvo_amd_error_image", "dvo_amd_kernel_timing", "dvo_amd_se3_exp", "dvo_amd_se3_log",
     "dvo_amd_solve6", "dvo_amd_bench_residual_pass", "dvo_amd_match_many",
     "dvo_amd_debug_finalize_stamps", "dvo_amd_comm_unique_id", "dvo_amd_comm_create", "dvo_amd_comm_destroy",
-    "dvo_amd_match_sharded", "dvo_amd_match_banded", "dvo_amd_debug_combine_bands", "dvo_amd_pyramid_create_raw",
+    "dvo_amd_match_sharded", "dvo_amd_match_banded", "dvo_amd_debug_combine_bands", "dvo_amd_debug_wire_layout", "dvo_amd_debug_take_wire", "dvo_amd_pyramid_create_raw",
     "dvo_amd_default_validator_stages", "dvo_amd_proposals_for_candidates", "dvo_amd_validate_proposals",
     "dvo_amd_track_frame", "dvo_amd_png_info", "dvo_amd_png_read_bgr8", "dvo_amd_png_read_gray16",
     "dvo_amd_format_trajectory_line", "dvo_amd_debug_tick_log", "dvo_amd_debug_iteration", "dvo_amd_match_selection", "dvo_amd_bench_residual_pass_pairs",
@@ -163,6 +163,8 @@ def lib():
     L.dvo_amd_match_sharded.argtypes = [vp, vp, vp, dp, C.POINTER(CResult)]
     L.dvo_amd_match_banded.argtypes = [vp, vp, vp, dp, C.POINTER(CResult), C.c_int]
     L.dvo_amd_debug_combine_bands.argtypes = [C.c_int, dp, dp]
+    L.dvo_amd_debug_wire_layout.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.dvo_amd_debug_take_wire.argtypes = [C.POINTER(C.c_uint), C.c_uint, C.c_int, C.POINTER(C.c_uint)]
     L.dvo_amd_se3_exp.argtypes = [dp, dp]
     L.dvo_amd_se3_exp.restype = None
     L.dvo_amd_se3_log.argtypes = [dp, dp]
@@ -573,6 +575,24 @@ def comm_unique_id() -> bytes:
     buf = (C.c_ubyte * 128)()
     _check(lib().dvo_amd_comm_unique_id(buf), "dvo_amd_comm_unique_id")
     return bytes(buf)
+
+
+def wire_layout():
+    """(pieces, payload words) of a record on its way to the host: pieces of three payload words and the tick number"""
+    a, b = C.c_int(), C.c_int()
+    _check(lib().dvo_amd_debug_wire_layout(C.byref(a), C.byref(b)), "wire_layout")
+    return a.value, b.value
+
+
+def take_wire(wire: np.ndarray, tick: int, from_piece: int, record: np.ndarray) -> int:
+    """Host side of the record hand-off (host only): `wire` is a 16-byte aligned uint32 array [pieces, 4], `record` the uint32
+    payload words collected so far; returns the first piece that does not carry `tick` yet."""
+    up = C.POINTER(C.c_uint)
+    assert wire.dtype == np.uint32 and record.dtype == np.uint32 and wire.flags.c_contiguous and record.flags.c_contiguous
+    rc = lib().dvo_amd_debug_take_wire(wire.ctypes.data_as(up), tick, from_piece, record.ctypes.data_as(up))
+    if rc < 0:
+        _check(-rc, "take_wire")
+    return rc
 
 
 def combine_bands(bands) -> np.ndarray:

@@ -1942,6 +1942,22 @@ int dvo_amd_match_sharded(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_
   return match_one_banded(ctx, reference, current, T_init, result, ctx->comm_ranks, ctx->comm_rank, 1, true);
 }
 
+int dvo_amd_debug_wire_layout(int *n_pieces, int *n_record_words) {
+  if (!n_pieces || !n_record_words) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  *n_pieces = kFinWirePieces, *n_record_words = kFinWords;
+  return DVO_AMD_OK;
+}
+
+int dvo_amd_debug_take_wire(const unsigned *wire, unsigned tick, int from_piece, unsigned *record_words) {
+  if (!wire || !record_words || from_piece < 0 || from_piece > kFinWirePieces || (reinterpret_cast<uintptr_t>(wire) & 15u))
+    return -DVO_AMD_ERR_INVALID_ARGUMENT;
+  FinOut rec;
+  std::memcpy(&rec, record_words, sizeof(rec));
+  const int next = take_wire(reinterpret_cast<const FinWire *>(wire), &rec, tick, from_piece);
+  std::memcpy(record_words, &rec, sizeof(rec));
+  return next;
+}
+
 int dvo_amd_debug_combine_bands(int n_bands, const double *bands, double *out) {
   // bands: n x {valid, first_w, last_r0, last_r1, S[3], S_odd[3]} = 10 doubles each; out: {valid, S[3], S_odd[3]}
   if (n_bands < 1 || n_bands > 4096 || !bands || !out) return DVO_AMD_ERR_INVALID_ARGUMENT;

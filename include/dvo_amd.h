@@ -218,6 +218,15 @@ int dvo_amd_match_banded(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_a
 /* host-only: the ordered combine of band records {valid, first_w, last_r0, last_r1, S[3], S_odd[3]} (10 doubles per band)
  * -> {valid, S[3], S_odd[3]}; exported for the CPU tests of the multi-GPU path */
 int dvo_amd_debug_combine_bands(int n_bands, const double *bands, double *out);
+/* host-only: the receiving side of the record hand-off.  A tick's 784-byte record reaches the host (and, for a sharded pair,
+ * the peers) as `*n_pieces` pieces of 16 bytes -- three payload words and the tick number -- each written by one store of
+ * the device; a piece counts when its tag is the tick waited for, in whatever order the pieces arrive.
+ * dvo_amd_debug_wire_layout reports the piece and payload-word counts; dvo_amd_debug_take_wire copies the payload of the
+ * pieces from `from_piece` on that carry `tick` out of `wire` (16-byte aligned, 4 words per piece) into `record_words`
+ * and returns the index of the first piece that does not (n_pieces when the record is complete), or minus an error code.
+ * Exported for the CPU tests. */
+int dvo_amd_debug_wire_layout(int *n_pieces, int *n_record_words);
+int dvo_amd_debug_take_wire(const unsigned *wire, unsigned tick, int from_piece, unsigned *record_words);
 
 /*
  * Batched 2-stage loop-closure validation: dvo_slam::constraints::ConstraintProposalValidator::validate
