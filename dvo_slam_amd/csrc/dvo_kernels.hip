@@ -198,7 +198,8 @@ __device__ __forceinline__ void finish_pixel_rtz(const LevelPairDesc &d, const P
   const float czy = DVO_BLEND(g.b0.y, g.b0.w, g.b1.y, g.b1.w);
 #undef DVO_BLEND
   // any NaN among the blended channels rejects the point (:261); channels 6,7 are always 0
-  const bool has_nan = (ci != ci) || (cz != cz) || (cix != cix) || (ciy != ciy) || (czx != czx) || (czy != czy);
+  // (one unordered compare tests two channels)
+  const bool has_nan = __builtin_isunordered(ci, cz) || __builtin_isunordered(cix, ciy) || __builtin_isunordered(czx, czy);
   // e = wcur * cur + wref * ref', ref' = {I, transformed depth, Ix, Iy} (:269-271)
   const float t0 = d.wc[0] * ci + d.wr[0] * ri;
   const float t1 = d.wc[1] * cz + d.wr[1] * p.sz;
@@ -536,16 +537,17 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
     {
       // computeScaleSse with Q5: a pair (2j, 2j+1) contributes (w_2j + w_2j+1) r_2j r_2j^T (:603-621).
       // S0 assumes this segment starts on an even global rank, S1 on an odd one.  Invalid pixels have weight 0.
-      const float sxx = r0 * r0, sxy = r0 * r1, syy = r1 * r1;
-      // the segment's first valid pixel reads the zeros slot 0 starts with, so its "predecessor" products vanish
-      const float pxx = prev.x * prev.x, pxy = prev.x * prev.y, pyy = prev.y * prev.y;
+      // the segment's first valid pixel reads the zeros slot 0 starts with, so its "predecessor" products vanish.
+      // (the residual is picked before it is squared: four selects instead of six)
       const bool odd = (rank & 1) != 0;
-      S0[0] = __builtin_fmaf(wgt, odd ? pxx : sxx, S0[0]);
-      S0[1] = __builtin_fmaf(wgt, odd ? pxy : sxy, S0[1]);
-      S0[2] = __builtin_fmaf(wgt, odd ? pyy : syy, S0[2]);
-      S1[0] = __builtin_fmaf(wgt, odd ? sxx : pxx, S1[0]);
-      S1[1] = __builtin_fmaf(wgt, odd ? sxy : pxy, S1[1]);
-      S1[2] = __builtin_fmaf(wgt, odd ? syy : pyy, S1[2]);
+      const float a0 = odd ? prev.x : r0, a1 = odd ? prev.y : r1;  // what the even-start hypothesis weights at this pixel
+      const float b0 = odd ? r0 : prev.x, b1 = odd ? r1 : prev.y;  // ... the odd-start hypothesis
+      S0[0] = __builtin_fmaf(wgt, a0 * a0, S0[0]);
+      S0[1] = __builtin_fmaf(wgt, a0 * a1, S0[1]);
+      S0[2] = __builtin_fmaf(wgt, a1 * a1, S0[2]);
+      S1[0] = __builtin_fmaf(wgt, b0 * b0, S1[0]);
+      S1[1] = __builtin_fmaf(wgt, b0 * b1, S1[1]);
+      S1[2] = __builtin_fmaf(wgt, b1 * b1, S1[2]);
       // first valid pixel of the segment: its partner (if any) lives in an earlier segment
       first_w = (ok && rank == 0) ? wgt : first_w;
     }
