@@ -1031,7 +1031,15 @@ __device__ bool exchange_records(const ExchangeArgs &a, const unsigned *own_reco
 // log-likelihood partials in fp64 with 16-byte loads, eight in flight per thread.  Two block barriers in all; the record is
 // assembled in LDS and pushed to the pinned host buffer as self-validating 16-byte pieces (FinWire): no fence, no ready word.
 __global__ __launch_bounds__(kFinThreads) void k_finalize(const FinArgs args) {
-  const FinItem &it = args.items[blockIdx.x];
+  FinItem it;
+  if (args.table) {  // more items than the argument block holds: the item comes from the table uploaded with the tick's items
+    const DVO_CONST FinItem *p = (const DVO_CONST FinItem *)args.table + blockIdx.x;
+    it.records = p->records, it.n_blocks = p->n_blocks, it.block_first = p->block_first;
+    it.n_ll_blocks = p->n_ll_blocks, it.ll_first = p->ll_first, it.ll_partials = p->ll_partials;
+    it.seg_prefix_out = p->seg_prefix_out, it.out = p->out, it.out_dev = p->out_dev, it.seq = p->seq, it.pad = p->pad;
+  } else {
+    it = args.items[blockIdx.x];
+  }
   const int t = threadIdx.x;
   __shared__ double sh_acc[kFinChunks][kFinCols];
   __shared__ SegRec sh_seg[kFinSegThreads];

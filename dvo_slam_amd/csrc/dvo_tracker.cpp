@@ -419,6 +419,9 @@ int pyramid_selection(dvo_amd_pyramid *p, float ti, float td, const Selection **
 // context + Gauss-Newton driver
 // ------------------------------------------------------------------------------------------------------------------
 
+// bytes of one tick stream's item table: tick items, then reduce items
+constexpr size_t kTableBytes = ((sizeof(TickItem) * kMaxTableItems + 63) / 64) * 64 + sizeof(FinItem) * kMaxTableItems;
+
 struct JobSlot {
   float2 *res[2] = {nullptr, nullptr};
   float *records = nullptr;
@@ -445,7 +448,8 @@ struct dvo_amd_context {
   unsigned *tickets = nullptr;         // device, one arrival counter per tick stream
   // item tables for launches with more pairs than the kernel-argument block holds: per tick stream a pinned host staging
   // area and its device copy (uploaded in-stream in front of the launch)
-  TickItem *item_host = nullptr, *item_dev = nullptr;  // [kMaxTickStreams][kMaxTableItems]
+  // per tick stream: kMaxTableItems tick items followed by as many reduce items (one upload per launch)
+  char *item_host = nullptr, *item_dev = nullptr;
   int stage_owner[kMaxTickStreams] = {0, 0, 0, 0, 0, 0, 0, 0};  // pair group (id + 1) whose table upload last used a staging slot
   int items_per_launch = kMaxItemsPerLaunch;           // DVO_AMD_ITEMS_PER_LAUNCH (<= kMaxTableItems)
   int spec_levels = -1;                                // start the next level speculatively in the tick of a level's last
@@ -1124,8 +1128,8 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
   const size_t n_launch = (items.size() + cap - 1) / cap;
   const size_t per = (items.size() + n_launch - 1) / n_launch;
   if (per > (size_t)kMaxItemsPerLaunch && !ctx->item_host) {
-    HIP_TRY(hipHostMalloc((void **)&ctx->item_host, sizeof(TickItem) * kMaxTickStreams * kMaxTableItems, hipHostMallocDefault));
-    HIP_TRY(hipMalloc((void **)&ctx->item_dev, sizeof(TickItem) * kMaxTickStreams * kMaxTableItems));
+    HIP_TRY(hipHostMalloc((void **)&ctx->item_host, kTableBytes * kMaxTickStreams, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void **)&ctx->item_dev, kTableBytes * kMaxTickStreams));
   }
   size_t launch_index = 0;
   for (size_t first = 0; first < items.size(); first += per, ++launch_index) {
@@ -1141,7 +1145,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
     ta.n_items = use_table ? 0 : n_here;
     ta.compact = 0;
     int max_blocks = 0;
-    TickItem *stage = use_table ? ctx->item_host + stream_slot * kMaxTableItems : ta.items;
+    TickItem *stage = use_table ? reinterpret_cast<TickItem *>(ctx->item_host + stream_slot * kTableBytes) : ta.items;
     // Optionally (DVO_AMD_PHYS_BLOCKS) a physical block walks several logical ones, so that only the first pays the
     // dependent-load prologue.  Measured on MI355X: the coarser scheduling loses more than the prologue costs (36 level-0
     // pairs: 129 us with one block per logical block, 141 us folded 2x, 157 us folded 5x), so the default is no folding.
@@ -1162,9 +1166,14 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
         HIP_TRY(hipStreamSynchronize(st));
       ctx->stage_owner[stream_slot] = grp.id + 1;
     }
-    if (use_table)
-      HIP_TRY(hipMemcpyAsync(ctx->item_dev + stream_slot * kMaxTableItems, stage, sizeof(TickItem) * (size_t)n_here,
+    // the reduce items of the launch travel behind its tick items, in the same upload
+    const size_t fin_offset = align_up(sizeof(TickItem) * (size_t)n_here, 64);
+    if (use_table) {
+      FinItem *fin_stage = reinterpret_cast<FinItem *>(reinterpret_cast<char *>(stage) + fin_offset);
+      for (int i = 0; i < n_here; ++i) fin_stage[i] = fin_items[first + (size_t)i];
+      HIP_TRY(hipMemcpyAsync(ctx->item_dev + stream_slot * kTableBytes, stage, fin_offset + sizeof(FinItem) * (size_t)n_here,
                              hipMemcpyHostToDevice, st));
+    }
     size_t ev = 0;
     if (ctx->timing) {
       int rc = timing_begin(ctx, &ev);
@@ -1186,16 +1195,19 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
     }
     hipEvent_t t0 = ctx->timing ? ctx->events[ev].first : nullptr, t1 = ctx->timing ? ctx->events[ev].second : nullptr;
     if (!use_table) (void)tick_args_layout(ta, max_blocks);
-    hipError_t e = use_table ? launch_tick_table(ctx->item_dev + stream_slot * kMaxTableItems, n_here, max_blocks, st, t0, t1)
+    hipError_t e = use_table ? launch_tick_table(reinterpret_cast<const TickItem *>(ctx->item_dev + stream_slot * kTableBytes), n_here, max_blocks, st, t0, t1)
                              : launch_tick(ta, max_blocks, st, t0, t1);
     if (e != hipSuccess) return fail_hip("launch_tick", e);
-    for (int f0 = 0; f0 < n_here; f0 += kMaxFinItems) {  // the reduce kernel takes its items by value, 48 per launch
+    // the reduce kernel takes its items by value, 48 per launch, or all of them from the table the tick's upload carried
+    for (int f0 = 0; f0 < n_here; f0 += use_table ? n_here : kMaxFinItems) {
       FinArgs fa;
-      fa.n_items = std::min(kMaxFinItems, n_here - f0);
+      fa.n_items = use_table ? n_here : std::min(kMaxFinItems, n_here - f0);
       fa.pad = ctx->fin_stamps ? 0x57A3 : 0;
       fa.ticket = ctx->tickets + 16 * stream_slot;  // one counter per stream
       fa.exchange = nullptr, fa.xseq = 0, fa.pad2 = 0;
-      for (int i = 0; i < fa.n_items; ++i) fa.items[i] = fin_items[first + (size_t)f0 + (size_t)i];
+      fa.table = use_table ? reinterpret_cast<const FinItem *>(ctx->item_dev + stream_slot * kTableBytes + fin_offset) : nullptr;
+      if (!use_table)
+        for (int i = 0; i < fa.n_items; ++i) fa.items[i] = fin_items[first + (size_t)f0 + (size_t)i];
       e = launch_finalize(fa, st);
       if (e != hipSuccess) return fail_hip("launch_finalize", e);
     }

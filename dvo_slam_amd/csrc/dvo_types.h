@@ -154,6 +154,7 @@ struct FinArgs {
   const struct ExchangeArgs *exchange;  // tile-sharded pair: push item 0's record to the peers, gather theirs (else null)
   unsigned xseq;          // sequence number of this tick's exchange
   unsigned pad2;
+  const FinItem *table;   // n_items items in device memory (uploaded in-stream with the tick's item table) instead of items[]
   FinItem items[kMaxFinItems];
 };
 static_assert(sizeof(FinArgs) <= 3800, "kernel argument block too large");
