@@ -228,6 +228,8 @@ typedef float v4acc __attribute__((ext_vector_type(4)));
 // Timing-only ablation builds (scripts/ablate.sh: -DDVO_ABLATE=<mask>); never defined in the shipped library.
 // 1: no LDS staging / MFMA   2: no gather loads   4: no rank / pair-sum logic   8: no residual spill store
 // 16: no pixel steps at all (prologue + epilogue only)   32: no epilogue (reductions, block record)
+// 64: epilogue without the seven wave reductions   128: without the moment sums of the four waves   256: without the ordered
+// combine of the four wave segments
 #ifndef DVO_ABLATE
 #define DVO_ABLATE 0
 #endif
@@ -611,12 +613,12 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    const float s0 = wave_sum_to_lane63<RMODE>(S0[i]);
-    const float s1 = wave_sum_to_lane63<RMODE>(S1[i]);
+    const float s0 = (DVO_ABLATE & 64) ? S0[i] : wave_sum_to_lane63<RMODE>(S0[i]);
+    const float s1 = (DVO_ABLATE & 64) ? S1[i] : wave_sum_to_lane63<RMODE>(S1[i]);
     if (lane == 63) sm[wave][kRecS0 + i] = s0, sm[wave][kRecS1 + i] = s1;
   }
   {
-    const float fw = wave_sum_to_lane63<RMODE>(first_w);
+    const float fw = (DVO_ABLATE & 64) ? first_w : wave_sum_to_lane63<RMODE>(first_w);
     if (lane == 63) {
       const v2f last = slots[0];  // the last valid residual of the segment (zeros if there is none)
       sm[wave][kRecFirstW] = fw;
@@ -629,7 +631,11 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
 
   DVO_GLOBAL float *rec = (DVO_GLOBAL float *)d.records + (size_t)lb * kRecStride;
   const int tid = threadIdx.x;
-  if (tid < kNumAcc) {
+  if ((DVO_ABLATE & 128) && tid < kNumAcc) {
+    rec[kRecAcc + tid] = stage[tid];
+  } else if ((DVO_ABLATE & 256) && tid == 128) {
+    rec[kRecCount] = sm[0][kRecCount];
+  } else if (tid < kNumAcc) {
     if (ACC == 0) {
       rec[kRecAcc + tid] = (sm[0][kRecAcc + tid] + sm[1][kRecAcc + tid]) + (sm[2][kRecAcc + tid] + sm[3][kRecAcc + tid]);
     } else {
