@@ -267,6 +267,7 @@ def main():
         k_ms, k_launches = trk.kernel_timing(False)
         log = trk.tick_log()
         alg_bytes_k = sum(o.alg_bytes for o in out)
+    elapsed_local = elapsed
     # MAX over ranks of the elapsed time, SUM over ranks of the pairs aligned
     elapsed, pairs = sharding.aggregate(elapsed, B * args.steps, dist,
                                         None if dist is None else ("cpu" if args.rehearse_on_one_gpu else "cuda"))
@@ -334,13 +335,20 @@ def main():
                             "the timed region (which ran %d streams at once: its launches overlap, so the per-launch figure "
                             "here is not the concurrent rate)" % T),
                 "residual_passes": int(passes),
+                "concurrent": {
+                    "achieved": alg_bytes / elapsed_local / 1e9, "unit": "GB/s", "frac": alg_bytes / elapsed_local / 1e9 / HBM_PEAK_GBS,
+                    "what": "all launches of the timed region of this GPU together: their algorithmic bytes / the wall time of the "
+                            "region (%d host threads, k_finalize and the host turn-around included)" % T},
                 "issue": issue_roofline(log, k_ms),
             },
         }
         try:
-            ms_i, ab_i, nl_i = trk.bench_residual_pass(ref, curs[0], 0, cur_pose(0), 36, 0, reps=20)
+            # (8 steps per wave: what suits a launch that has the GPU to itself; the driver's own choice for this many pixels is
+            # 16, tuned for launches that share the GPU with three others)
+            ms_i, ab_i, nl_i = trk.bench_residual_pass(ref, curs[0], 0, cur_pose(0), 36, 2, reps=20)
             line["roofline_isolated_kernel"] = {
-                "what": "the residual pass alone: level 0, 36 pairs in one launch (one launch's worth of resident pairs)",
+                "what": "the residual pass alone: level 0, 36 pairs in one launch (one launch's worth of resident pairs), 8 steps "
+                        "of 64 pixels per wave",
                 "achieved": ab_i / ms_i / 1e6, "unit": "GB/s", "frac": ab_i / ms_i / 1e6 / HBM_PEAK_GBS,
                 "launch_us": ms_i * 1e3 / nl_i, "alg_bytes_per_launch": ab_i / nl_i}
         except Exception as exc:  # pragma: no cover

@@ -481,7 +481,10 @@ struct dvo_amd_context {
   ncclResult_t (*p_allgather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*p_comm_destroy)(ncclComm_t) = nullptr;
   unsigned tick_seq = 0;
-  long long steps_at[4] = {2048, 8192, 32768, 262144};  // wave-step counts from which a tick takes 2 / 4 / 8 / 16 steps per wave
+  // wave-step counts from which a tick takes 2 / 4 / 8 / 16 steps per wave.  Tuned on the throughput of several streams at once:
+  // a launch that runs alone on the GPU would like segments half as long (more blocks to fill it), kernels that share the
+  // GPU with three others gain more from fewer prologues and epilogues (+6 % pairs/s against 2048, 8192, 32768, 262144)
+  long long steps_at[4] = {2048, 4096, 12288, 49152};
                                                          // (DVO_AMD_STEPS_AT="a,b,c,d", read when the context is created)
   int fault_slot_alloc = -1;           // DVO_AMD_FAULT_SLOT_ALLOC: fail the allocation of this slot once (tests of the error path)
   bool fin_stamps = false;             // DVO_AMD_FIN_STAMPS=1: k_finalize records phase stamps (diagnostic)
