@@ -627,10 +627,31 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
       sm[wave][kRecLastR + 1] = last.y;
     }
   }
+  // which Gram-matrix entries make up moment `tid` (rows/cols 0-5 = Ja, 6-11 = Jb, 12 = r0, 13 = r1): worked out while the
+  // other waves are still on their way to the barrier
+  const int tid = threadIdx.x;
+  int e0 = 0, e1 = -1;
+  if (ACC >= 1 && tid < kNumAcc) {
+    if (tid < kAccAR0) {
+      const int kind = tid / 21;
+      int t = tid - kind * 21, i = 0;
+      while (t >= 6 - i) t -= 6 - i, ++i;
+      const int j = i + t;
+      if (kind == 0) {
+        e0 = i * 16 + j;
+      } else if (kind == 1) {
+        e0 = i * 16 + 6 + j, e1 = j * 16 + 6 + i;
+      } else {
+        e0 = (6 + i) * 16 + 6 + j;
+      }
+    } else {
+      const int q = tid - kAccAR0, grp = q / 6, i = q - grp * 6;  // AR0, AR1, BR0, BR1
+      e0 = ((grp >> 1) * 6 + i) * 16 + 12 + (grp & 1);
+    }
+  }
   __syncthreads();
 
   DVO_GLOBAL float *rec = (DVO_GLOBAL float *)d.records + (size_t)lb * kRecStride;
-  const int tid = threadIdx.x;
   if ((DVO_ABLATE & 128) && tid < kNumAcc) {
     rec[kRecAcc + tid] = stage[tid];
   } else if ((DVO_ABLATE & 256) && tid == 128) {
@@ -639,24 +660,6 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
     if (ACC == 0) {
       rec[kRecAcc + tid] = (sm[0][kRecAcc + tid] + sm[1][kRecAcc + tid]) + (sm[2][kRecAcc + tid] + sm[3][kRecAcc + tid]);
     } else {
-      // map the moment index back to Gram-matrix entries (rows/cols 0-5 = Ja, 6-11 = Jb, 12 = r0, 13 = r1)
-      int e0, e1 = -1;
-      if (tid < kAccAR0) {
-        const int kind = tid / 21;
-        int t = tid - kind * 21, i = 0;
-        while (t >= 6 - i) t -= 6 - i, ++i;
-        const int j = i + t;
-        if (kind == 0) {
-          e0 = i * 16 + j;
-        } else if (kind == 1) {
-          e0 = i * 16 + 6 + j, e1 = j * 16 + 6 + i;
-        } else {
-          e0 = (6 + i) * 16 + 6 + j;
-        }
-      } else {
-        const int q = tid - kAccAR0, grp = q / 6, i = q - grp * 6;  // AR0, AR1, BR0, BR1
-        e0 = ((grp >> 1) * 6 + i) * 16 + 12 + (grp & 1);
-      }
       float v;
       if (ACC == 2) {
         // Gram entry (r, c), r <= c, lives in block type (r / 4, c / 4) at (r % 4, c % 4): sum over the 4 waves x 4 rows
@@ -681,34 +684,44 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
       rec[kRecAcc + tid] = v;
     }
   } else if (tid == 128) {
-    // ordered combine of the four wave segments (see combine rule in k_finalize)
-    int c = 0;
+    // ordered combine of the four wave segments (see combine rule in k_finalize).  Everything is read first and the fold is
+    // written without branches (an empty segment changes nothing, through selects): one round of LDS latency instead of
+    // eight in the tail of every block
+    unsigned CB[kWavesPerBlock];
+    float FW[kWavesPerBlock], L0[kWavesPerBlock], L1[kWavesPerBlock], A0[kWavesPerBlock][3], A1[kWavesPerBlock][3];
+#pragma unroll
+    for (int wv = 0; wv < kWavesPerBlock; ++wv) {
+      CB[wv] = f2u(sm[wv][kRecCount]), FW[wv] = sm[wv][kRecFirstW], L0[wv] = sm[wv][kRecLastR], L1[wv] = sm[wv][kRecLastR + 1];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) A0[wv][i] = sm[wv][kRecS0 + i], A1[wv][i] = sm[wv][kRecS1 + i];
+    }
+    unsigned c = 0;
     float fw = 0.0f, l0 = 0.0f, l1 = 0.0f;
     float s0[3] = {0.0f, 0.0f, 0.0f}, s1[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
     for (int wv = 0; wv < kWavesPerBlock; ++wv) {
-      const int cb = (int)f2u(sm[wv][kRecCount]);
-      rec[kRecWaveCnt + wv] = u2f((unsigned)cb);
-      if (cb == 0) continue;
-      const float bfw = sm[wv][kRecFirstW];
-      const bool flip = (c & 1) != 0;  // b starts on the opposite parity of a
-      float x0[3], x1[3];
+      rec[kRecWaveCnt + wv] = u2f(CB[wv]);
+      const bool ne = CB[wv] != 0;           // an empty segment is skipped
+      const bool first = c == 0;             // nothing before it: its first weight is the combined segment's
+      const bool flip = (c & 1u) != 0;       // b starts on the opposite parity of a
+      const float bfw = FW[wv];
+      // b's first pixel is a pair-second when b starts on an odd rank: it weights a's last residual
+      const float r[3] = {l0 * l0, l0 * l1, l1 * l1};
+#pragma unroll
       for (int i = 0; i < 3; ++i) {
-        x0[i] = sm[wv][(flip ? kRecS1 : kRecS0) + i];  // contribution if the combined segment starts even
-        x1[i] = sm[wv][(flip ? kRecS0 : kRecS1) + i];  // ... starts odd
+        float x0 = flip ? A1[wv][i] : A0[wv][i];  // contribution if the combined segment starts even
+        float x1 = flip ? A0[wv][i] : A1[wv][i];  // ... starts odd
+        const float add = bfw * r[i];
+        x0 = (!first && flip) ? x0 + add : x0;
+        x1 = (!first && !flip) ? x1 + add : x1;
+        s0[i] = ne ? s0[i] + x0 : s0[i];
+        s1[i] = ne ? s1[i] + x1 : s1[i];
       }
-      if (c > 0) {
-        const float rxx = l0 * l0, rxy = l0 * l1, ryy = l1 * l1;
-        // b's first pixel is a pair-second when b starts on an odd rank: it weights a's last residual
-        float *tgt = flip ? x0 : x1;
-        tgt[0] += bfw * rxx, tgt[1] += bfw * rxy, tgt[2] += bfw * ryy;
-      } else {
-        fw = bfw;
-      }
-      for (int i = 0; i < 3; ++i) s0[i] += x0[i], s1[i] += x1[i];
-      l0 = sm[wv][kRecLastR], l1 = sm[wv][kRecLastR + 1];
-      c += cb;
+      fw = (ne && first) ? bfw : fw;
+      l0 = ne ? L0[wv] : l0, l1 = ne ? L1[wv] : l1;
+      c += CB[wv];
     }
-    rec[kRecCount] = u2f((unsigned)c);
+    rec[kRecCount] = u2f(c);
     rec[kRecFirstW] = fw;
     rec[kRecLastR] = l0;
     rec[kRecLastR + 1] = l1;
