@@ -838,19 +838,36 @@ __device__ __forceinline__ void tick_body(const TickItem &it, const int bx) {
   }
 }
 
+// Which item owns this block, and which of the item's blocks is it?  Two-dimensional grid: (block, item).  One-dimensional
+// ("compact") grid: lanes 0 .. n_items look at the items' first block groups; the owner is the last item that starts at or
+// before this block's group (every wave finds the same one).
+template <class Args>
+__device__ __forceinline__ int tick_locate(const Args &args, int &bx) {
+  constexpr int kSlots = (int)(sizeof(args.group_first) / sizeof(args.group_first[0]));
+  if (!args.compact) {
+    bx = (int)blockIdx.x;
+    return (int)blockIdx.y;
+  }
+  const int lane = threadIdx.x & (kWave - 1);
+  const unsigned g = blockIdx.x >> 3;
+  const unsigned first = lane <= args.n_items ? (unsigned)args.group_first[lane < kSlots ? lane : 0] : 0xFFFFFFFFu;
+  const int idx = __builtin_amdgcn_readfirstlane(__popcll(__ballot(first <= g)) - 1);
+  bx = (int)blockIdx.x - ((int)args.group_first[idx] << 3);
+  return idx;
+}
+
 template <int RMODE, int ACC, int OCC>
 __global__ __launch_bounds__(kBlockThreads, OCC) void k_tick(const TickArgs args) {
-  if (args.compact) {
-    // one-dimensional grid: which item owns this block?  Lanes 0 .. n_items look at the items' first block groups; the
-    // owner is the last item that starts at or before this block's group (every wave finds the same one).
-    const int lane = threadIdx.x & (kWave - 1);
-    const unsigned g = blockIdx.x >> 3;
-    const unsigned first = lane <= args.n_items ? (unsigned)args.group_first[lane < kMaxItemsPerLaunch + 4 ? lane : 0] : 0xFFFFFFFFu;
-    const int idx = __builtin_amdgcn_readfirstlane(__popcll(__ballot(first <= g)) - 1);
-    tick_body<RMODE, ACC, (OCC >= 5 || ACC == 2)>(args.items[idx], (int)blockIdx.x - ((int)args.group_first[idx] << 3));
-  } else {
-    tick_body<RMODE, ACC, (OCC >= 5 || ACC == 2)>(args.items[blockIdx.y], (int)blockIdx.x);
-  }
+  int bx;
+  const int idx = tick_locate(args, bx);
+  tick_body<RMODE, ACC, (OCC >= 5 || ACC == 2)>(args.items[idx], bx);
+}
+
+// the same kernel behind the small argument block of a tick of at most kMaxSmallItems pairs
+__global__ __launch_bounds__(kBlockThreads, 4) void k_tick_small(const TickArgsSmall args) {
+  int bx;
+  const int idx = tick_locate(args, bx);
+  tick_body<1, 1, false>(args.items[idx], bx);
 }
 
 // The same tick with the items in a device-resident table (uploaded in-stream before the launch): for launches with more
@@ -894,13 +911,15 @@ static TickKernel pick_tick_kernel() {
 // A tick's items are at different pyramid levels: the two-dimensional grid (blocks of the largest item x items) launches
 // mostly blocks that return at once, and the dispatcher starts only ~4 of them per nanosecond.  When more than half of the
 // grid would be such blocks the launch goes out one-dimensional with every item's blocks back to back.
-int tick_args_layout(TickArgs &args, int max_blocks) {
+template <class Args>
+static int tick_args_layout_impl(Args &args, int max_blocks) {
+  constexpr int kSlots = (int)(sizeof(args.group_first) / sizeof(args.group_first[0]));
   unsigned groups = 0;
   for (int i = 0; i < args.n_items; ++i) {
     args.group_first[i] = (uint16_t)groups;
     groups += ((unsigned)args.items[i].res_phys + args.items[i].ll_blocks + 7u) >> 3;
   }
-  for (int i = args.n_items; i < kMaxItemsPerLaunch + 4; ++i) args.group_first[i] = (uint16_t)groups;
+  for (int i = args.n_items; i < kSlots; ++i) args.group_first[i] = (uint16_t)groups;
   const long long grid2d = (long long)((max_blocks + 7) & ~7) * args.n_items;
   static int mode = -1;  // DVO_AMD_COMPACT_GRID=0 / 1 forces a layout (tuning)
   if (mode < 0) {
@@ -909,6 +928,25 @@ int tick_args_layout(TickArgs &args, int max_blocks) {
   }
   args.compact = groups > 0 && groups < 65536 && (mode == 1 || (mode == 2 && 2ll * 8 * groups < grid2d)) ? 1 : 0;
   return (int)(groups * 8);
+}
+int tick_args_layout(TickArgs &args, int max_blocks) { return tick_args_layout_impl(args, max_blocks); }
+int tick_args_layout(TickArgsSmall &args, int max_blocks) { return tick_args_layout_impl(args, max_blocks); }
+
+hipError_t launch_tick_small(const TickArgsSmall &args, int max_blocks, hipStream_t stream, hipEvent_t t_start, hipEvent_t t_stop) {
+  (void)pick_tick_kernel();  // reads the environment switches
+  if (g_acc_mode != 1 || g_occ != 4 || g_reduce_mode == 0) return hipErrorNotSupported;
+  if (args.n_items <= 0 || max_blocks <= 0) return hipSuccess;
+  dim3 grid((unsigned)((max_blocks + 7) & ~7), (unsigned)args.n_items, 1);
+  if (args.compact) grid = dim3((unsigned)args.group_first[args.n_items] * 8u, 1, 1);
+  if (t_start && t_stop) {
+    void *kargs[] = {const_cast<TickArgsSmall *>(&args)};
+    const hipError_t e = hipExtLaunchKernel(reinterpret_cast<const void *>(&k_tick_small), grid, dim3(kBlockThreads), kargs, 0, stream,
+                                            t_start, t_stop, 0);
+    if (e != hipSuccess) return e;
+  } else {
+    hipLaunchKernelGGL(k_tick_small, grid, dim3(kBlockThreads), 0, stream, args);
+  }
+  return hipGetLastError();
 }
 
 hipError_t launch_tick(const TickArgs &args, int max_blocks, hipStream_t stream, hipEvent_t t_start, hipEvent_t t_stop) {
@@ -989,7 +1027,7 @@ __device__ __forceinline__ SegRec seg_combine(const SegRec &a, const SegRec &b) 
 __device__ unsigned long long g_fin_stamps[8];
 #define DVO_FIN_STAMP(i)                                                                  \
   do {                                                                                    \
-    if (args.pad == 0x57A3 && blockIdx.x == 0 && threadIdx.x == 0) g_fin_stamps[i] = __builtin_amdgcn_s_memtime(); \
+    if (stamps && threadIdx.x == 0) g_fin_stamps[i] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 
 
@@ -1049,16 +1087,8 @@ __device__ bool exchange_records(const ExchangeArgs &a, const unsigned *own_reco
 // residual / weight) left to right and locates the log-likelihood cut; waves 1.. sum the 87 moments and the
 // log-likelihood partials in fp64 with 16-byte loads, eight in flight per thread.  Two block barriers in all; the record is
 // assembled in LDS and pushed to the pinned host buffer as self-validating 16-byte pieces (FinWire): no fence, no ready word.
-__global__ __launch_bounds__(kFinThreads) void k_finalize(const FinArgs args) {
-  FinItem it;
-  if (args.table) {  // more items than the argument block holds: the item comes from the table uploaded with the tick's items
-    const DVO_CONST FinItem *p = (const DVO_CONST FinItem *)args.table + blockIdx.x;
-    it.records = p->records, it.n_blocks = p->n_blocks, it.block_first = p->block_first;
-    it.n_ll_blocks = p->n_ll_blocks, it.ll_first = p->ll_first, it.ll_partials = p->ll_partials;
-    it.seg_prefix_out = p->seg_prefix_out, it.out = p->out, it.out_dev = p->out_dev, it.seq = p->seq, it.pad = p->pad;
-  } else {
-    it = args.items[blockIdx.x];
-  }
+// One block reduces one item (see above); `exchange`: the tile-sharded pair's one-hop exchange instead of the hand-off to the host.
+__device__ __forceinline__ void finalize_block(const FinItem &it, const bool stamps, const ExchangeArgs *exchange, const unsigned xseq) {
   const int t = threadIdx.x;
   __shared__ double sh_acc[kFinChunks][kFinCols];
   __shared__ SegRec sh_seg[kFinSegThreads];
@@ -1220,20 +1250,20 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const FinArgs args) {
   DVO_FIN_STAMP(2);
 
   // ---- tile-sharded pair: the record goes to the peers instead, theirs come back to the host (see exchange_records)
-  if (args.exchange && blockIdx.x == 0) {
+  if (exchange && blockIdx.x == 0) {
     __shared__ int sh_bad;
     if (t == 0) sh_bad = 0;
     __syncthreads();
-    const DVO_CONST ExchangeArgs *xp = (const DVO_CONST ExchangeArgs *)args.exchange;
+    const DVO_CONST ExchangeArgs *xp = (const DVO_CONST ExchangeArgs *)exchange;
     ExchangeArgs xa;
 #pragma unroll
     for (int i = 0; i < kMaxExchangeRanks; ++i) xa.peers[i] = xp->peers[i];
     xa.local = xp->local, xa.host_records = xp->host_records, xa.host_seq = xp->host_seq;
     xa.n_ranks = xp->n_ranks, xa.rank = xp->rank, xa.timeout_ticks = xp->timeout_ticks;
-    if (!exchange_records(xa, reinterpret_cast<const unsigned *>(&sh_out), args.xseq, t >> 6, kFinThreads / kWave, t & (kWave - 1)))
+    if (!exchange_records(xa, reinterpret_cast<const unsigned *>(&sh_out), xseq, t >> 6, kFinThreads / kWave, t & (kWave - 1)))
       atomicOr(&sh_bad, 1);
     __syncthreads();
-    if (t == 0 && sh_bad) __hip_atomic_store(xa.host_seq, args.xseq | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (t == 0 && sh_bad) __hip_atomic_store(xa.host_seq, xseq | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }
   // ---- publish: every piece of the record goes to the pinned host buffer with the tick's sequence number inside it, in one
@@ -1245,8 +1275,32 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const FinArgs args) {
   DVO_FIN_STAMP(3);
 }
 
+__global__ __launch_bounds__(kFinThreads) void k_finalize(const FinArgs args) {
+  FinItem it;
+  if (args.table) {  // more items than the argument block holds: the item comes from the table uploaded with the tick's items
+    const DVO_CONST FinItem *p = (const DVO_CONST FinItem *)args.table + blockIdx.x;
+    it.records = p->records, it.n_blocks = p->n_blocks, it.block_first = p->block_first;
+    it.n_ll_blocks = p->n_ll_blocks, it.ll_first = p->ll_first, it.ll_partials = p->ll_partials;
+    it.seg_prefix_out = p->seg_prefix_out, it.out = p->out, it.out_dev = p->out_dev, it.seq = p->seq, it.pad = p->pad;
+  } else {
+    it = args.items[blockIdx.x];
+  }
+  finalize_block(it, args.pad == 0x57A3 && blockIdx.x == 0, blockIdx.x == 0 ? args.exchange : nullptr, args.xseq);
+}
+
+// the same behind the small argument block of a tick of at most kMaxSmallItems pairs
+__global__ __launch_bounds__(kFinThreads) void k_finalize_small(const FinArgsSmall args) {
+  finalize_block(args.items[blockIdx.x], args.pad == 0x57A3 && blockIdx.x == 0, nullptr, 0u);
+}
+
 hipError_t read_finalize_stamps(unsigned long long out[8]) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fin_stamps), sizeof(unsigned long long) * 8);
+}
+
+hipError_t launch_finalize_small(const FinArgsSmall &args, hipStream_t stream) {
+  if (args.n_items <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_finalize_small, dim3((unsigned)args.n_items), dim3(kFinThreads), 0, stream, args);
+  return hipGetLastError();
 }
 
 hipError_t launch_finalize(const FinArgs &args, hipStream_t stream) {

@@ -488,6 +488,7 @@ struct dvo_amd_context {
                                                          // (DVO_AMD_STEPS_AT="a,b,c,d", read when the context is created)
   int fault_slot_alloc = -1;           // DVO_AMD_FAULT_SLOT_ALLOC: fail the allocation of this slot once (tests of the error path)
   bool fin_stamps = false;             // DVO_AMD_FIN_STAMPS=1: k_finalize records phase stamps (diagnostic)
+  bool small_args = true;              // ticks of at most kMaxSmallItems pairs use the small argument blocks (DVO_AMD_SMALL_ARGS=0: never)
   bool poll = true;                    // wait for a tick by polling the records' sequence words instead of hipStreamSynchronize
   // optional kernel timing (bench.py roofline section)
   bool timing = false;
@@ -1197,6 +1198,24 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
       ctx->tick_log_pending.insert(ctx->tick_log_pending.end(), rec, rec + kTickLogFields);
     }
     hipEvent_t t0 = ctx->timing ? ctx->events[ev].first : nullptr, t1 = ctx->timing ? ctx->events[ev].second : nullptr;
+    if (ctx->small_args && !use_table && n_launch == 1 && n_here <= kMaxSmallItems) {
+      // a single match() or the two-pair front-end step: the same two kernels behind argument blocks a tenth the size
+      TickArgsSmall ts;
+      ts.n_items = n_here, ts.compact = 0;
+      for (int i = 0; i < kMaxSmallItems; ++i) ts.items[i] = ta.items[i < n_here ? i : 0];
+      (void)tick_args_layout(ts, max_blocks);
+      const hipError_t es = launch_tick_small(ts, max_blocks, st, t0, t1);
+      if (es == hipSuccess) {
+        FinArgsSmall fs;
+        fs.n_items = n_here, fs.pad = ctx->fin_stamps ? 0x57A3 : 0;
+        for (int i = 0; i < kMaxSmallItems; ++i) fs.items[i] = fin_items[first + (size_t)(i < n_here ? i : 0)];
+        const hipError_t ef = launch_finalize_small(fs, st);
+        if (ef != hipSuccess) return fail_hip("launch_finalize", ef);
+        continue;
+      }
+      if (es != hipErrorNotSupported) return fail_hip("launch_tick", es);
+      (void)hipGetLastError();  // another k_tick variant was selected by an environment switch: the full-size launch below
+    }
     if (!use_table) (void)tick_args_layout(ta, max_blocks);
     hipError_t e = use_table ? launch_tick_table(reinterpret_cast<const TickItem *>(ctx->item_dev + stream_slot * kTableBytes), n_here, max_blocks, st, t0, t1)
                              : launch_tick(ta, max_blocks, st, t0, t1);
@@ -1536,6 +1555,8 @@ int dvo_amd_context_create(int device, const dvo_amd_config *cfg, dvo_amd_contex
   ctx->poll = !(pe && pe[0] == '0');
   const char *fs = getenv("DVO_AMD_FIN_STAMPS");
   ctx->fin_stamps = fs && fs[0] == '1';
+  const char *sa = getenv("DVO_AMD_SMALL_ARGS");
+  ctx->small_args = !(sa && sa[0] == '0');
   const char *hp = getenv("DVO_AMD_HOST_PROF");
   ctx->host_prof = hp && hp[0] == '1';
   if (const char *sl = getenv("DVO_AMD_SPEC_LEVELS")) ctx->spec_levels = sl[0] == '1' ? 1 : 0;

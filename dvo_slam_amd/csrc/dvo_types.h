@@ -159,6 +159,22 @@ struct FinArgs {
 };
 static_assert(sizeof(FinArgs) <= 3800, "kernel argument block too large");
 
+// A tick of at most eight pairs (a single match(), the two-pair front-end step, small batches) goes out with argument blocks a tenth the size:
+// the runtime copies the kernel arguments into device-visible memory at every launch, and both launches sit on the critical
+// path of a single-pair tick.
+constexpr int kMaxSmallItems = 8;
+struct TickArgsSmall {
+  int n_items;
+  int compact;
+  uint16_t group_first[kMaxSmallItems + 4];
+  TickItem items[kMaxSmallItems];
+};
+struct FinArgsSmall {
+  int n_items;
+  int pad;  // 0x57A3: record phase stamps (diagnostic)
+  FinItem items[kMaxSmallItems];
+};
+
 // ---- launch wrappers (dvo_kernels.hip) ----------------------------------------------------------------------------
 // t_start / t_stop (both or neither): events that receive the begin / end time stamps of this dispatch itself
 // (hipExtLaunchKernelGGL), i.e. the kernel's own duration without the launch latency an event pair around it would add
@@ -167,6 +183,12 @@ hipError_t launch_tick(const TickArgs &args, int max_blocks, hipStream_t stream,
                        hipEvent_t t_stop = nullptr);
 // fills group_first / compact from the items' block counts; returns the number of blocks of the compact grid
 int tick_args_layout(TickArgs &args, int max_blocks);
+int tick_args_layout(TickArgsSmall &args, int max_blocks);
+// the same kernels with the small argument blocks (only the default k_tick variant: returns hipErrorNotSupported when an
+// environment switch selected another one, and the caller falls back to the full-size launch)
+hipError_t launch_tick_small(const TickArgsSmall &args, int max_blocks, hipStream_t stream, hipEvent_t t_start = nullptr,
+                             hipEvent_t t_stop = nullptr);
+hipError_t launch_finalize_small(const FinArgsSmall &args, hipStream_t stream);
 // the same kernel reading its items from a device-resident table (more pairs per launch than the argument block holds)
 constexpr int kMaxTableItems = 288;
 hipError_t launch_tick_table(const TickItem *items_dev, int n_items, int max_blocks, hipStream_t stream,
