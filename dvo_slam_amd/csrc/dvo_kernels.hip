@@ -994,7 +994,13 @@ constexpr int kFinSegThreads = 64;    // wave 0: the ordered part of the records
 constexpr int kFinAccFirst = 64;      // threads [64, ...): row-chunks x 24 groups of 4 columns (waves 1.. sum the moments)
 constexpr int kFinCols = 96;
 constexpr int kFinCol4 = kFinCols / 4;
-constexpr int kFinChunks = (kFinThreads - kFinAccFirst) / kFinCol4;
+constexpr int kFinThreadsBatch = 256;  // the launch of a tick of many pairs: half the block runs 2 % more pairs/s next to other
+                                       // streams' k_tick blocks (a small tick keeps 512 threads: its level-0 reduce is bandwidth)
+template <int NT>
+struct FinGeometry {
+  static constexpr int kChunks = (NT - kFinAccFirst) / kFinCol4;
+  static_assert(kFinAccFirst + kNumAcc + 1 <= NT && kChunks >= 2, "the block holds the output threads and at least two row chunks");
+};
 
 struct SegRec {
   int c;
@@ -1088,7 +1094,9 @@ __device__ bool exchange_records(const ExchangeArgs &a, const unsigned *own_reco
 // log-likelihood partials in fp64 with 16-byte loads, eight in flight per thread.  Two block barriers in all; the record is
 // assembled in LDS and pushed to the pinned host buffer as self-validating 16-byte pieces (FinWire): no fence, no ready word.
 // One block reduces one item (see above); `exchange`: the tile-sharded pair's one-hop exchange instead of the hand-off to the host.
+template <int NT>
 __device__ __forceinline__ void finalize_block(const FinItem &it, const bool stamps, const ExchangeArgs *exchange, const unsigned xseq) {
+  constexpr int kFinChunks = FinGeometry<NT>::kChunks;
   const int t = threadIdx.x;
   __shared__ double sh_acc[kFinChunks][kFinCols];
   __shared__ SegRec sh_seg[kFinSegThreads];
@@ -1260,7 +1268,7 @@ __device__ __forceinline__ void finalize_block(const FinItem &it, const bool sta
     for (int i = 0; i < kMaxExchangeRanks; ++i) xa.peers[i] = xp->peers[i];
     xa.local = xp->local, xa.host_records = xp->host_records, xa.host_seq = xp->host_seq;
     xa.n_ranks = xp->n_ranks, xa.rank = xp->rank, xa.timeout_ticks = xp->timeout_ticks;
-    if (!exchange_records(xa, reinterpret_cast<const unsigned *>(&sh_out), xseq, t >> 6, kFinThreads / kWave, t & (kWave - 1)))
+    if (!exchange_records(xa, reinterpret_cast<const unsigned *>(&sh_out), xseq, t >> 6, NT / kWave, t & (kWave - 1)))
       atomicOr(&sh_bad, 1);
     __syncthreads();
     if (t == 0 && sh_bad) __hip_atomic_store(xa.host_seq, xseq | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1275,7 +1283,8 @@ __device__ __forceinline__ void finalize_block(const FinItem &it, const bool sta
   DVO_FIN_STAMP(3);
 }
 
-__global__ __launch_bounds__(kFinThreads) void k_finalize(const FinArgs args) {
+template <int NT>
+__global__ __launch_bounds__(NT) void k_finalize(const FinArgs args) {
   FinItem it;
   if (args.table) {  // more items than the argument block holds: the item comes from the table uploaded with the tick's items
     const DVO_CONST FinItem *p = (const DVO_CONST FinItem *)args.table + blockIdx.x;
@@ -1285,12 +1294,12 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const FinArgs args) {
   } else {
     it = args.items[blockIdx.x];
   }
-  finalize_block(it, args.pad == 0x57A3 && blockIdx.x == 0, blockIdx.x == 0 ? args.exchange : nullptr, args.xseq);
+  finalize_block<NT>(it, args.pad == 0x57A3 && blockIdx.x == 0, blockIdx.x == 0 ? args.exchange : nullptr, args.xseq);
 }
 
 // the same behind the small argument block of a tick of at most kMaxSmallItems pairs
 __global__ __launch_bounds__(kFinThreads) void k_finalize_small(const FinArgsSmall args) {
-  finalize_block(args.items[blockIdx.x], args.pad == 0x57A3 && blockIdx.x == 0, nullptr, 0u);
+  finalize_block<kFinThreads>(args.items[blockIdx.x], args.pad == 0x57A3 && blockIdx.x == 0, nullptr, 0u);
 }
 
 hipError_t read_finalize_stamps(unsigned long long out[8]) {
@@ -1305,7 +1314,10 @@ hipError_t launch_finalize_small(const FinArgsSmall &args, hipStream_t stream) {
 
 hipError_t launch_finalize(const FinArgs &args, hipStream_t stream) {
   if (args.n_items <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_finalize, dim3((unsigned)args.n_items), dim3(kFinThreads), 0, stream, args);
+  if (args.n_items > kMaxSmallItems && !args.exchange)
+    hipLaunchKernelGGL(k_finalize<kFinThreadsBatch>, dim3((unsigned)args.n_items), dim3(kFinThreadsBatch), 0, stream, args);
+  else
+    hipLaunchKernelGGL(k_finalize<kFinThreads>, dim3((unsigned)args.n_items), dim3(kFinThreads), 0, stream, args);
   return hipGetLastError();
 }
 
