@@ -774,6 +774,30 @@ def test_item_table_launches_give_the_same_results(capi, synth, pair640, monkeyp
         assert synth.pose_error((fwd if i % 2 else bwd).Transformation, T) <= POSE_TOL
 
 
+def test_small_argument_blocks_change_nothing(capi, synth, pair640, monkeypatch):
+    """Ticks of at most eight pairs are launched behind small kernel-argument blocks (k_tick_small / k_finalize_small, the same
+    device code): every result, statistics included, is bit for bit the one of the full-size launch; a nine-pair batch (full
+    size, 256-thread reduce) agrees with it within the summation-order tolerance."""
+    monkeypatch.setenv("DVO_AMD_SMALL_ARGS", "0")
+    full = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0))
+    monkeypatch.delenv("DVO_AMD_SMALL_ARGS")
+    small = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0))
+    a, b = full.match(pair640["gr"], pair640["gc"]), small.match(pair640["gr"], pair640["gc"])
+    assert np.array_equal(a.Transformation, b.Transformation) and np.array_equal(a.Information, b.Information)
+    assert a.LogLikelihood == b.LogLikelihood and len(a.Levels) == len(b.Levels)
+    for la, lb in zip(a.Levels, b.Levels):
+        assert la["TerminationCriterion"] == lb["TerminationCriterion"] and len(la["Iterations"]) == len(lb["Iterations"])
+        for ia, ib in zip(la["Iterations"], lb["Iterations"]):
+            assert ia["ValidConstraints"] == ib["ValidConstraints"]
+            assert ia["TDistributionLogLikelihood"] == ib["TDistributionLogLikelihood"]
+            assert np.array_equal(ia["EstimateIncrement"], ib["EstimateIncrement"])
+    refs, curs = [pair640["gr"], pair640["gc"]] * 4, [pair640["gc"], pair640["gr"]] * 4
+    for x, y in zip(full.match_batch(refs, curs, stats=False), small.match_batch(refs, curs, stats=False)):  # eight pairs
+        assert np.array_equal(x.Transformation, y.Transformation)
+    nine = small.match_batch(refs + [pair640["gr"]], curs + [pair640["gc"]], stats=False)
+    assert all(synth.pose_error(a.Transformation, r.Transformation) <= POSE_TOL for r in nine[0::2])
+
+
 def test_pyramid_from_device_memory(capi, synth, pair640):
     torch = pytest.importorskip("torch")
     (Ir, Zr), (Ic, Zc) = pair640["frames"]
