@@ -165,9 +165,9 @@ F64_SCALE_RTOL, F64_A_RTOL, F64_B_CS, F64_LL_RTOL = 1e-6, 1e-6, 5e-7, 1e-6  # me
 REF_SCALE_RTOL, REF_A_RTOL, REF_B_CS, REF_LL_RTOL = 1e-3, 1e-3, 3e-5, 2e-6    # measured: 1.9e-4, 2.0e-4, 8.6e-6, 0
 
 
-@pytest.mark.parametrize("case", ["640x480 levels 3..0", "640x480 swapped", "336x250 levels 2..0"])
+@pytest.mark.parametrize("case", ["640x480 levels 3..0", "640x480 swapped", "336x250 levels 2..0", "1280x960 levels 4..0"])
 def test_every_iteration_of_a_match_teacher_forced(capi, orc, synth, pair640, case, capsys):
-    """Every Gauss-Newton iteration of a full oracle match() (BASELINE config 2 and two more), replayed stage-wise on the GPU
+    """Every Gauss-Newton iteration of a full oracle match() (BASELINE configs 2 and 3 and two more), replayed stage-wise on the GPU
     from the ORACLE's pose and previous precision of that iteration (dense_tracking.cpp:271-347 per iteration).  No pose drift
     between the two sides, so the weighted iterations (k >= 1) are held to the same tolerances as iteration 0:
     valid-constraint count exact; scale, normal equations and likelihood against a float64 restatement at fp32-epsilon level
@@ -177,12 +177,22 @@ def test_every_iteration_of_a_match_teacher_forced(capi, orc, synth, pair640, ca
         if "swapped" in case:
             gr, gc, orr, occ = gc, gr, occ, orr
         first = 3
+    elif case.startswith("1280x960"):
+        (Ir, Zr), (Ic, Zc), _ = synth.make_pair(1280, 960)
+        K = synth.intrinsics_for(1280, 960)
+        gr, orr = _pyramids(capi, orc, (Ir, Zr), K, 5)
+        gc, occ = _pyramids(capi, orc, (Ic, Zc), K, 5)
+        first = 4
     else:
         (Ir, Zr), (Ic, Zc), _ = synth.make_pair(336, 250, xi_gt=synth.XI_GT_PAIR * 0.4)
         K = synth.intrinsics_for(336, 250)
         gr, gc = capi.RgbdImagePyramid(Ir, Zr, K, 3), capi.RgbdImagePyramid(Ic, Zc, K, 3)
         orr, occ = orc.Pyramid(Ir, Zr, K, 3), orc.Pyramid(Ic, Zc, K, 3)
         first = 2
+    # The reference's sequential fp32 sums drift with the number of terms (840 000 at level 0 of 1280x960): against the float64
+    # restatement the oracle itself is off by 6.1e-4 (scale), 2.1e-3 (A), 1.2e-4 (b) there, the GPU by 1e-7 as everywhere.
+    REF_SCALE_RTOL, REF_A_RTOL, REF_B_CS = ((2e-3, 6e-3, 4e-4) if case.startswith("1280x960") else
+                                            (globals()["REF_SCALE_RTOL"], globals()["REF_A_RTOL"], globals()["REF_B_CS"]))
     trk = capi.DenseTracker(capi.Config(FirstLevel=first, LastLevel=0))
     ro = orc.match(orc.default_config(first_level=first, last_level=0, rcp_mode=orc.RCP_EXACT), orr, occ)
     n_checked = n_weighted = 0
