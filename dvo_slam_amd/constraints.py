@@ -8,6 +8,7 @@ There is no CPU path.
 """
 from __future__ import annotations
 
+import time
 import ctypes as C
 
 import numpy as np
@@ -244,9 +245,11 @@ class ConstraintProposalValidator:
             cpr[i].reference, cpr[i].current = index[id(p.Reference)], index[id(p.Current)]
             cpr[i].initial_transformation = _colmajor(p.InitialTransformation)
         n_out = C.c_int()
-        capi._check(_lib().dvo_amd_validate_proposals(self.tracker._h, len(keyframes), ckf, len(self.stages), cst,
-                                                      len(proposals), cpr, C.byref(n_out), self.max_in_flight),
-                    "dvo_amd_validate_proposals")
+        t0 = time.perf_counter()
+        status = _lib().dvo_amd_validate_proposals(self.tracker._h, len(keyframes), ckf, len(self.stages), cst,
+                                                   len(proposals), cpr, C.byref(n_out), self.max_in_flight)
+        self.native_ms = (time.perf_counter() - t0) * 1e3  # the library call alone, without this binding's marshalling
+        capi._check(status, "dvo_amd_validate_proposals")
         out = []
         for i in range(n_out.value):
             c = cpr[i]
