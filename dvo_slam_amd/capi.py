@@ -28,7 +28,7 @@ EXPORTS = [
     "dvo_amd_residuals", "dvo_amd_error_image", "dvo_amd_kernel_timing", "dvo_amd_se3_exp", "dvo_amd_se3_log",
     "dvo_amd_solve6", "dvo_amd_bench_residual_pass", "dvo_amd_match_many",
     "dvo_amd_debug_finalize_stamps", "dvo_amd_comm_unique_id", "dvo_amd_comm_create", "dvo_amd_comm_destroy",
-    "dvo_amd_match_sharded", "dvo_amd_match_banded", "dvo_amd_debug_combine_bands", "dvo_amd_debug_wire_layout", "dvo_amd_debug_take_wire", "dvo_amd_pyramid_create_raw",
+    "dvo_amd_match_sharded", "dvo_amd_match_banded", "dvo_amd_context_device", "dvo_amd_debug_combine_bands", "dvo_amd_debug_wire_layout", "dvo_amd_debug_take_wire", "dvo_amd_pyramid_create_raw",
     "dvo_amd_default_validator_stages", "dvo_amd_proposals_for_candidates", "dvo_amd_validate_proposals",
     "dvo_amd_track_frame", "dvo_amd_png_info", "dvo_amd_png_read_bgr8", "dvo_amd_png_read_gray16",
     "dvo_amd_format_trajectory_line", "dvo_amd_debug_tick_log", "dvo_amd_debug_iteration", "dvo_amd_match_selection", "dvo_amd_bench_residual_pass_pairs",

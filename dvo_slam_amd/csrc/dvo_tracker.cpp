@@ -1613,6 +1613,12 @@ int dvo_amd_configure(dvo_amd_context *ctx, const dvo_amd_config *cfg) {
   return DVO_AMD_OK;
 }
 
+int dvo_amd_context_device(const dvo_amd_context *ctx, int *device) {
+  if (!ctx || !device) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  *device = ctx->device;
+  return DVO_AMD_OK;
+}
+
 int dvo_amd_get_config(const dvo_amd_context *ctx, dvo_amd_config *cfg) {
   if (!ctx || !cfg) return DVO_AMD_ERR_INVALID_ARGUMENT;
   *cfg = ctx->cfg;

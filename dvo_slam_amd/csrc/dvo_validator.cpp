@@ -5,8 +5,12 @@
 // hands one proposal at a time to a per-thread validator (keyframe_graph.cpp:525-593); here a stage aligns ALL of its
 // proposals, including the cross-validation inverses, in one dvo_amd_match_many() call, so the GPU sees full launches.
 // Only the public C ABI of the tracker is used: no kernels, no device memory in this file.
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -206,6 +210,45 @@ int dvo_amd_proposals_for_candidates(const dvo_amd_keyframe *keyframes, int keyf
   return DVO_AMD_OK;
 }
 
+namespace {
+// worker contexts of the validator, per device, kept for the life of the process
+struct WorkerPool {
+  std::mutex mu;
+  std::vector<dvo_amd_context *> idle[16];
+};
+WorkerPool &worker_pool() {
+  static WorkerPool *p = new WorkerPool;  // never destroyed: contexts may outlive static destruction order
+  return *p;
+}
+int worker_acquire(int device, const dvo_amd_config *cfg, dvo_amd_context **out) {
+  *out = nullptr;
+  if (device < 0 || device >= 16) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  {
+    std::lock_guard<std::mutex> lock(worker_pool().mu);
+    std::vector<dvo_amd_context *> &idle = worker_pool().idle[device];
+    if (!idle.empty()) {
+      *out = idle.back();
+      idle.pop_back();
+    }
+  }
+  if (*out) return dvo_amd_configure(*out, cfg);
+  return dvo_amd_context_create(device, cfg, out);
+}
+void worker_release(int device, dvo_amd_context *c) {
+  std::lock_guard<std::mutex> lock(worker_pool().mu);
+  worker_pool().idle[device].push_back(c);
+}
+int validator_threads() {
+  static int n = -1;
+  if (n < 0) {
+    const char *e = getenv("DVO_AMD_VALIDATOR_THREADS");
+    n = e ? atoi(e) : 3;
+    n = n < 1 ? 1 : (n > 8 ? 8 : n);
+  }
+  return n;
+}
+}  // namespace
+
 int dvo_amd_validate_proposals(dvo_amd_context *ctx, int n_keyframes, const dvo_amd_keyframe *keyframes, int n_stages,
                                const dvo_amd_validator_stage *stages, int n_proposals,
                                dvo_amd_constraint_proposal *proposals, int *n_out, int max_in_flight) {
@@ -284,7 +327,36 @@ int dvo_amd_validate_proposals(dvo_amd_context *ctx, int n_keyframes, const dvo_
         results[i].iterations = &its[i * (size_t)its_per_pair];
         results[i].iterations_capacity = its_per_pair;
       }
-      rc = dvo_amd_match_many(ctx, (int)n, refs.data(), curs.data(), inits.data(), results.data(), max_in_flight);
+      // The reference deals the proposals over TBB workers (keyframe_graph.cpp:576-593); one host thread advances ~36 pairs
+      // per 20 us, which for a stage of many short alignments is slower than the GPU: a large stage is split over a few
+      // worker contexts (own stream and scratch each, kept between calls), the caller's thread taking the first share.
+      const int n_workers = (int)std::min<size_t>((size_t)validator_threads(), n / 24);
+      if (n_workers <= 1) {
+        rc = dvo_amd_match_many(ctx, (int)n, refs.data(), curs.data(), inits.data(), results.data(), max_in_flight);
+      } else {
+        int device = 0;
+        rc = dvo_amd_context_device(ctx, &device);
+        if (rc) break;
+        std::vector<dvo_amd_context *> wctx((size_t)n_workers, nullptr);
+        std::vector<int> wrc((size_t)n_workers, DVO_AMD_OK);
+        wctx[0] = ctx;
+        for (int w = 1; w < n_workers && rc == DVO_AMD_OK; ++w) rc = worker_acquire(device, &stage.tracking_config, &wctx[(size_t)w]);
+        if (rc == DVO_AMD_OK) {
+          auto share = [&](int w) {
+            const size_t lo = n * (size_t)w / (size_t)n_workers, hi = n * (size_t)(w + 1) / (size_t)n_workers;
+            wrc[(size_t)w] = dvo_amd_match_many(wctx[(size_t)w], (int)(hi - lo), refs.data() + lo, curs.data() + lo, inits.data() + 16 * lo,
+                                                results.data() + lo, max_in_flight);
+          };
+          std::vector<std::thread> threads;
+          for (int w = 1; w < n_workers; ++w) threads.emplace_back(share, w);
+          share(0);
+          for (std::thread &t : threads) t.join();
+          for (int w = 0; w < n_workers; ++w)
+            if (wrc[(size_t)w] != DVO_AMD_OK && rc == DVO_AMD_OK) rc = wrc[(size_t)w];
+        }
+        for (int w = 1; w < n_workers; ++w)
+          if (wctx[(size_t)w]) worker_release(device, wctx[(size_t)w]);
+      }
       if (rc) break;
       for (size_t i = 0; i < n; ++i) {
         last[i] = last_level_of(results[i]);

@@ -124,6 +124,8 @@ void dvo_amd_default_config(dvo_amd_config *cfg);
 /* DenseTracker::DenseTracker(cfg) / configure(), dense_tracking.cpp:54-97 */
 int dvo_amd_context_create(int device, const dvo_amd_config *cfg, dvo_amd_context **out);
 void dvo_amd_context_destroy(dvo_amd_context *ctx);
+/* the HIP device the context was created on */
+int dvo_amd_context_device(const dvo_amd_context *ctx, int *device);
 int dvo_amd_configure(dvo_amd_context *ctx, const dvo_amd_config *cfg);
 int dvo_amd_get_config(const dvo_amd_context *ctx, dvo_amd_config *cfg);
 
@@ -301,7 +303,9 @@ void dvo_amd_default_validator_stages(const dvo_amd_config *frontend_cfg, double
 int dvo_amd_proposals_for_candidates(const dvo_amd_keyframe *keyframes, int keyframe, int n_candidates, const int *candidates,
                                      dvo_amd_constraint_proposal *proposals);
 /* validate(): proposals[0..n_proposals) in, survivors compacted to the front in the reference's order, *n_out of them.
- * The context's tracker configuration is restored before returning.  max_in_flight as in dvo_amd_match_many. */
+ * The context's tracker configuration is restored before returning.  max_in_flight as in dvo_amd_match_many.  A stage of many
+ * alignments is dealt over a few worker contexts of the library's own (same device, created on first use, own host threads for
+ * the duration of the call: keyframe_graph.cpp:576-593 deals the proposals over TBB workers the same way). */
 int dvo_amd_validate_proposals(dvo_amd_context *ctx, int n_keyframes, const dvo_amd_keyframe *keyframes, int n_stages,
                                const dvo_amd_validator_stage *stages, int n_proposals,
                                dvo_amd_constraint_proposal *proposals, int *n_out, int max_in_flight);
