@@ -60,6 +60,10 @@ while time.time() < t_end and not errors:
     t_round_end = time.time() + 5.0
     for x in ths:
         x.start()
+    while any(x.is_alive() for x in ths):  # a progress line every half minute (a silent run is taken to be hung)
+        ths[0].join(timeout=30.0)
+        with lock:
+            print(f"[{time.time() - t0:6.1f} s] calls {stats['calls']}, pairs {stats['pairs']}, worst {stats['worst']:.2e}", flush=True)
     for x in ths:
         x.join()
     round_ += 1
