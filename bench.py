@@ -2,9 +2,11 @@
 """bench.py -- frame-pairs/s of the dense RGB-D alignment hot path on MI355X (BASELINE.json metric).
 
 A "step" = one pass over B independent 640x480 frame pairs (4-level coarse-to-fine Gauss-Newton,
-FirstLevel 3 -> LastLevel 0, reference defaults otherwise) aligned on ONE GPU through the C ABI
-(dvo_amd_match_many): T host threads, each with its own tracker, work through an equal share of the batch with a fixed
-number of pairs resident at a time.  Pyramids of all frames are built beforehand and stay resident in HBM, as
+FirstLevel 3 -> LastLevel 0, reference defaults otherwise) aligned on ONE GPU through the C ABI: T host threads, each with
+its own tracker, work through an equal share of the batch with a fixed number of pairs resident at a time.  A thread hands
+its tracker the next step's share (dvo_amd_match_submit) before it collects the current one (dvo_amd_match_wait), so a
+tracker does not run dry between steps -- the shape of the loop-closure validator fed proposal list after proposal list
+(keyframe_graph.cpp:434-498, 576-593); --drain-between-steps gives the old one-call-per-step behaviour (dvo_amd_match_many).  Pyramids of all frames are built beforehand and stay resident in HBM, as
 LocalTracker::update pre-builds them (dvo_slam/src/local_tracker.cpp:163-169), so the timed region is
 DenseTracker::match only.  With N GPUs every rank aligns its own B pairs (independent units, no data-path
 collective): weak scaling, value = N * B * K / max-over-ranks(time).
@@ -63,6 +65,9 @@ def parse():
                     help="pairs resident per tracker at a time (0 = the whole share in lock step)")
     ap.add_argument("--threads", type=int, default=8,
                     help="host threads per GPU, each with its own tracker (HIP stream) and an equal share of the batch")
+    ap.add_argument("--drain-between-steps", action="store_true",
+                    help="one dvo_amd_match_many call per step and thread (the tracker drains to empty at the end of every step) "
+                         "instead of submitting the next step's share before waiting for the current one")
     ap.add_argument("--no-stats", action="store_true",
                     help="drop the per-iteration statistics (Result.Statistics) in the timed region; by default they are "
                          "delivered, as the reference's callers read them (keyframe_tracker.cpp:167, "
@@ -197,24 +202,39 @@ def main():
     distinct_pairs = len(set(idx))
     shares = sharding.split_for_threads(list(range(B)), T)
     with_stats = not args.no_stats
-    # result structs (+ per-iteration statistics arrays) are allocated once per host thread and refilled every step
-    result_bufs = [trackers[t].alloc_results(len(shares[t])) if with_stats else None for t in range(T)]
+    # result structs (+ per-iteration statistics arrays) are allocated once per host thread (two sets: the step being
+    # collected and the step already queued behind it) and refilled every step
+    result_bufs = [[trackers[t].alloc_results(len(shares[t])) for _ in range(2)] if with_stats else None for t in range(T)]
+    streaming = not args.drain_between_steps
 
     def run_steps(n_steps, collect, r_list=None, c_list=None, stats=with_stats):
-        """n_steps lock-step batches of B pairs on this GPU; with T > 1 every thread drives its own stream"""
+        """n_steps batches of B pairs on this GPU; with T > 1 every thread drives its own tracker"""
         r_list, c_list = r_list or refs, c_list or curb
 
         def worker(t):
             ix = shares[t]
             r, c = [r_list[i] for i in ix], [c_list[i] for i in ix]
+
+            def tally(out):
+                collect.append((sum(o.alg_bytes for o in out), sum(o.n_residual_passes for o in out),
+                                sum(o.is_nan for o in out), sum(o.n_iterations for o in out),
+                                sum(o.alg_bytes_discarded for o in out)))
+            prev = None
             for s_ in range(n_steps):
                 ts = time.perf_counter()
-                out = trackers[t].match_batch(r, c, stats=False, in_flight=args.in_flight, raw=True,
-                                              results=result_bufs[t] if stats else None)
-                collect.append((sum(o.alg_bytes for o in out), sum(o.n_residual_passes for o in out),
-                                sum(o.is_nan for o in out), sum(o.n_iterations for o in out)))
+                bufs = result_bufs[t][s_ % 2] if stats else None
+                if streaming:
+                    # the next step's share is queued behind the current one before the current one is collected
+                    sub = trackers[t].submit(r, c, stats=False, in_flight=args.in_flight, results=bufs)
+                    if prev is not None:
+                        tally(trackers[t].wait(prev, raw=True))
+                    prev = sub
+                else:
+                    tally(trackers[t].match_batch(r, c, stats=False, in_flight=args.in_flight, raw=True, results=bufs))
                 if os.environ.get("DVO_BENCH_DEBUG"):
                     print(f"thread {t} step {s_}: {(time.perf_counter() - ts) * 1e3:.2f} ms", file=sys.stderr, flush=True)
+            if prev is not None:
+                tally(trackers[t].wait(prev, raw=True))
         if T == 1:
             worker(0)
         else:
@@ -233,6 +253,10 @@ def main():
 
     run_steps(args.prime, [])
     run_steps(args.warmup, [])
+    if os.environ.get("DVO_BENCH_MAPS"):
+        # every library of the run is mapped by now: raw-address stacks (glog under rocprofv3) can be attributed afterwards
+        with open(os.environ["DVO_BENCH_MAPS"], "w") as fh:
+            fh.write(open("/proc/self/maps").read())
     # single-pair latency (informational)
     t0 = time.perf_counter()
     n_lat = 10
@@ -252,6 +276,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     alg_bytes = sum(c[0] for c in col)
+    discarded_bytes = sum(c[4] for c in col)
     passes = sum(c[1] for c in col)
     iterations_delivered = sum(c[3] for c in col)
     if sum(c[2] for c in col):
@@ -267,7 +292,18 @@ def main():
         k_ms, k_launches = trk.kernel_timing(False)
         log = trk.tick_log()
         alg_bytes_k = sum(o.alg_bytes for o in out)
+        discarded_k = sum(o.alg_bytes_discarded for o in out)
     elapsed_local = elapsed
+    tile_shard = None
+    if world > 1 and (not args.rehearse_on_one_gpu or os.environ.get("DVO_AMD_EXCHANGE") == "peer"):
+        # (a one-GPU rehearsal can only exercise the peer exchange: RCCL refuses two ranks on one device)
+        # BASELINE config 4 from the driver's own multi-GPU command: every rank takes part (the exchange is collective)
+        del trackers[1:]
+        try:
+            tile_shard = tile_shard_measure(args, capi, synth, dist, rank, world, device, K, levels, first_level,
+                                            steps=max(2, args.steps // 4), warmup=1)
+        except Exception as exc:  # pragma: no cover - a side measurement never fails the bench line
+            tile_shard = {"error": repr(exc)}
     # MAX over ranks of the elapsed time, SUM over ranks of the pairs aligned
     elapsed, pairs = sharding.aggregate(elapsed, B * args.steps, dist,
                                         None if dist is None else ("cpu" if args.rehearse_on_one_gpu else "cuda"))
@@ -275,8 +311,11 @@ def main():
 
     if rank == 0:
         if T == 1:
-            alg_bytes_k = alg_bytes
-        achieved = alg_bytes_k / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+            alg_bytes_k, discarded_k = alg_bytes, discarded_bytes
+        # USEFUL algorithmic bytes: speculative residual passes whose iteration was rolled back are not counted
+        useful_k = alg_bytes_k - discarded_k
+        achieved = useful_k / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        useful = alg_bytes - discarded_bytes
         line = {
             "metric": "frame-pairs/s (640x480, 4-level GN align)" if W == 640 else f"frame-pairs/s ({W}x{H}, {levels}-level GN align)",
             "value": value,
@@ -298,7 +337,8 @@ def main():
                             f"({n_pyramids} pyramids, {pyramid_bytes / 2**20:.0f} MiB resident: "
                             f"{'beyond' if pyramid_bytes > 256 * 2**20 else 'inside'} the 256 MiB Infinity Cache), worked "
                             f"through by {T} host threads (one tracker / HIP stream each) with at most "
-                            f"{args.in_flight or 'all'} pairs resident per tracker, pyramids pre-built and resident in HBM, "
+                            f"{args.in_flight or 'all'} pairs resident per tracker"
+                            f"{' and the next step queued behind the current one' if streaming else ''}, pyramids pre-built and resident in HBM, "
                             f"per-iteration statistics {'delivered' if with_stats else 'dropped'}",
                 "pairs_per_step_per_gpu": B,
                 "distinct_pairs_per_step": distinct_pairs,
@@ -307,6 +347,8 @@ def main():
                 "host_threads_per_gpu": T,
                 "host_threads_pinned_to_numa_node": numa,
                 "pairs_in_flight_per_tracker": args.in_flight,
+                "residency": "kept across steps (next step's share submitted before the current one is collected)" if streaming
+                             else "drained at the end of every step",
                 "iteration_statistics": "delivered" if with_stats else "dropped",
                 "sharding": "independent pairs per rank, no collective on the data path",
             },
@@ -321,14 +363,17 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "achieved_is": "ALGORITHMIC bytes (56 B per selected reference pixel per residual pass, SURVEY.md 8d) / k_tick "
-                               "launch duration; an upper-level view, not the bytes HBM actually moved: see `traffic` and `issue`",
+                "achieved_is": "USEFUL algorithmic bytes (56 B per selected reference pixel per residual pass, SURVEY.md 8d, without "
+                               "the speculative passes that were rolled back: `speculation_waste`) / k_tick launch duration; an "
+                               "upper-level view, not the bytes HBM actually moved: see `traffic` and `issue`",
+                "speculation_waste": {"discarded_fraction_of_submitted_bytes": (discarded_k / alg_bytes_k) if alg_bytes_k else None,
+                                      "achieved_counting_discarded_passes": alg_bytes_k / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0},
                 "traffic": traffic_from_profiles(),
                 "traffic_source": traffic_source(),
                 "kernel": "k_tick (fused warp+residual+weights+normal equations, with the log-likelihood items of the tick)",
                 "launches": int(k_launches),
                 "avg_launch_us": (k_ms * 1e3 / k_launches) if k_launches else None,
-                "alg_bytes_per_launch": (alg_bytes_k / k_launches) if k_launches else None,
+                "alg_bytes_per_launch": (useful_k / k_launches) if k_launches else None,
                 "measured": "HIP events stamped by the dispatch itself (hipExtLaunchKernel start / stop) on the launching "
                             "stream, every launch alone on the GPU, " + ("inside the timed region" if T == 1 else
                             "in a single-stream pass over one host thread's share of the batch, same pairs in flight, right after "
@@ -336,9 +381,10 @@ def main():
                             "here is not the concurrent rate)" % T),
                 "residual_passes": int(passes),
                 "concurrent": {
-                    "achieved": alg_bytes / elapsed_local / 1e9, "unit": "GB/s", "frac": alg_bytes / elapsed_local / 1e9 / HBM_PEAK_GBS,
-                    "what": "all launches of the timed region of this GPU together: their algorithmic bytes / the wall time of the "
-                            "region (%d host threads, k_finalize and the host turn-around included)" % T},
+                    "achieved": useful / elapsed_local / 1e9, "unit": "GB/s", "frac": useful / elapsed_local / 1e9 / HBM_PEAK_GBS,
+                    "discarded_fraction_of_submitted_bytes": (discarded_bytes / alg_bytes) if alg_bytes else None,
+                    "what": "all launches of the timed region of this GPU together: their USEFUL algorithmic bytes / the wall time of "
+                            "the region (%d host threads, k_finalize and the host turn-around included)" % T},
                 "issue": issue_roofline(log, k_ms),
             },
         }
@@ -353,6 +399,8 @@ def main():
                 "launch_us": ms_i * 1e3 / nl_i, "alg_bytes_per_launch": ab_i / nl_i}
         except Exception as exc:  # pragma: no cover
             line["roofline_isolated_kernel"] = {"error": str(exc)}
+        if tile_shard is not None:
+            line["tile_shard"] = tile_shard
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, ref_frame, cur_frames[:8], K, levels, first_level)
         if world == 1 and not args.no_extras:
@@ -422,66 +470,108 @@ def issue_roofline(log, k_ms):
         return {"error": repr(exc)}
 
 
-def tile_shard_bench(args, capi, synth, sharding, dist, rank, world, device, ref_frame, cur_frames, K, levels, first_level):
-    """Strong scaling of one pair: every rank holds the same two pyramids and aligns band `rank` of every level."""
+def tile_shard_measure(args, capi, synth, dist, rank, world, device, K, levels, first_level, steps, warmup):
+    """BASELINE config 4: ONE pair at a time, every level tile-sharded over the ranks with a per-tick exchange of the 784-byte
+    band records.  Both exchanges are measured when they come up: the RCCL all-gather (`rccl`, the path whose collective is
+    the library's own) and the one-hop peer exchange (`peer`: mapped fine-grained buffers written by the tail of k_finalize --
+    never run across two GPUs before the first multi-GPU run of this bench, so its poses are cross-checked against the RCCL
+    path's here and the verdict is part of the output).  A peer exchange that does not come up on every rank (allocation,
+    hipIpc attach, or a first tick that times out) falls back to RCCL automatically and says why.  DVO_AMD_EXCHANGE = peer |
+    rccl restricts the measurement to one path."""
     import numpy as np
 
-    # every rank must hold the SAME frames: regenerate them rank-independently
+    from dvo_slam_amd import sharding
+
+    _all_ranks = sharding.all_ranks
+    # every rank must hold the SAME frames: rank-independent ids
     ref_frame = synth.render(args.width, args.height, None, frame_id=0)
     cur_frames = [synth.render(args.width, args.height, synth.se3_exp(synth.XI_GT_PAIR * (0.6 + 0.1 * i)), frame_id=1 + 2 * i)
                   for i in range(4)]
     ref = capi.RgbdImagePyramid(ref_frame[0], ref_frame[1], K, levels, device=device)
     curs = [capi.RgbdImagePyramid(f[0], f[1], K, levels, device=device) for f in cur_frames]
-    trk = capi.DenseTracker(capi.Config(FirstLevel=first_level, LastLevel=0), device=device)
-    exchange = os.environ.get("DVO_AMD_EXCHANGE", "peer")
-    if exchange == "peer":
-        # one-hop exchange: every rank maps every peer's exchange buffer (hipIpc); handles all-gathered here
-        handle = trk.exchange_create(world, rank)
-        handles = [handle]
+    cfg = capi.Config(FirstLevel=first_level, LastLevel=0)
+    want = os.environ.get("DVO_AMD_EXCHANGE", "auto")
+    pairs_per_step = 8
+
+    def barrier():
         if dist is not None:
-            handles = [None] * world
-            dist.all_gather_object(handles, handle)
-        trk.exchange_attach(handles)
-    else:
+            import torch
+
+            dist.barrier()
+            if dist.get_backend() == "nccl":
+                torch.cuda.synchronize()
+
+    def timed(trk):
+        poses = []
+        for _ in range(warmup + 1):
+            for i in range(pairs_per_step):
+                poses.append(trk.match_sharded(ref, curs[i % len(curs)]).Transformation)
+        barrier()
+        t0 = time.perf_counter()
+        ticks = 0
+        for _ in range(steps):
+            for i in range(pairs_per_step):
+                ticks += trk.match_sharded(ref, curs[i % len(curs)]).n_ticks
+        barrier()
+        elapsed = max(_all_ranks(dist, time.perf_counter() - t0))
+        n_pairs = pairs_per_step * steps  # the SAME pairs on every rank: total work is fixed
+        return {"pairs_per_s": n_pairs / elapsed, "us_per_tick": elapsed * 1e6 / max(ticks, 1), "ms_per_step": elapsed * 1e3 / steps,
+                "ticks": ticks}, poses[:pairs_per_step]
+
+    out = {"ranks": world, "pairs_per_step": pairs_per_step, "steps": steps,
+           "what": f"ONE synthetic {args.width}x{args.height} pair at a time, every pyramid level tile-sharded over {world} GPU(s) "
+                   "(bands of scan-order blocks), per-tick exchange of the 784-byte band records (BASELINE config 4); strong scaling, "
+                   "expected to be slower than one GPU at this size (a tick is ~24 us, so is a small-message exchange)"}
+    poses = {}
+    if want in ("auto", "rccl"):
+        trk = capi.DenseTracker(cfg, device=device)
         ids = [capi.comm_unique_id() if rank == 0 else None]
         if dist is not None:
             dist.broadcast_object_list(ids, src=0)
         trk.comm_create(ids[0], world, rank)
-    pairs_per_step = 8
-    for _ in range(args.warmup + 1):
-        for i in range(pairs_per_step):
-            trk.match_sharded(ref, curs[i % len(curs)])
-    if dist is not None:
-        import torch
+        out["rccl"], poses["rccl"] = timed(trk)
+        del trk
+    if want in ("auto", "peer"):
+        trk = capi.DenseTracker(cfg, device=device)
+        # every stage runs on every rank and counts only if it succeeded everywhere: the ranks agree on a fallback
+        handle, ok, why = sharding.collective_stage(dist, lambda: trk.exchange_create(world, rank), capi.DvoAmdError)
+        if ok:
+            handles = _all_ranks(dist, handle)
+            _, ok, why = sharding.collective_stage(dist, lambda: trk.exchange_attach(handles), capi.DvoAmdError)
+        if ok:  # the first tick: a peer whose writes never become visible times out here
+            _, ok, why = sharding.collective_stage(dist, lambda: trk.match_sharded(ref, curs[0]), capi.DvoAmdError)
+        if ok:
+            out["peer"], poses["peer"] = timed(trk)
+            out["peer"]["verified_over_xgmi_before_this_run"] = False
+            if "rccl" in poses:
+                diff = max(float(np.abs(a - b).max()) for a, b in zip(poses["peer"], poses["rccl"]))
+                out["peer"]["max_abs_pose_difference_to_rccl_path"] = diff  # same records, same fold: expected exactly 0
+                out["peer"]["agrees_with_rccl_path"] = bool(diff == 0.0)
+        else:
+            out["peer"] = {"unavailable": why, "fallback": "rccl"}
+            if want == "peer":
+                raise SystemExit(f"bench.py: DVO_AMD_EXCHANGE=peer but the peer exchange did not come up ({why})")
+        del trk
+    # the figure quoted for config 4: the collective path unless only the peer path was asked for (or only it came up)
+    best = "rccl" if "rccl" in out and "pairs_per_s" in out.get("rccl", {}) else "peer"
+    out["quoted"] = best
+    out["pairs_per_s"] = out[best]["pairs_per_s"]
+    out["us_per_tick"] = out[best]["us_per_tick"]
+    out["ms_per_step"] = out[best]["ms_per_step"]
+    return out
 
-        dist.barrier()
-        torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ticks = 0
-    for _ in range(args.steps):
-        for i in range(pairs_per_step):
-            r = trk.match_sharded(ref, curs[i % len(curs)])
-            ticks += r.n_ticks
-    if dist is not None:
-        import torch
 
-        dist.barrier()
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    elapsed, _ = sharding.aggregate(elapsed, 0, dist, "cuda" if dist is not None else None)
-    n_pairs = pairs_per_step * args.steps  # the SAME pairs on every rank: total work is fixed
+def tile_shard_bench(args, capi, synth, sharding, dist, rank, world, device, ref_frame, cur_frames, K, levels, first_level):
+    """--tile-shard: config 4 as the bench line itself (strong scaling of one pair)."""
+    m = tile_shard_measure(args, capi, synth, dist, rank, world, device, K, levels, first_level, args.steps, args.warmup)
     if rank == 0:
         print(json.dumps({
-            "metric": "frame-pairs/s (640x480, 4-level GN align)", "value": n_pairs / elapsed, "unit": "frame-pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
+            "metric": "frame-pairs/s (640x480, 4-level GN align)", "value": m["pairs_per_s"], "unit": "frame-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["ms_per_step"],
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"ONE synthetic {args.width}x{args.height} pair at a time, every pyramid level tile-sharded "
-                                   f"over {world} GPU(s) (bands of scan-order blocks), per-tick "
-                                   + ("one-hop peer exchange (mapped exchange buffers, k_exchange)" if exchange == "peer" else
-                                      "RCCL all-gather") + f" of the 784-byte band records, {pairs_per_step} pairs per step",
-                       "exchange": exchange,
+            "config": {"workload": m["what"], "exchange": m["quoted"],
                        "sharding": "tile-shard with per-iteration exchange of the band records (BASELINE config 4)"},
-            "us_per_tick": elapsed * 1e6 / max(ticks, 1),
+            "us_per_tick": m["us_per_tick"], "tile_shard": m,
         }), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -33,6 +33,7 @@ EXPORTS = [
     "dvo_amd_track_frame", "dvo_amd_png_info", "dvo_amd_png_read_bgr8", "dvo_amd_png_read_gray16",
     "dvo_amd_format_trajectory_line", "dvo_amd_debug_tick_log", "dvo_amd_debug_iteration", "dvo_amd_match_selection", "dvo_amd_bench_residual_pass_pairs",
     "dvo_amd_exchange_create", "dvo_amd_exchange_attach", "dvo_amd_exchange_destroy",
+    "dvo_amd_match_submit", "dvo_amd_match_wait", "dvo_amd_match_poll", "dvo_amd_debug_next_seq",
 ]
 
 
@@ -59,7 +60,7 @@ class CResult(C.Structure):
                 ("is_nan", C.c_int), ("n_levels", C.c_int), ("levels", CLevelStats * MAX_LEVELS),
                 ("n_iterations", C.c_int), ("iterations_capacity", C.c_int),
                 ("iterations", C.POINTER(CIterationStats)), ("n_ticks", C.c_int), ("n_residual_passes", C.c_int),
-                ("alg_bytes", C.c_double)]
+                ("alg_bytes", C.c_double), ("alg_bytes_discarded", C.c_double)]
 
 
 class CFrameCriteria(C.Structure):
@@ -143,6 +144,10 @@ def lib():
     L.dvo_amd_match_selection.argtypes = [vp, vp, C.c_float, C.c_float, vp, dp, C.POINTER(CResult)]
     L.dvo_amd_match_batch.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), dp, C.POINTER(CResult)]
     L.dvo_amd_match_many.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), dp, C.POINTER(CResult), C.c_int]
+    L.dvo_amd_match_submit.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), dp, C.POINTER(CResult), C.c_int,
+                                       C.POINTER(C.c_ulonglong)]
+    L.dvo_amd_match_wait.argtypes = [vp, C.c_ulonglong]
+    L.dvo_amd_match_poll.argtypes = [vp, C.c_ulonglong, C.POINTER(C.c_int)]
     L.dvo_amd_residuals.argtypes = [vp, vp, vp, C.c_int, fp, fp, C.POINTER(C.c_int)]
     L.dvo_amd_error_image.argtypes = [vp, vp, vp, dp, C.c_int, fp]
     L.dvo_amd_debug_iteration.argtypes = [vp, vp, vp, C.c_int, fp, fp, fp, C.POINTER(CIterationProbe)]
@@ -165,6 +170,8 @@ def lib():
     L.dvo_amd_debug_combine_bands.argtypes = [C.c_int, dp, dp]
     L.dvo_amd_debug_wire_layout.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.dvo_amd_debug_take_wire.argtypes = [C.POINTER(C.c_uint), C.c_uint, C.c_int, C.POINTER(C.c_uint)]
+    L.dvo_amd_debug_next_seq.argtypes = [C.c_uint]
+    L.dvo_amd_debug_next_seq.restype = C.c_uint
     L.dvo_amd_se3_exp.argtypes = [dp, dp]
     L.dvo_amd_se3_exp.restype = None
     L.dvo_amd_se3_log.argtypes = [dp, dp]
@@ -323,6 +330,7 @@ class Result:
         self.n_ticks = c.n_ticks
         self.n_residual_passes = c.n_residual_passes
         self.alg_bytes = c.alg_bytes
+        self.alg_bytes_discarded = c.alg_bytes_discarded
         self.Levels = []
         for l in range(c.n_levels):
             L = c.levels[l]
@@ -342,6 +350,19 @@ class Result:
 
     def isNaN(self) -> bool:
         return self._is_nan
+
+
+class Submission:
+    """n pairs queued with DenseTracker.submit: the ticket, and the result structs the library fills (kept alive here)"""
+
+    def __init__(self, ticket, res, its, n):
+        self.ticket, self._res, self._its, self.n = ticket, res, its, n
+
+    def results(self, raw: bool = False):
+        if raw:
+            self._res._keepalive = self._its
+            return self._res
+        return [Result(self._res[i], self._its[i]) for i in range(self.n)]
 
 
 class DenseTracker:
@@ -421,6 +442,41 @@ class DenseTracker:
         if not stats:
             return [Result(res[i], None) for i in range(n)]
         return [Result(res[i], its[i]) for i in range(n)]
+
+    def submit(self, references, currents, T_inits=None, stats: bool = True, in_flight: int = 72, results=None):
+        """dvo_amd_match_submit: queue n pairs behind whatever this tracker is still working on and return at once; the
+        tracker keeps `in_flight` pairs resident across submissions (it never drains while it is fed).  Returns a
+        Submission; wait(submission) / poll(submission) complete it."""
+        n = len(references)
+        assert len(currents) == n
+        if results is not None:
+            res, its = results
+        elif stats:
+            res, its = self._alloc_results(n)
+        else:
+            res, its = (CResult * n)(), [None] * n
+        refs = (C.c_void_p * n)(*[r._h for r in references])
+        curs = (C.c_void_p * n)(*[c._h for c in currents])
+        T0, T0a = None, None
+        if T_inits is not None:
+            T0a = np.ascontiguousarray(np.stack([np.asarray(T, dtype=np.float64).T for T in T_inits]))
+            T0 = T0a.ctypes.data_as(C.POINTER(C.c_double))
+        ticket = C.c_ulonglong()
+        _check(lib().dvo_amd_match_submit(self._h, n, refs, curs, T0, res, in_flight, C.byref(ticket)), "dvo_amd_match_submit")
+        return Submission(ticket.value, res, its, n)
+
+    def wait(self, submission=None, raw: bool = False):
+        """dvo_amd_match_wait: drive the queue until the submission (None: everything submitted) is complete; returns its
+        results (raw=True: the C result structs as the library filled them)."""
+        _check(lib().dvo_amd_match_wait(self._h, 0 if submission is None else submission.ticket), "dvo_amd_match_wait")
+        return None if submission is None else submission.results(raw)
+
+    def poll(self, submission=None) -> bool:
+        """dvo_amd_match_poll: advance whatever has landed, never waiting for the GPU; True when the submission is complete"""
+        done = C.c_int()
+        _check(lib().dvo_amd_match_poll(self._h, 0 if submission is None else submission.ticket, C.byref(done)),
+               "dvo_amd_match_poll")
+        return bool(done.value)
 
     def track_frame(self, keyframe: RgbdImagePyramid, last_frame: RgbdImagePyramid, frame: RgbdImagePyramid,
                     last_keyframe_pose=None):
@@ -578,7 +634,7 @@ def comm_unique_id() -> bytes:
 
 
 def wire_layout():
-    """(pieces, payload words) of a record on its way to the host: pieces of three payload words and the tick number"""
+    """(pieces, payload words) of a record on its way to the host: pieces of two {payload word, tick number} halves"""
     a, b = C.c_int(), C.c_int()
     _check(lib().dvo_amd_debug_wire_layout(C.byref(a), C.byref(b)), "wire_layout")
     return a.value, b.value

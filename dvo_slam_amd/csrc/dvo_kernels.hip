@@ -20,6 +20,7 @@
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "dvo_types.h"
 
@@ -54,23 +55,15 @@ __device__ __forceinline__ float dpp_read(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, true));
 }
 
-// Sum over the 64 lanes of a wave; the total is valid in lane 63.
-// RMODE 0: ds_bpermute butterfly (reference implementation), RMODE 1: DPP row operations.
-template <int RMODE>
+// Sum over the 64 lanes of a wave with DPP row operations; the total is valid in lane 63.
 __device__ __forceinline__ float wave_sum_to_lane63(float v) {
-  if (RMODE == 0) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-  } else {
-    v += dpp_read<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
-    v += dpp_read<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
-    v += dpp_read<0x141, 0xF>(v);  // row_half_mirror
-    v += dpp_read<0x140, 0xF>(v);  // row_mirror: every lane holds its row's sum
-    v += dpp_read<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
-    v += dpp_read<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3
-    return v;
-  }
+  v += dpp_read<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v += dpp_read<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v += dpp_read<0x141, 0xF>(v);  // row_half_mirror
+  v += dpp_read<0x140, 0xF>(v);  // row_mirror: every lane holds its row's sum
+  v += dpp_read<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
+  v += dpp_read<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3
+  return v;
 }
 
 __device__ __forceinline__ double wave_sum_double(double v) {
@@ -244,16 +237,11 @@ typedef float v4acc __attribute__((ext_vector_type(4)));
 //        through LDS (lane-per-point -> lane-per-component) and accumulated by v_mfma_f32_16x16x4_f32 into 2 x 4
 //        registers.  The MFMA sums over the points itself, so no 87-value wave reduction is needed and the kernel fits
 //        4 waves per SIMD (the 87-register form is capped at 2).
-// ACC 2: the same Gram matrix from its 4x4 blocks: v is cut into the groups [Ja0..3] [Ja4,Ja5,Jb0,Jb1] [Jb2..5] [r0,r1,0,0] and
-//        v_mfma_f32_4x4x1_16B_f32 (16 independent 4x4 outer products per instruction, one pixel each) accumulates only the 9
-//        group pairs the 87 moments need (6 of the symmetric J J^T part + 3 J r^T): 36 instructions x 8 cycles per 64 pixels
-//        instead of 16 x 32, at the price of 36 accumulator registers and a 16-block reduction in the epilogue.
-// LEAN: the build for five waves per SIMD.  One staging buffer instead of two (a wave's LDS queue is in order: the reads of
-//        what step n - 1 staged are issued before step n's writes), K*T in LDS instead of 12 registers, the next step's reference
-//        scalars requested after the gathers have landed instead of a whole step ahead.
-template <int RMODE, int ACC, bool LEAN>
+// (Measured and removed in round 3, DESIGN.md section 10: the Gram matrix from 4x4-block MFMAs, a five-waves-per-SIMD build,
+// physical blocks walking several logical ones, item tables in device memory.)
+template <int ACC>
 __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const int lb) {
-  constexpr int kBufs = LEAN ? 1 : 2;
+  constexpr int kBufs = 2;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
   const int seg = lb * kWavesPerBlock + wave;
@@ -282,23 +270,11 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
 
   // K*T lives in vector registers: as scalars the 12 values do not fit next to the descriptors, and the compiler re-reads
   // them from the kernel arguments inside every step, with a full scalar-memory wait in front of the projection
-  // (LEAN is short of registers instead: there K*T sits in LDS, written once per block, and is fetched at the top of every
-  // step with three broadcast reads, so that it is not live while the gathers and the accumulators are)
-  constexpr bool kKtLds = LEAN;
-  constexpr bool kLatePrefetch = LEAN;
-  __shared__ __attribute__((aligned(16))) float kt_lds[12];
   float kt[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) {
     kt[i] = it.kt[i];
-    if (!kKtLds) DVO_OPAQUE(kt[i]);
-  }
-  if (kKtLds) {
-    if (threadIdx.x == 0) {
-#pragma unroll
-      for (int i = 0; i < 12; ++i) kt_lds[i] = kt[i];
-    }
-    __syncthreads();
+    DVO_OPAQUE(kt[i]);
   }
   const bool unit_w = (it.flags & kItemUnitWeights) != 0;
   const float P0 = it.P[0], P1 = it.P[1], P2 = it.P[2], P3 = it.P[3];
@@ -320,35 +296,7 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
   const int g_comp = lane & 15, g_sub = lane >> 4, g_cb = (g_comp >> 2) ^ (g_sub >> 1);
   const float *const g_even = stage + (wave * kBufs * kWave + g_sub) * 16 + ((g_cb << 2) | (g_comp & 3));
   const float *const g_odd = stage + (wave * kBufs * kWave + g_sub) * 16 + (((g_cb ^ 2) << 2) | (g_comp & 3));
-  // 4x4-block form (ACC 2): MFMA m of a step covers the 16 pixels 16 m .. 16 m + 15, one per block; lane 4 b + i supplies
-  // element i of a component group of pixel 16 m + b.  A group is exactly one 16-byte chunk of the staged row, at chunk position
-  // g ^ ((p >> 1) & 3) = g ^ ((b >> 1) & 3): four lane-constant offsets, the rest are immediates.  Conflict free: within a
-  // half wave the 8 blocks x 4 elements fall on 32 different banks.
-  constexpr int kGram4Types = 9;  // (gA, gB): (0,0) (0,1) (0,2) (1,1) (1,2) (2,2) (0,3) (1,3) (2,3)
-  v4acc g4[ACC == 2 ? kGram4Types : 1];
-#pragma unroll
-  for (int t = 0; t < (ACC == 2 ? kGram4Types : 1); ++t) g4[t] = v4acc{0.0f, 0.0f, 0.0f, 0.0f};
-  const int b4 = lane >> 2, i4 = lane & 3, sw4 = (b4 >> 1) & 3;
-  const float *const g4_base = stage + (wave * kBufs * kWave + b4) * 16 + i4;
   auto gram_from_stage = [&](const int q) __attribute__((always_inline)) {
-    if (ACC == 2) {
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        float R[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) R[g] = g4_base[((g ^ sw4) << 2) + (q & (kBufs - 1)) * kWave * 16 + m * 256];
-        g4[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(R[0], R[0], g4[0], 0, 0, 0);
-        g4[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(R[0], R[1], g4[1], 0, 0, 0);
-        g4[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(R[0], R[2], g4[2], 0, 0, 0);
-        g4[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(R[1], R[1], g4[3], 0, 0, 0);
-        g4[4] = __builtin_amdgcn_mfma_f32_4x4x1f32(R[1], R[2], g4[4], 0, 0, 0);
-        g4[5] = __builtin_amdgcn_mfma_f32_4x4x1f32(R[2], R[2], g4[5], 0, 0, 0);
-        g4[6] = __builtin_amdgcn_mfma_f32_4x4x1f32(R[0], R[3], g4[6], 0, 0, 0);
-        g4[7] = __builtin_amdgcn_mfma_f32_4x4x1f32(R[1], R[3], g4[7], 0, 0, 0);
-        g4[8] = __builtin_amdgcn_mfma_f32_4x4x1f32(R[2], R[3], g4[8], 0, 0, 0);
-      }
-      return;
-    }
 #pragma unroll
     for (int m = 0; m < 16; m += 2) {
       const float va = g_even[(q & (kBufs - 1)) * kWave * 16 + 64 * m];
@@ -375,15 +323,7 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
       n_iy = ld_off<float>(p_iy, 4u * idx);
       n_tx = ld_off<float>(p_tx, 4u * pcol), n_ty = ld_off<float>(p_ty, 4u * (prow < d.h ? prow : d.h - 1));
     };
-    if (prefetch && !kLatePrefetch) prefetch_next();
-    float ktl[12];
-    if (kKtLds) {
-      const v4f *kp = reinterpret_cast<const v4f *>(kt_lds);
-      asm volatile("" : "+v"(kp));  // not loop invariant to the compiler: re-read every step
-      const v4f k0 = kp[0], k1 = kp[1], k2 = kp[2];
-      ktl[0] = k0.x, ktl[1] = k0.y, ktl[2] = k0.z, ktl[3] = k0.w, ktl[4] = k1.x, ktl[5] = k1.y, ktl[6] = k1.z, ktl[7] = k1.w;
-      ktl[8] = k2.x, ktl[9] = k2.y, ktl[10] = k2.z, ktl[11] = k2.w;
-    }
+    if (prefetch) prefetch_next();
 
     // ---- switch to round-toward-zero: every float that crosses is made opaque on both sides of the s_setreg
     DVO_OPAQUE(x); DVO_OPAQUE(y); DVO_OPAQUE(z); DVO_OPAQUE(ri); DVO_OPAQUE(rix); DVO_OPAQUE(riy);
@@ -392,7 +332,7 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
     float r0, r1, e2, e3, e4, e5;
     bool ok;
     {
-      const Proj p = project_pixel_rtz(kKtLds ? ktl : kt, d, x, y, z);
+      const Proj p = project_pixel_rtz(kt, d, x, y, z);
       Gathered g;
       if (DVO_ABLATE & 2) {
         const v4f c = {p.u, 1.5f, p.v, 0.25f};
@@ -417,7 +357,6 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
     round_to_nearest();
     DVO_OPAQUE(r0); DVO_OPAQUE(r1); DVO_OPAQUE(e2); DVO_OPAQUE(e3); DVO_OPAQUE(e4); DVO_OPAQUE(e5);
     DVO_OPAQUE(x); DVO_OPAQUE(y); DVO_OPAQUE(z);
-    if (prefetch && kLatePrefetch) prefetch_next();
 
     // spill the residual of this iteration for the log-likelihood pass (NaN marks an invalid pixel)
     {
@@ -570,38 +509,19 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
   }
 
   if (DVO_ABLATE & 32) {  // (ablation 32: no epilogue -- keep the accumulators alive, write nothing)
-    DVO_KEEP(S0[0] + S1[0] + first_w + gram_a[0] + gram_b[0] + g4[0][0] + (float)run_count);
+    DVO_KEEP(S0[0] + S1[0] + first_w + gram_a[0] + gram_b[0] + (float)run_count);
     return;
   }
   if (ACC >= 1 && !(DVO_ABLATE & 1) && steps > 0) gram_from_stage(1);  // the last step (odd index) staged into buffer 1
 
   // ---- wave reduction, then the four waves of the block through LDS
   __shared__ float sm[kWavesPerBlock][kRecStride];
-  // ACC 2: a wave's 4x4 block sums go to the start of its own staging area (its last reads of it are behind it in the wave's
-  // in-order LDS queue): [row of 16 lanes][type][i][j], 576 floats
-  constexpr int kG4Scratch = 4 * kGram4Types * 16;
-  static_assert(kG4Scratch <= kBufs * kWave * 16, "the 4x4 block sums fit a wave's staging area");
   if (ACC == 0) {
 #pragma unroll
     for (int i = 0; i < kNumAcc; ++i) {
-      const float s = wave_sum_to_lane63<RMODE>(acc[i]);
+      const float s = wave_sum_to_lane63(acc[i]);
       if (lane == 63) sm[wave][kRecAcc + i] = s;
     }
-  } else if (ACC == 2) {
-    // D of block b sits in lanes 4 b .. 4 b + 3 (column j), register i (row): first the four blocks of every 16-lane row
-    // (two DPP row shifts leave the row's sum in its lanes 12..15), then one LDS word per (row, type, i, j)
-    float *scr = stage + wave * kBufs * kWave * 16;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int t = 0; t < kGram4Types; ++t)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float v = g4[t][i];
-        v += dpp_read<0x114, 0xF>(v);  // row_shr:4
-        v += dpp_read<0x118, 0xF>(v);  // row_shr:8
-        if ((lane & 15) >= 12) scr[((lane >> 4) * kGram4Types + t) * 16 + i * 4 + (lane & 3)] = v;
-      }
   } else {
     // C/D layout of the 16x16 MFMA: register r of lane l is G[row = (l>>4)*4 + r][col = l&15]
     // into the start of the wave's own staging area (its reads of it are behind it in the in-order LDS queue)
@@ -613,12 +533,12 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    const float s0 = (DVO_ABLATE & 64) ? S0[i] : wave_sum_to_lane63<RMODE>(S0[i]);
-    const float s1 = (DVO_ABLATE & 64) ? S1[i] : wave_sum_to_lane63<RMODE>(S1[i]);
+    const float s0 = (DVO_ABLATE & 64) ? S0[i] : wave_sum_to_lane63(S0[i]);
+    const float s1 = (DVO_ABLATE & 64) ? S1[i] : wave_sum_to_lane63(S1[i]);
     if (lane == 63) sm[wave][kRecS0 + i] = s0, sm[wave][kRecS1 + i] = s1;
   }
   {
-    const float fw = (DVO_ABLATE & 64) ? first_w : wave_sum_to_lane63<RMODE>(first_w);
+    const float fw = (DVO_ABLATE & 64) ? first_w : wave_sum_to_lane63(first_w);
     if (lane == 63) {
       const v2f last = slots[0];  // the last valid residual of the segment (zeros if there is none)
       sm[wave][kRecFirstW] = fw;
@@ -660,27 +580,9 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
     if (ACC == 0) {
       rec[kRecAcc + tid] = (sm[0][kRecAcc + tid] + sm[1][kRecAcc + tid]) + (sm[2][kRecAcc + tid] + sm[3][kRecAcc + tid]);
     } else {
-      float v;
-      if (ACC == 2) {
-        // Gram entry (r, c), r <= c, lives in block type (r / 4, c / 4) at (r % 4, c % 4): sum over the 4 waves x 4 rows
-        auto entry = [&](const int e) {
-          const int r = e >> 4, c = e & 15, ga = r >> 2, gb = c >> 2;
-          const int type = gb == 3 ? 6 + ga : (ga == 0 ? gb : (ga == 1 ? 2 + gb : 5));
-          const int off = type * 16 + (r & 3) * 4 + (c & 3);
-          float sum = 0.0f;
-          for (int wv = 0; wv < kWavesPerBlock; ++wv) {
-            const float *scr = stage + wv * kBufs * kWave * 16 + off;
-            sum += (scr[0] + scr[kGram4Types * 16]) + (scr[2 * kGram4Types * 16] + scr[3 * kGram4Types * 16]);
-          }
-          return sum;
-        };
-        v = entry(e0);
-        if (e1 >= 0) v += entry(e1);
-      } else {
-        constexpr int kW = kBufs * kWave * 16;  // floats between the staging areas of two waves
-        v = (stage[e0] + stage[kW + e0]) + (stage[2 * kW + e0] + stage[3 * kW + e0]);
-        if (e1 >= 0) v += (stage[e1] + stage[kW + e1]) + (stage[2 * kW + e1] + stage[3 * kW + e1]);
-      }
+      constexpr int kW = kBufs * kWave * 16;  // floats between the staging areas of two waves
+      float v = (stage[e0] + stage[kW + e0]) + (stage[2 * kW + e0] + stage[3 * kW + e0]);
+      if (e1 >= 0) v += (stage[e1] + stage[kW + e1]) + (stage[2 * kW + e1] + stage[3 * kW + e1]);
       rec[kRecAcc + tid] = v;
     }
   } else if (tid == 128) {
@@ -821,21 +723,15 @@ __device__ __forceinline__ LevelPairDesc load_desc(const TickItem &it) {
   return d;
 }
 
-template <int RMODE, int ACC, bool LEAN>
+template <int ACC>
 __device__ __forceinline__ void tick_body(const TickItem &it, const int bx) {
-  const int rp = it.res_phys;
-  if (bx >= rp + it.ll_blocks) return;
+  const int rb = it.res_blocks;
+  if (bx >= rb + it.ll_blocks) return;
   const LevelPairDesc d = load_desc(it);
-  if (bx < rp) {
-    // a physical block walks several logical blocks when the launch holds many more blocks than the GPU has slots: the
-    // item and its descriptors are fetched once, and only the first logical block pays the dependent-load prologue
-    for (int lb = bx; lb < it.res_blocks; lb += rp) {
-      residual_pass<RMODE, ACC, LEAN>(it, d, it.res_first + xcd_contiguous_block(lb, it.res_blocks));
-      __syncthreads();  // the reduction scratch in LDS is reused by the next logical block
-    }
-  } else {
-    loglik_pass(it, d, it.ll_first + (bx - rp));
-  }
+  if (bx < rb)
+    residual_pass<ACC>(it, d, it.res_first + xcd_contiguous_block(bx, rb));
+  else
+    loglik_pass(it, d, it.ll_first + (bx - rb));
 }
 
 // Which item owns this block, and which of the item's blocks is it?  Two-dimensional grid: (block, item).  One-dimensional
@@ -856,57 +752,55 @@ __device__ __forceinline__ int tick_locate(const Args &args, int &bx) {
   return idx;
 }
 
-template <int RMODE, int ACC, int OCC>
-__global__ __launch_bounds__(kBlockThreads, OCC) void k_tick(const TickArgs args) {
+// ACC 1 (default): Gram matrix on the matrix pipe, 4 waves per SIMD.  ACC 0 (DVO_AMD_ACCUM=valu): 87 fp32 registers per lane,
+// 2 waves per SIMD -- kept as the cross-check of the summation (tests/test_gpu_parity.py runs the parity suite's criterion under it).
+template <int ACC>
+__global__ __launch_bounds__(kBlockThreads, ACC == 0 ? 2 : 4) void k_tick(const TickArgs args) {
   int bx;
   const int idx = tick_locate(args, bx);
-  tick_body<RMODE, ACC, (OCC >= 5 || ACC == 2)>(args.items[idx], bx);
+  tick_body<ACC>(args.items[idx], bx);
 }
 
 // the same kernel behind the small argument block of a tick of at most kMaxSmallItems pairs
 __global__ __launch_bounds__(kBlockThreads, 4) void k_tick_small(const TickArgsSmall args) {
   int bx;
   const int idx = tick_locate(args, bx);
-  tick_body<1, 1, false>(args.items[idx], bx);
+  tick_body<1>(args.items[idx], bx);
 }
 
-// The same tick with the items in a device-resident table (uploaded in-stream before the launch): for launches with more
-// resident pairs than fit the 4 KB kernel-argument block.  The item is pulled into scalar registers once per block.
-template <int RMODE, int ACC, int OCC>
-__global__ __launch_bounds__(kBlockThreads, OCC) void k_tick_table(const TickItem *items) {
-  const DVO_CONST TickItem *p = (const DVO_CONST TickItem *)items + blockIdx.y;
-  TickItem it;
-  it.ref = p->ref, it.cur = p->cur, it.slot = p->slot;
-  it.res_blocks = p->res_blocks, it.ll_blocks = p->ll_blocks, it.res_first = p->res_first, it.ll_first = p->ll_first;
-  it.steps_log2 = p->steps_log2, it.flags = p->flags, it.res_phys = p->res_phys;
-  it.ll_cut_rank = p->ll_cut_rank;
-#pragma unroll
-  for (int i = 0; i < 12; ++i) it.kt[i] = p->kt[i];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) it.P[i] = p->P[i];
-  tick_body<RMODE, ACC, (OCC >= 5 || ACC == 2)>(it, (int)blockIdx.x);
+// DVO_AMD_LAUNCH_LOCK=1: a process-wide mutex around every kernel launch.  Only for profiled multi-thread runs: rocprofv3's
+// queue interceptor reads past the end of an AQL ring when two host threads publish packets to one hardware queue across
+// the ring's wrap (profiles/r03_rocprofv3_sigsegv_root_cause.md); under the lock every doorbell finds exactly one packet.
+static std::mutex g_launch_mu;
+static bool launch_lock_enabled() {  // (function-local statics: initialised once, thread-safe)
+  static const bool on = [] {
+    const char *e = getenv("DVO_AMD_LAUNCH_LOCK");
+    return e && e[0] == '1';
+  }();
+  return on;
 }
+struct LaunchGuard {
+  bool held;
+  LaunchGuard() {
+    held = launch_lock_enabled();
+    if (held) g_launch_mu.lock();
+  }
+  ~LaunchGuard() {
+    if (held) g_launch_mu.unlock();
+  }
+};
 
-static int g_reduce_mode = -1;  // DVO_AMD_REDUCE=0: ds_bpermute butterfly instead of DPP (debug cross-check)
-static int g_acc_mode = -1;     // DVO_AMD_ACCUM=valu: 87 register accumulators; =mfma4: the Gram matrix from 4x4 blocks; default: the full 16x16 Gram matrix
-static int g_occ = 4;           // DVO_AMD_OCC=3|4|5: compile-time register budget in waves per SIMD
+// DVO_AMD_ACCUM=valu: 87 register accumulators; default: the Gram matrix on the matrix pipe
+static int acc_mode() {
+  static const int m = [] {
+    const char *a = getenv("DVO_AMD_ACCUM");
+    return (a && (a[0] == 'v' || a[0] == 'V' || a[0] == '0')) ? 0 : 1;
+  }();
+  return m;
+}
 
 typedef void (*TickKernel)(const TickArgs);
-static TickKernel pick_tick_kernel() {
-  if (g_reduce_mode < 0) {
-    const char *e = getenv("DVO_AMD_REDUCE");
-    g_reduce_mode = (e && e[0] == '0') ? 0 : 1;
-    const char *a = getenv("DVO_AMD_ACCUM");
-    g_acc_mode = 1;
-    if (a && (a[0] == 'v' || a[0] == 'V' || a[0] == '0')) g_acc_mode = 0;
-    if (a && !strcmp(a, "mfma4")) g_acc_mode = 2;
-    const char *o = getenv("DVO_AMD_OCC");
-    g_occ = (o && o[0] == '5') ? 5 : (o && o[0] == '3') ? 3 : 4;
-  }
-  if (g_acc_mode == 0) return g_reduce_mode == 0 ? k_tick<0, 0, 2> : k_tick<1, 0, 2>;
-  if (g_acc_mode == 1) return g_occ == 5 ? k_tick<1, 1, 5> : g_reduce_mode == 0 ? k_tick<0, 1, 4> : k_tick<1, 1, 4>;
-  return g_occ == 3 ? k_tick<1, 2, 3> : g_occ == 5 ? k_tick<1, 2, 5> : k_tick<1, 2, 4>;
-}
+static TickKernel pick_tick_kernel() { return acc_mode() == 0 ? k_tick<0> : k_tick<1>; }
 
 // A tick's items are at different pyramid levels: the two-dimensional grid (blocks of the largest item x items) launches
 // mostly blocks that return at once, and the dispatcher starts only ~4 of them per nanosecond.  When more than half of the
@@ -917,15 +811,14 @@ static int tick_args_layout_impl(Args &args, int max_blocks) {
   unsigned groups = 0;
   for (int i = 0; i < args.n_items; ++i) {
     args.group_first[i] = (uint16_t)groups;
-    groups += ((unsigned)args.items[i].res_phys + args.items[i].ll_blocks + 7u) >> 3;
+    groups += ((unsigned)args.items[i].res_blocks + args.items[i].ll_blocks + 7u) >> 3;
   }
   for (int i = args.n_items; i < kSlots; ++i) args.group_first[i] = (uint16_t)groups;
   const long long grid2d = (long long)((max_blocks + 7) & ~7) * args.n_items;
-  static int mode = -1;  // DVO_AMD_COMPACT_GRID=0 / 1 forces a layout (tuning)
-  if (mode < 0) {
+  static const int mode = [] {  // DVO_AMD_COMPACT_GRID=0 / 1 forces a layout (tuning)
     const char *e = getenv("DVO_AMD_COMPACT_GRID");
-    mode = e ? (e[0] == '0' ? 0 : 1) : 2;
-  }
+    return e ? (e[0] == '0' ? 0 : 1) : 2;
+  }();
   args.compact = groups > 0 && groups < 65536 && (mode == 1 || (mode == 2 && 2ll * 8 * groups < grid2d)) ? 1 : 0;
   return (int)(groups * 8);
 }
@@ -933,9 +826,9 @@ int tick_args_layout(TickArgs &args, int max_blocks) { return tick_args_layout_i
 int tick_args_layout(TickArgsSmall &args, int max_blocks) { return tick_args_layout_impl(args, max_blocks); }
 
 hipError_t launch_tick_small(const TickArgsSmall &args, int max_blocks, hipStream_t stream, hipEvent_t t_start, hipEvent_t t_stop) {
-  (void)pick_tick_kernel();  // reads the environment switches
-  if (g_acc_mode != 1 || g_occ != 4 || g_reduce_mode == 0) return hipErrorNotSupported;
+  if (acc_mode() != 1) return hipErrorNotSupported;
   if (args.n_items <= 0 || max_blocks <= 0) return hipSuccess;
+  LaunchGuard guard;
   dim3 grid((unsigned)((max_blocks + 7) & ~7), (unsigned)args.n_items, 1);
   if (args.compact) grid = dim3((unsigned)args.group_first[args.n_items] * 8u, 1, 1);
   if (t_start && t_stop) {
@@ -952,6 +845,7 @@ hipError_t launch_tick_small(const TickArgsSmall &args, int max_blocks, hipStrea
 hipError_t launch_tick(const TickArgs &args, int max_blocks, hipStream_t stream, hipEvent_t t_start, hipEvent_t t_stop) {
   TickKernel kernel = pick_tick_kernel();
   if (args.n_items <= 0 || max_blocks <= 0) return hipSuccess;
+  LaunchGuard guard;
   dim3 grid((unsigned)((max_blocks + 7) & ~7), (unsigned)args.n_items, 1);
   if (args.compact) grid = dim3((unsigned)args.group_first[args.n_items] * 8u, 1, 1);
   if (t_start && t_stop) {
@@ -962,22 +856,6 @@ hipError_t launch_tick(const TickArgs &args, int max_blocks, hipStream_t stream,
   } else {
     hipLaunchKernelGGL(kernel, grid, dim3(kBlockThreads), 0, stream, args);
   }
-  return hipGetLastError();
-}
-
-hipError_t launch_tick_table(const TickItem *items_dev, int n_items, int max_blocks, hipStream_t stream, hipEvent_t t_start,
-                             hipEvent_t t_stop) {
-  if (n_items <= 0 || max_blocks <= 0) return hipSuccess;
-  dim3 grid((unsigned)((max_blocks + 7) & ~7), (unsigned)n_items, 1);
-  if (t_start && t_stop)
-  {
-    void *kargs[] = {&items_dev};
-    const hipError_t e = hipExtLaunchKernel(reinterpret_cast<const void *>(&k_tick_table<1, 1, 4>), grid, dim3(kBlockThreads),
-                                            kargs, 0, stream, t_start, t_stop, 0);
-    if (e != hipSuccess) return e;
-  }
-  else
-    hipLaunchKernelGGL((k_tick_table<1, 1, 4>), grid, dim3(kBlockThreads), 0, stream, items_dev);
   return hipGetLastError();
 }
 
@@ -1049,11 +927,12 @@ __device__ __forceinline__ v4u ld16_system(const DVO_GLOBAL void *p) {
   asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
   return v;
 }
+// piece i of a record: two 8-byte halves {payload word, tag} (FinWire)
 __device__ __forceinline__ v4u wire_piece(const unsigned *record_words, int i, unsigned tag) {
   v4u piece;
-  piece.x = record_words[3 * i];
-  piece.y = 3 * i + 1 < kFinWords ? record_words[3 * i + 1] : 0u;
-  piece.z = 3 * i + 2 < kFinWords ? record_words[3 * i + 2] : 0u;
+  piece.x = record_words[2 * i];
+  piece.y = tag;
+  piece.z = 2 * i + 1 < kFinWords ? record_words[2 * i + 1] : 0u;
   piece.w = tag;
   return piece;
 }
@@ -1062,28 +941,35 @@ __device__ __forceinline__ v4u wire_piece(const unsigned *record_words, int i, u
 // (p mod n_waves) pushes it into rank p's exchange buffer as tagged 16-byte pieces, then every lane waits -- bounded -- for
 // "its" pieces of rank p's record of this tick to land in the local buffer and forwards them, tag included, to the host.
 // No fence and no ready word anywhere: a piece is valid when its tag is the tick.  Returns false on a timeout.
-__device__ bool exchange_records(const ExchangeArgs &a, const unsigned *own_record, unsigned seq, int wave, int n_waves, int lane) {
-  const int slot = (int)(seq & 1u) * a.n_ranks;
+// The exchange description stays in memory and is read through the constant address space (scalar loads, the peer table
+// indexed dynamically): a by-value copy with a dynamically indexed array would live in scratch.
+__device__ bool exchange_records(const ExchangeArgs *xa, const unsigned *own_record, unsigned seq, int wave, int n_waves, int lane) {
+  const DVO_CONST ExchangeArgs *a = (const DVO_CONST ExchangeArgs *)xa;
+  const int n_ranks = a->n_ranks, rank = a->rank;
+  const unsigned long long timeout = (unsigned long long)a->timeout_ticks;
+  const int slot = (int)(seq & 1u) * n_ranks;
   bool ok = true;
-  for (int p = wave; p < a.n_ranks; p += n_waves) {
-    FinWire *dst = a.peers[p] + slot + a.rank;
+  for (int p = wave; p < n_ranks; p += n_waves) {
+    FinWire *dst = a->peers[p] + slot + rank;
     for (int i = lane; i < kFinWirePieces; i += kWave) st16_system((DVO_GLOBAL void *)dst->piece[i], wire_piece(own_record, i, seq));
   }
-  for (int p = wave; p < a.n_ranks; p += n_waves) {
-    const FinWire *in = a.local + slot + p;
-    FinWire *out = a.host_records + p;
+  const FinWire *local = a->local;
+  FinWire *host_records = a->host_records;
+  for (int p = wave; p < n_ranks; p += n_waves) {
+    const FinWire *in = local + slot + p;
+    FinWire *out = host_records + p;
     for (int i = lane; i < kFinWirePieces; i += kWave) {
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
       v4u piece = ld16_system((const DVO_GLOBAL void *)in->piece[i]);
-      while (piece.w != seq) {
+      while (piece.y != seq || piece.w != seq) {  // both halves of the piece carry the tick (FinWire)
         __builtin_amdgcn_s_sleep(8);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)a.timeout_ticks) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > timeout) {
           ok = false;
           break;
         }
         piece = ld16_system((const DVO_GLOBAL void *)in->piece[i]);
       }
-      if (piece.w == seq) st16_system((DVO_GLOBAL void *)out->piece[i], piece);
+      if (piece.y == seq && piece.w == seq) st16_system((DVO_GLOBAL void *)out->piece[i], piece);
     }
   }
   return ok;
@@ -1094,7 +980,8 @@ __device__ bool exchange_records(const ExchangeArgs &a, const unsigned *own_reco
 // log-likelihood partials in fp64 with 16-byte loads, eight in flight per thread.  Two block barriers in all; the record is
 // assembled in LDS and pushed to the pinned host buffer as self-validating 16-byte pieces (FinWire): no fence, no ready word.
 // One block reduces one item (see above); `exchange`: the tile-sharded pair's one-hop exchange instead of the hand-off to the host.
-template <int NT>
+// EXCHANGE is a compile-time property of the launch: the batch and single-pair kernels carry no trace of the exchange tail.
+template <int NT, bool EXCHANGE>
 __device__ __forceinline__ void finalize_block(const FinItem &it, const bool stamps, const ExchangeArgs *exchange, const unsigned xseq) {
   constexpr int kFinChunks = FinGeometry<NT>::kChunks;
   const int t = threadIdx.x;
@@ -1258,24 +1145,21 @@ __device__ __forceinline__ void finalize_block(const FinItem &it, const bool sta
   DVO_FIN_STAMP(2);
 
   // ---- tile-sharded pair: the record goes to the peers instead, theirs come back to the host (see exchange_records)
-  if (exchange && blockIdx.x == 0) {
+  if (EXCHANGE && exchange && blockIdx.x == 0) {
     __shared__ int sh_bad;
     if (t == 0) sh_bad = 0;
     __syncthreads();
-    const DVO_CONST ExchangeArgs *xp = (const DVO_CONST ExchangeArgs *)exchange;
-    ExchangeArgs xa;
-#pragma unroll
-    for (int i = 0; i < kMaxExchangeRanks; ++i) xa.peers[i] = xp->peers[i];
-    xa.local = xp->local, xa.host_records = xp->host_records, xa.host_seq = xp->host_seq;
-    xa.n_ranks = xp->n_ranks, xa.rank = xp->rank, xa.timeout_ticks = xp->timeout_ticks;
-    if (!exchange_records(xa, reinterpret_cast<const unsigned *>(&sh_out), xseq, t >> 6, NT / kWave, t & (kWave - 1)))
+    if (!exchange_records(exchange, reinterpret_cast<const unsigned *>(&sh_out), xseq, t >> 6, NT / kWave, t & (kWave - 1)))
       atomicOr(&sh_bad, 1);
     __syncthreads();
-    if (t == 0 && sh_bad) __hip_atomic_store(xa.host_seq, xseq | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (t == 0 && sh_bad)
+      __hip_atomic_store(((const DVO_CONST ExchangeArgs *)exchange)->host_seq, xseq | 0x80000000u, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }
   // ---- publish: every piece of the record goes to the pinned host buffer with the tick's sequence number inside it, in one
   // 16-byte system-scope store per lane.  The host validates piece by piece (FinWire), so nothing is fenced or ordered here.
+  static_assert(kFinWirePieces <= 256, "one lane per piece in the smallest finalize block");
   if (t < kFinWirePieces)
     st16_system((DVO_GLOBAL void *)it.out->piece[t], wire_piece(reinterpret_cast<const unsigned *>(&sh_out), t, it.seq));
   if (it.out_dev && t < (int)(sizeof(FinOut) / 16))  // device copy for the collective fallback of a tile-sharded pair
@@ -1283,23 +1167,15 @@ __device__ __forceinline__ void finalize_block(const FinItem &it, const bool sta
   DVO_FIN_STAMP(3);
 }
 
-template <int NT>
+template <int NT, bool EXCHANGE>
 __global__ __launch_bounds__(NT) void k_finalize(const FinArgs args) {
-  FinItem it;
-  if (args.table) {  // more items than the argument block holds: the item comes from the table uploaded with the tick's items
-    const DVO_CONST FinItem *p = (const DVO_CONST FinItem *)args.table + blockIdx.x;
-    it.records = p->records, it.n_blocks = p->n_blocks, it.block_first = p->block_first;
-    it.n_ll_blocks = p->n_ll_blocks, it.ll_first = p->ll_first, it.ll_partials = p->ll_partials;
-    it.seg_prefix_out = p->seg_prefix_out, it.out = p->out, it.out_dev = p->out_dev, it.seq = p->seq, it.pad = p->pad;
-  } else {
-    it = args.items[blockIdx.x];
-  }
-  finalize_block<NT>(it, args.pad == 0x57A3 && blockIdx.x == 0, blockIdx.x == 0 ? args.exchange : nullptr, args.xseq);
+  finalize_block<NT, EXCHANGE>(args.items[blockIdx.x], args.pad == 0x57A3 && blockIdx.x == 0,
+                               EXCHANGE && blockIdx.x == 0 ? args.exchange : nullptr, args.xseq);
 }
 
 // the same behind the small argument block of a tick of at most kMaxSmallItems pairs
 __global__ __launch_bounds__(kFinThreads) void k_finalize_small(const FinArgsSmall args) {
-  finalize_block<kFinThreads>(args.items[blockIdx.x], args.pad == 0x57A3 && blockIdx.x == 0, nullptr, 0u);
+  finalize_block<kFinThreads, false>(args.items[blockIdx.x], args.pad == 0x57A3 && blockIdx.x == 0, nullptr, 0u);
 }
 
 hipError_t read_finalize_stamps(unsigned long long out[8]) {
@@ -1308,16 +1184,20 @@ hipError_t read_finalize_stamps(unsigned long long out[8]) {
 
 hipError_t launch_finalize_small(const FinArgsSmall &args, hipStream_t stream) {
   if (args.n_items <= 0) return hipSuccess;
+  LaunchGuard guard;
   hipLaunchKernelGGL(k_finalize_small, dim3((unsigned)args.n_items), dim3(kFinThreads), 0, stream, args);
   return hipGetLastError();
 }
 
 hipError_t launch_finalize(const FinArgs &args, hipStream_t stream) {
   if (args.n_items <= 0) return hipSuccess;
-  if (args.n_items > kMaxSmallItems && !args.exchange)
-    hipLaunchKernelGGL(k_finalize<kFinThreadsBatch>, dim3((unsigned)args.n_items), dim3(kFinThreadsBatch), 0, stream, args);
+  LaunchGuard guard;
+  if (args.exchange)
+    hipLaunchKernelGGL((k_finalize<kFinThreads, true>), dim3((unsigned)args.n_items), dim3(kFinThreads), 0, stream, args);
+  else if (args.n_items > kMaxSmallItems)
+    hipLaunchKernelGGL((k_finalize<kFinThreadsBatch, false>), dim3((unsigned)args.n_items), dim3(kFinThreadsBatch), 0, stream, args);
   else
-    hipLaunchKernelGGL(k_finalize<kFinThreads>, dim3((unsigned)args.n_items), dim3(kFinThreads), 0, stream, args);
+    hipLaunchKernelGGL((k_finalize<kFinThreads, false>), dim3((unsigned)args.n_items), dim3(kFinThreads), 0, stream, args);
   return hipGetLastError();
 }
 
@@ -1338,6 +1218,7 @@ __global__ void k_pyr_down(const float *__restrict__ ip, const float *__restrict
 
 hipError_t launch_pyr_down(const float *i_prev, const float *z_prev, int w_prev, float *i_out, float *z_out, int w, int h,
                            hipStream_t stream) {
+  LaunchGuard guard;
   dim3 grid((unsigned)((w + 255) / 256), (unsigned)h);
   hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), 0, stream, i_prev, z_prev, w_prev, i_out, z_out, w, h);
   return hipGetLastError();
@@ -1374,6 +1255,7 @@ __global__ void k_level_planes(const float *__restrict__ ip, const float *__rest
 hipError_t launch_level_planes(const float *i_plane, const float *z_plane, int w, int h, int n_pad, float fx, float fy,
                                float ox, float oy, float4 *c_a, float2 *c_b, float *r_i, float *r_ix, float *r_iy,
                                float *tx, float *ty, int ty_len, hipStream_t stream) {
+  LaunchGuard guard;
   int span = n_pad > ty_len ? n_pad : ty_len;
   if (w > span) span = w;
   hipLaunchKernelGGL(k_level_planes, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, stream, i_plane, z_plane, w, h,
@@ -1386,22 +1268,24 @@ hipError_t launch_level_planes(const float *i_plane, const float *z_plane, int w
 __global__ void k_select(const float *__restrict__ zp, const float4 *__restrict__ c_a, const float2 *__restrict__ c_b, int n,
                          int n_pad, float ti, float td, float *__restrict__ zsel, int *__restrict__ counters) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_pad) return;
   float out = u2f(0x7fc00000u);
+  bool ok = false;
   if (i < n) {
     const float z = zp[i];
     const float4 a = c_a[i];
     const float2 b = c_b[i];
-    const bool ok = (z == z) && (b.x == b.x) && (b.y == b.y) &&
-                    (__builtin_fabsf(a.z) > ti || __builtin_fabsf(a.w) > ti || __builtin_fabsf(b.x) > td ||
-                     __builtin_fabsf(b.y) > td);
-    if (ok) {
-      out = z;
-      atomicAdd(&counters[0], 1);
-      atomicMax(&counters[1], i);
-    }
+    ok = (z == z) && (b.x == b.x) && (b.y == b.y) &&
+         (__builtin_fabsf(a.z) > ti || __builtin_fabsf(a.w) > ti || __builtin_fabsf(b.x) > td || __builtin_fabsf(b.y) > td);
+    if (ok) out = z;
   }
-  zsel[i] = out;
+  if (i < n_pad) zsel[i] = out;
+  // count and last index (selectPointsFromImage's running output pointer, point_selection.cpp:119-152): one ballot per wave,
+  // one atomic pair per wave that selected anything -- the highest selected lane of a wave holds the wave's largest index
+  const unsigned long long m = __ballot(ok);
+  if (m != 0ull && (threadIdx.x & (kWave - 1)) == 63 - __builtin_clzll(m)) {
+    atomicAdd(&counters[0], __popcll(m));
+    atomicMax(&counters[1], i);
+  }
 }
 
 // Q3: computeResidualsSse walks the selection two points at a time and never looks at an odd trailing point
@@ -1412,6 +1296,7 @@ __global__ void k_select_drop_odd(float *zsel, const int *counters) {
 
 hipError_t launch_select(const float *z_plane, const float4 *c_a, const float2 *c_b, int n, int n_pad, float ti, float td,
                          float *zsel, int *counters, hipStream_t stream) {
+  LaunchGuard guard;
   hipError_t e = hipMemsetAsync(counters, 0, sizeof(int), stream);
   if (e != hipSuccess) return e;
   e = hipMemsetAsync(counters + 1, 0xFF, sizeof(int), stream);
@@ -1428,6 +1313,7 @@ __global__ void k_copy_strided(const float *__restrict__ src, int stride, float 
 }
 
 hipError_t launch_copy_strided(const float *src, int stride, float *dst, int w, int h, hipStream_t stream) {
+  LaunchGuard guard;
   hipLaunchKernelGGL(k_copy_strided, dim3((unsigned)((w + 255) / 256), (unsigned)h), dim3(256), 0, stream, src, stride, dst, w,
                      h);
   return hipGetLastError();
@@ -1490,6 +1376,7 @@ __global__ void k_ingest(const unsigned char *__restrict__ img, int channels, in
 
 hipError_t launch_ingest(const unsigned char *img, int channels, int img_stride_bytes, const unsigned short *raw_z,
                          int z_stride, float z_scale, float *i_plane, float *z_plane, int w, int h, hipStream_t stream) {
+  LaunchGuard guard;
   const int wq = w / 4;
   hipLaunchKernelGGL(k_ingest, dim3((unsigned)((wq + 63) / 64), (unsigned)h), dim3(64), 0, stream, img, channels,
                      img_stride_bytes, raw_z, z_stride, z_scale, i_plane, z_plane, w, h);
@@ -1502,6 +1389,7 @@ __global__ void k_mask_from_zsel(const float *__restrict__ zsel, int n, int last
 }
 
 hipError_t launch_mask_from_zsel(const float *zsel, int n, int last_dropped, unsigned char *mask, hipStream_t stream) {
+  LaunchGuard guard;
   hipLaunchKernelGGL(k_mask_from_zsel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, zsel, n, last_dropped, mask);
   return hipGetLastError();
 }
@@ -1523,6 +1411,7 @@ __global__ void k_unpack_plane(const float4 *__restrict__ c_a, const float2 *__r
 }
 
 hipError_t launch_unpack_plane(const float4 *c_a, const float2 *c_b, int plane, int n, float *dst, hipStream_t stream) {
+  LaunchGuard guard;
   hipLaunchKernelGGL(k_unpack_plane, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c_a, c_b, plane, n, dst);
   return hipGetLastError();
 }

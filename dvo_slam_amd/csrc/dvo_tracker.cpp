@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -419,8 +420,7 @@ int pyramid_selection(dvo_amd_pyramid *p, float ti, float td, const Selection **
 // context + Gauss-Newton driver
 // ------------------------------------------------------------------------------------------------------------------
 
-// bytes of one tick stream's item table: tick items, then reduce items
-constexpr size_t kTableBytes = ((sizeof(TickItem) * kMaxTableItems + 63) / 64) * 64 + sizeof(FinItem) * kMaxTableItems;
+struct Runner;  // the resident pairs of a context and the queue behind them (defined with the driver below)
 
 struct JobSlot {
   float2 *res[2] = {nullptr, nullptr};
@@ -445,20 +445,13 @@ struct dvo_amd_context {
   FinOut *out_host = nullptr;            // = out_store.data()
   int out_capacity = 0;
   SlotDesc *slot_desc = nullptr;       // device, [slot]
-  unsigned *tickets = nullptr;         // device, one arrival counter per tick stream
-  // item tables for launches with more pairs than the kernel-argument block holds: per tick stream a pinned host staging
-  // area and its device copy (uploaded in-stream in front of the launch)
-  // per tick stream: kMaxTableItems tick items followed by as many reduce items (one upload per launch)
-  char *item_host = nullptr, *item_dev = nullptr;
-  int stage_owner[kMaxTickStreams] = {0, 0, 0, 0, 0, 0, 0, 0};  // pair group (id + 1) whose table upload last used a staging slot
-  int items_per_launch = kMaxItemsPerLaunch;           // DVO_AMD_ITEMS_PER_LAUNCH (<= kMaxTableItems)
+  Runner *runner = nullptr;            // resident pairs + pending queue (dvo_amd_match_submit / _wait, dvo_amd_match_many)
+  int items_per_launch = kMaxItemsPerLaunch;           // DVO_AMD_ITEMS_PER_LAUNCH (<= kMaxItemsPerLaunch: tuning)
   int spec_levels = -1;                                // start the next level speculatively in the tick of a level's last
                                                        // likelihood: -2..3 ticks per pair, but a converged level's last likelihood is
                                                        // rejected about half the time (+3 % residual work).  -1 (default): only
                                                        // while at most kSpecLevelsMaxPairs pairs are resident in the tick (latency
                                                        // matters, the GPU has room); DVO_AMD_SPEC_LEVELS=0 never, =1 always
-  int phys_block_target = 1 << 30;                     // DVO_AMD_PHYS_BLOCKS=n: fold a launch's residual-pass blocks down to ~n
-                                                       // physical blocks that walk several logical ones (measured: slower, off)
   // DVO_AMD_HOST_PROF=1: where the host thread spends its time (printed when the context is destroyed)
   bool host_prof = false;
   double prof_submit_ns = 0.0, prof_wait_ns = 0.0, prof_process_ns = 0.0;
@@ -477,6 +470,7 @@ struct dvo_amd_context {
   FinOut x_store[kMaxExchangeRanks];            // ... decoded
   unsigned *x_host_seq = nullptr;               // pinned: tick | 0x80000000 when the exchange kernel gave up waiting for a peer
   unsigned x_seq = 0;
+  bool x_broken = false;                        // a tick of the exchange timed out: every later dvo_amd_match_sharded fails fast
   ExchangeArgs *x_args_dev = nullptr;           // device copy of the exchange description k_finalize reads
   ncclResult_t (*p_allgather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*p_comm_destroy)(ncclComm_t) = nullptr;
@@ -554,6 +548,7 @@ struct Job {
   int recent_count = 0;
   int level_first_iteration = 0;
   double alg_px = 0.0;
+  double discarded_px = 0.0;  // selected pixels of speculative residual passes that were thrown away
 };
 
 dvo_amd_iteration_stats *stats_push(Job &j) {
@@ -614,6 +609,7 @@ void finish_job(Job &j) {
   for (int i = 0; i < 36; ++i) si += r->information[i];
   r->is_nan = !(std::isfinite(s) && std::isfinite(si));
   r->alg_bytes = 56.0 * j.alg_px;
+  r->alg_bytes_discarded = 56.0 * j.discarded_px;
   j.done = true;
 }
 
@@ -777,6 +773,7 @@ void process_loglik(Job &j, const FinOut *outs) {
   j.error = -(double)ll;
   const bool accept = j.error < j.last_error;  // :312
   if (!accept) {
+    if (j.sub_res) j.discarded_px += j.sub_px;  // iteration k+1 (or the next level's first pass) ran alongside: thrown away
     j.have_spec = false;  // a speculative start of the next level assumed acceptance: discarded
     j.next_flip = a.buf ^ 1;
     // :314-322: roll back iteration a (and the speculative iteration b, if any)
@@ -841,10 +838,6 @@ int ensure_slots_impl(dvo_amd_context *ctx, int n_jobs, int n_pad) {
   }
   std::memset(ctx->out_wire, 0, sizeof(FinWire) * (size_t)n_slots);  // tick numbers restart below: no piece may carry an old one
   HIP_TRY(hipMalloc((void **)&ctx->slot_desc, sizeof(SlotDesc) * n_slots));
-  if (!ctx->tickets) {
-    HIP_TRY(hipMalloc((void **)&ctx->tickets, sizeof(unsigned) * 16 * kMaxTickStreams));
-    HIP_TRY(hipMemset(ctx->tickets, 0, sizeof(unsigned) * 16 * kMaxTickStreams));
-  }
   std::vector<SlotDesc> slot_host((size_t)n_slots);
   const int max_blocks = new_pad / (kStepPx * kWavesPerBlock);  // one-step segments: the most blocks a level can have
   const size_t b_res = align_up(sizeof(float2) * new_pad, 256);
@@ -950,15 +943,16 @@ int timing_collect(dvo_amd_context *ctx) {
 
 // Take the pieces of a record that carry tick `seq` out of a pinned buffer into *dst; returns the index of the first piece
 // that is not there yet (kFinWirePieces when the record is complete).  A piece is one aligned 16-byte load: payload and tag
-// come from the same store of the device.
+// come from the same store of the device, and each 8-byte half of the piece carries the tag.
 int take_wire(const FinWire *w, FinOut *dst_record, unsigned seq, int from_piece) {
   unsigned *dst = reinterpret_cast<unsigned *>(dst_record);
   for (int i = from_piece; i < kFinWirePieces; ++i) {
     __asm__ __volatile__("" ::: "memory");
     alignas(16) unsigned u[4];
     _mm_store_si128(reinterpret_cast<__m128i *>(u), _mm_load_si128(reinterpret_cast<const __m128i *>(w->piece[i])));
-    if (u[3] != seq) return i;
-    for (int k = 0; k < 3 && 3 * i + k < kFinWords; ++k) dst[3 * i + k] = u[k];
+    if (u[1] != seq || u[3] != seq) return i;  // both 8-byte halves carry the tick (FinWire)
+    dst[2 * i] = u[0];
+    if (2 * i + 1 < kFinWords) dst[2 * i + 1] = u[2];
   }
   dst_record->seq = seq;
   return kFinWirePieces;
@@ -1044,7 +1038,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
     if (wants_spec(j)) total_px += j.ref->lv[j.level - 1].n;
   }
   const int steps_now = pick_steps(ctx, total_px);
-  const unsigned seq = ++ctx->tick_seq;
+  const unsigned seq = ctx->tick_seq = next_seq(ctx->tick_seq);
   grp.seq = seq;
 
   std::vector<TickItem> items;
@@ -1080,7 +1074,6 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
       while (j.b.steps < kMaxSteps && blocks_for(j.ref->lv[j.level].n, j.b.steps) > 2048) j.b.steps *= 2;
       j.b.n_blocks = blocks_for(j.ref->lv[j.level].n, j.b.steps);
       w.res_blocks = (uint16_t)j.b.n_blocks;
-      w.res_phys = w.res_blocks;
       res_steps = j.b.steps;
       if (j.b.buf) w.flags |= kItemResBuf;
       if (j.b.k == 0) w.flags |= kItemUnitWeights;  // dense_tracking.cpp:286-293
@@ -1102,7 +1095,6 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
       w.ref = j.sel->ref_desc + nl;  // the likelihood pass only uses the slot's buffers
       w.cur = j.cur->cur_desc + nl;
       w.res_blocks = (uint16_t)j.spec_b.n_blocks;
-      w.res_phys = w.res_blocks;
       res_steps = j.spec_b.steps;
       if (j.spec_b.buf) w.flags |= kItemResBuf;
       w.flags |= kItemUnitWeights;
@@ -1128,13 +1120,9 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
 
   // split evenly over as few launches as the argument block allows; launch i (and the finalize of its jobs) goes to stream
   // i so that the launches of one tick overlap instead of queueing behind each other's latency floor
-  const size_t cap = (size_t)std::min(std::max(ctx->items_per_launch, 1), kMaxTableItems);
+  const size_t cap = (size_t)std::min(std::max(ctx->items_per_launch, 1), kMaxItemsPerLaunch);
   const size_t n_launch = (items.size() + cap - 1) / cap;
   const size_t per = (items.size() + n_launch - 1) / n_launch;
-  if (per > (size_t)kMaxItemsPerLaunch && !ctx->item_host) {
-    HIP_TRY(hipHostMalloc((void **)&ctx->item_host, kTableBytes * kMaxTickStreams, hipHostMallocDefault));
-    HIP_TRY(hipMalloc((void **)&ctx->item_dev, kTableBytes * kMaxTickStreams));
-  }
   size_t launch_index = 0;
   for (size_t first = 0; first < items.size(); first += per, ++launch_index) {
     hipStream_t st;
@@ -1144,39 +1132,12 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
     }
     TickArgs ta;
     const int n_here = (int)std::min(per, items.size() - first);
-    const bool use_table = n_here > kMaxItemsPerLaunch;
-    const size_t stream_slot = ctx->timing ? 0 : (grp.stream_first + launch_index) % kMaxTickStreams;
-    ta.n_items = use_table ? 0 : n_here;
+    ta.n_items = n_here;
     ta.compact = 0;
     int max_blocks = 0;
-    TickItem *stage = use_table ? reinterpret_cast<TickItem *>(ctx->item_host + stream_slot * kTableBytes) : ta.items;
-    // Optionally (DVO_AMD_PHYS_BLOCKS) a physical block walks several logical ones, so that only the first pays the
-    // dependent-load prologue.  Measured on MI355X: the coarser scheduling loses more than the prologue costs (36 level-0
-    // pairs: 129 us with one block per logical block, 141 us folded 2x, 157 us folded 5x), so the default is no folding.
-    long long total_res_blocks = 0;
-    for (int i = 0; i < n_here; ++i) total_res_blocks += items[first + i].res_blocks;
-    const int walk = (int)std::min<long long>(8, std::max<long long>(1, total_res_blocks / ctx->phys_block_target));
     for (int i = 0; i < n_here; ++i) {
-      stage[i] = items[first + i];
-      // (a multiple of 8, so that a physical block's logical blocks keep its XCD in the XCD-contiguous block mapping)
-      stage[i].res_phys = (uint16_t)std::min<int>(stage[i].res_blocks, ((stage[i].res_blocks + walk - 1) / walk + 7) & ~7);
-      max_blocks = std::max(max_blocks, (int)stage[i].res_phys + (int)stage[i].ll_blocks);
-    }
-    if (use_table) {
-      // The staging slot (and its stream) is shared with whatever launch maps to the same index.  Within one group the tick
-      // that used it has been waited for; a second lap of this tick's launches, or another group's launch that may still be
-      // in flight (groups with more than one launch each), must drain first: the async upload reads the pinned area later.
-      if (launch_index >= (size_t)kMaxTickStreams || (ctx->stage_owner[stream_slot] != 0 && ctx->stage_owner[stream_slot] != grp.id + 1))
-        HIP_TRY(hipStreamSynchronize(st));
-      ctx->stage_owner[stream_slot] = grp.id + 1;
-    }
-    // the reduce items of the launch travel behind its tick items, in the same upload
-    const size_t fin_offset = align_up(sizeof(TickItem) * (size_t)n_here, 64);
-    if (use_table) {
-      FinItem *fin_stage = reinterpret_cast<FinItem *>(reinterpret_cast<char *>(stage) + fin_offset);
-      for (int i = 0; i < n_here; ++i) fin_stage[i] = fin_items[first + (size_t)i];
-      HIP_TRY(hipMemcpyAsync(ctx->item_dev + stream_slot * kTableBytes, stage, fin_offset + sizeof(FinItem) * (size_t)n_here,
-                             hipMemcpyHostToDevice, st));
+      ta.items[i] = items[first + i];
+      max_blocks = std::max(max_blocks, (int)ta.items[i].res_blocks + (int)ta.items[i].ll_blocks);
     }
     size_t ev = 0;
     if (ctx->timing) {
@@ -1184,9 +1145,9 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
       if (rc) return rc;
       double rb = 0, lb = 0, px = 0, res_steps = 0, ll_steps = 0;
       for (int i = 0; i < n_here; ++i) {
-        rb += stage[i].res_blocks, lb += stage[i].ll_blocks;
-        res_steps += (double)stage[i].res_blocks * kWavesPerBlock * item_res_steps(stage[i]);
-        ll_steps += (double)stage[i].ll_blocks * kWavesPerBlock * item_ll_steps(stage[i]);
+        rb += ta.items[i].res_blocks, lb += ta.items[i].ll_blocks;
+        res_steps += (double)ta.items[i].res_blocks * kWavesPerBlock * item_res_steps(ta.items[i]);
+        ll_steps += (double)ta.items[i].ll_blocks * kWavesPerBlock * item_ll_steps(ta.items[i]);
       }
       for (size_t ji = grp.lo, k = 0; ji < grp.hi; ++ji) {
         const Job &j = jobs[ji];
@@ -1198,7 +1159,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
       ctx->tick_log_pending.insert(ctx->tick_log_pending.end(), rec, rec + kTickLogFields);
     }
     hipEvent_t t0 = ctx->timing ? ctx->events[ev].first : nullptr, t1 = ctx->timing ? ctx->events[ev].second : nullptr;
-    if (ctx->small_args && !use_table && n_launch == 1 && n_here <= kMaxSmallItems) {
+    if (ctx->small_args && n_launch == 1 && n_here <= kMaxSmallItems) {
       // a single match() or the two-pair front-end step: the same two kernels behind argument blocks a tenth the size
       TickArgsSmall ts;
       ts.n_items = n_here, ts.compact = 0;
@@ -1214,25 +1175,20 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
         continue;
       }
       if (es != hipErrorNotSupported) return fail_hip("launch_tick", es);
-      (void)hipGetLastError();  // another k_tick variant was selected by an environment switch: the full-size launch below
+      (void)hipGetLastError();  // DVO_AMD_ACCUM=valu selected the register form: the full-size launch below
     }
-    if (!use_table) (void)tick_args_layout(ta, max_blocks);
-    hipError_t e = use_table ? launch_tick_table(reinterpret_cast<const TickItem *>(ctx->item_dev + stream_slot * kTableBytes), n_here, max_blocks, st, t0, t1)
-                             : launch_tick(ta, max_blocks, st, t0, t1);
+    (void)tick_args_layout(ta, max_blocks);
+    hipError_t e = launch_tick(ta, max_blocks, st, t0, t1);
     if (e != hipSuccess) return fail_hip("launch_tick", e);
-    // the reduce kernel takes its items by value, 48 per launch, or all of them from the table the tick's upload carried
-    for (int f0 = 0; f0 < n_here; f0 += use_table ? n_here : kMaxFinItems) {
-      FinArgs fa;
-      fa.n_items = use_table ? n_here : std::min(kMaxFinItems, n_here - f0);
-      fa.pad = ctx->fin_stamps ? 0x57A3 : 0;
-      fa.ticket = ctx->tickets + 16 * stream_slot;  // one counter per stream
-      fa.exchange = nullptr, fa.xseq = 0, fa.pad2 = 0;
-      fa.table = use_table ? reinterpret_cast<const FinItem *>(ctx->item_dev + stream_slot * kTableBytes + fin_offset) : nullptr;
-      if (!use_table)
-        for (int i = 0; i < fa.n_items; ++i) fa.items[i] = fin_items[first + (size_t)f0 + (size_t)i];
-      e = launch_finalize(fa, st);
-      if (e != hipSuccess) return fail_hip("launch_finalize", e);
-    }
+    static_assert(kMaxFinItems >= kMaxItemsPerLaunch, "one reduce launch per tick launch");
+    FinArgs fa;
+    fa.n_items = n_here;
+    fa.pad = ctx->fin_stamps ? 0x57A3 : 0;
+    fa.exchange = nullptr, fa.xseq = 0, fa.pad2 = 0;
+    for (int i = 0; i < n_here; ++i) fa.items[i] = fin_items[first + (size_t)i];
+    for (int i = n_here; i < kMaxFinItems; ++i) fa.items[i] = fa.items[0];  // the whole block is copied by the launch: no stale stack bytes
+    e = launch_finalize(fa, st);
+    if (e != hipSuccess) return fail_hip("launch_finalize", e);
   }
   grp.in_flight = true;
   if (ctx->host_prof) ctx->prof_submit_ns += now_ns() - t_begin, ctx->prof_ticks++, ctx->prof_job_ticks += (long long)items.size();
@@ -1265,6 +1221,185 @@ int complete_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) 
     }
   }
   if (ctx->host_prof) ctx->prof_wait_ns += t_waited - t_begin, ctx->prof_process_ns += now_ns() - t_waited;
+  return DVO_AMD_OK;
+}
+
+// true when every record of the group's tick in flight has arrived completely (never waits)
+bool tick_landed(dvo_amd_context *ctx, const std::vector<Job> &jobs, const GroupTick &grp) {
+  if (!ctx->poll || ctx->timing) {
+    for (size_t si = 0; si <= ctx->extra_streams.size(); ++si)
+      if (hipStreamQuery(si == 0 ? ctx->stream : ctx->extra_streams[si - 1]) == hipErrorNotReady) return false;
+    return true;
+  }
+  for (size_t ji = grp.lo; ji < grp.hi; ++ji) {
+    const Job &j = jobs[ji];
+    if (j.done || !(j.sub_ll || j.sub_res)) continue;
+    const FinWire *w = ctx->out_wire + (size_t)(j.slot - ctx->slots.data());
+    for (int i = kFinWirePieces - 1; i >= 0; --i) {  // (the last pieces are written by the highest lanes: most likely missing)
+      __asm__ __volatile__("" ::: "memory");
+      alignas(16) unsigned u[4];
+      _mm_store_si128(reinterpret_cast<__m128i *>(u), _mm_load_si128(reinterpret_cast<const __m128i *>(w->piece[i])));
+      if (u[1] != grp.seq || u[3] != grp.seq) return false;
+    }
+  }
+  return true;
+}
+
+}  // namespace
+
+// ---- the queue behind a context: resident pairs + pending pairs ------------------------------------------------------------
+// dvo_amd_match_submit appends pairs, every tick of a group hands the slots of finished pairs to pending ones, so the launches
+// stay full across calls: a tracker that is fed before it runs dry never drains (the shape of tbb::parallel_reduce with
+// grain 1 over a proposal list that keeps growing, keyframe_graph.cpp:587-590).
+struct Pending {
+  dvo_amd_pyramid *ref = nullptr, *cur = nullptr;
+  dvo_amd_result *result = nullptr;
+  unsigned long long batch = 0;
+  bool has_init = false;
+  double T_init[16];
+};
+struct Batch {
+  unsigned long long id = 0;
+  int remaining = 0;
+};
+struct Runner {
+  std::vector<Job> jobs;                    // one per slot; done = free
+  std::vector<unsigned long long> batch_of_slot;  // 0 = free
+  std::vector<GroupTick> groups;
+  std::deque<Pending> pending;
+  std::deque<Batch> batches;                // in submission order; the front is popped once complete
+  unsigned long long next_batch = 1;
+  size_t next_group = 0;
+  int in_flight = 0;
+  bool timing = false;                      // the layout was made for kernel timing (one group)
+  int resident = 0;
+  int failed_status = DVO_AMD_OK;           // a tick failed: every batch up to failed_upto ended with this status
+  unsigned long long failed_upto = 0;
+};
+
+namespace {
+
+void runner_finish_slot(Runner &R, size_t sidx) {
+  Job &j = R.jobs[sidx];
+  for (Batch &b : R.batches)
+    if (b.id == R.batch_of_slot[sidx]) {
+      b.remaining--;
+      break;
+    }
+  R.batch_of_slot[sidx] = 0;
+  R.resident--;
+  dvo_amd_pyramid_release(j.ref);
+  dvo_amd_pyramid_release(j.cur);
+  j.ref = j.cur = nullptr;
+}
+
+// a tick failed: nothing of this context may still run when the caller gets the error (it is free to release its pyramids and
+// result arrays); every resident and pending pair is dropped and its batch closed with the status
+int runner_fail(dvo_amd_context *ctx, int code) {
+  Runner &R = *ctx->runner;
+  (void)hipStreamSynchronize(ctx->stream);
+  for (hipStream_t st : ctx->extra_streams) (void)hipStreamSynchronize(st);
+  for (size_t sidx = 0; sidx < R.jobs.size(); ++sidx)
+    if (R.batch_of_slot[sidx] != 0) {
+      R.jobs[sidx].done = true;
+      runner_finish_slot(R, sidx);
+    }
+  for (Pending &q : R.pending) {
+    dvo_amd_pyramid_release(q.ref);
+    dvo_amd_pyramid_release(q.cur);
+  }
+  R.pending.clear();
+  for (Batch &b : R.batches) b.remaining = 0;
+  for (GroupTick &g : R.groups) g.in_flight = false;
+  R.failed_status = code;
+  R.failed_upto = R.next_batch - 1;
+  R.batches.clear();
+  return code;
+}
+
+// complete the group's tick in flight (waits for it), hand free slots to pending pairs, submit the next tick
+int runner_step(dvo_amd_context *ctx, size_t g) {
+  Runner &R = *ctx->runner;
+  GroupTick &grp = R.groups[g];
+  const dvo_amd_config &cfg = ctx->cfg;
+  int rc = complete_tick(ctx, R.jobs, grp);
+  if (rc) return rc;
+  for (size_t sidx = grp.lo; sidx < grp.hi; ++sidx)
+    if (R.jobs[sidx].done && R.batch_of_slot[sidx] != 0) runner_finish_slot(R, sidx);
+  for (size_t sidx = grp.lo; sidx < grp.hi && !R.pending.empty(); ++sidx) {
+    Job &j = R.jobs[sidx];
+    if (!j.done) continue;
+    const Pending q = R.pending.front();
+    R.pending.pop_front();
+    j = Job();
+    j.ref = q.ref, j.cur = q.cur;
+    j.result = q.result;
+    j.slot = &ctx->slots[sidx];
+    j.cfg = &ctx->cfg;
+    R.batch_of_slot[sidx] = q.batch;
+    R.resident++;
+    rc = pyramid_selection(j.ref, cfg.intensity_derivative_threshold, cfg.depth_derivative_threshold, &j.sel);
+    if (rc) return rc;
+    dvo_amd_result *r = j.result;
+    r->n_levels = 0, r->n_iterations = 0, r->n_ticks = 0, r->n_residual_passes = 0, r->alg_bytes = 0.0, r->alg_bytes_discarded = 0.0, r->is_nan = 0;
+    if (!r->iterations) r->iterations_capacity = 0;
+    // dense_tracking.cpp:137-150
+    j.inc = q.has_init ? se3_from_matrix(q.T_init) : SE3::identity();
+    j.initial = j.inc;
+    j.estimate = SE3::identity();
+    j.level = cfg.first_level;
+    j.done = false;
+    start_level(j);
+  }
+  return submit_tick(ctx, R.jobs, grp);
+}
+
+int runner_drain(dvo_amd_context *ctx) {
+  Runner &R = *ctx->runner;
+  while (R.resident > 0 || !R.pending.empty()) {
+    const size_t g = R.next_group;
+    R.next_group = (R.next_group + 1) % R.groups.size();
+    int rc = runner_step(ctx, g);
+    if (rc) return runner_fail(ctx, rc);
+  }
+  return DVO_AMD_OK;
+}
+
+// Lay the context out for `in_flight` resident pairs of up to n_pad padded pixels.  Pairs enter a free slot as soon as one
+// opens up: the launch of every tick stays full although pairs need different numbers of iterations.  A pair's state machine
+// never looks at another pair, so results do not depend on the schedule (except through the wave-segment length a tick picks,
+// which only changes the order partial sums are taken in).  More resident pairs than one launch takes are split into groups
+// that tick independently, each on its own stream, in round-robin: while the host advances the pairs of one group the kernels
+// of the other groups keep the GPU busy.  (Kernel timing wants every launch alone on the GPU: one group then.)
+int runner_configure(dvo_amd_context *ctx, int in_flight, int n_pad) {
+  Runner &R = *ctx->runner;
+  in_flight = std::max(in_flight, 1);
+  const bool same = R.in_flight == in_flight && R.timing == ctx->timing && (int)ctx->slots.size() >= in_flight &&
+                    ctx->slot_n_pad >= n_pad && ctx->slot_n_pad > 0;
+  if (same) return DVO_AMD_OK;
+  if (R.in_flight > 0) {  // a different residency or larger frames: what is queued runs to completion in the old layout first
+    int rc = runner_drain(ctx);
+    if (rc) return rc;
+  }
+  int rc = ensure_slots(ctx, in_flight, n_pad);
+  if (rc) return rc;
+  R.jobs.assign((size_t)in_flight, Job());
+  for (Job &j : R.jobs) j.done = true;
+  R.batch_of_slot.assign((size_t)in_flight, 0ull);
+  const int cap = std::min(std::max(ctx->items_per_launch, 1), kMaxItemsPerLaunch);
+  const int n_groups = ctx->timing ? 1 : std::min(kMaxTickStreams, (in_flight + cap - 1) / cap);
+  const int per_group = (in_flight + n_groups - 1) / n_groups;
+  R.groups.assign((size_t)n_groups, GroupTick());
+  for (int g = 0; g < n_groups; ++g) {
+    R.groups[(size_t)g].lo = (size_t)std::min(g * per_group, in_flight);
+    R.groups[(size_t)g].hi = (size_t)std::min((g + 1) * per_group, in_flight);
+    R.groups[(size_t)g].stream_first = (size_t)g;
+    R.groups[(size_t)g].id = g;
+  }
+  R.next_group = 0;
+  R.in_flight = in_flight;
+  R.timing = ctx->timing;
+  R.resident = 0;
   return DVO_AMD_OK;
 }
 
@@ -1321,7 +1456,7 @@ void combine_bands(const FinOut *const *recs, int n, FinOut &out) {
 }
 
 int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, int n_local, bool exchange) {
-  const unsigned seq = ++ctx->tick_seq;
+  const unsigned seq = ctx->tick_seq = next_seq(ctx->tick_seq);
   if (!j.have_a && !j.have_b) return DVO_AMD_OK;
   // segment length as the unsharded driver picks it for one pair of this level: the same for every band count and rank
   int steps_level = pick_steps(ctx, j.ref->lv[j.level].n);
@@ -1331,7 +1466,6 @@ int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, i
   FinArgs fa;
   std::memset(&ta, 0, sizeof(ta));
   std::memset(&fa, 0, sizeof(fa));
-  fa.ticket = ctx->tickets;
   j.sub_ll = j.have_a, j.sub_res = j.have_b;
   if (j.have_b) {
     j.b.steps = steps_level, j.b.n_blocks = nb_level;
@@ -1366,7 +1500,6 @@ int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, i
       int first = 0, count = 0;
       band_range(nb_level, n_bands, band, &first, &count);
       w.res_first = (uint16_t)first, w.res_blocks = (uint16_t)count;
-      w.res_phys = w.res_blocks;
       if (j.b.buf) w.flags |= kItemResBuf;
       if (j.b.k == 0) w.flags |= kItemUnitWeights;
       make_kt(j.cur->lv[j.level], j.b.estimate_after, w.kt);
@@ -1379,7 +1512,7 @@ int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, i
     max_blocks = std::max(max_blocks, w.res_blocks + w.ll_blocks);
   }
   ta.n_items = n_local, fa.n_items = n_local;
-  if (exchange && ctx->x_ranks > 0) fa.exchange = ctx->x_args_dev, fa.xseq = ++ctx->x_seq;  // the tail of k_finalize exchanges
+  if (exchange && ctx->x_ranks > 0) fa.exchange = ctx->x_args_dev, fa.xseq = ctx->x_seq = next_seq(ctx->x_seq);  // the tail of k_finalize exchanges
   hipError_t e = launch_tick(ta, std::max(max_blocks, 1), ctx->stream);
   if (e != hipSuccess) return fail_hip("launch_tick", e);
   e = launch_finalize(fa, ctx->stream);
@@ -1397,7 +1530,11 @@ int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, i
       while ((have = take_wire(ctx->x_host + b, ctx->x_store + b, xseq, have)) != kFinWirePieces) {
         __builtin_ia32_pause();
         if (__atomic_load_n(ctx->x_host_seq, __ATOMIC_ACQUIRE) == (xseq | 0x80000000u)) {
-          g_last_error = "peer exchange timed out: a rank did not publish its band record";
+          // After a timeout the ranks no longer agree on the tick number (a peer may have taken this rank's record and
+          // moved on): the exchange is dead for good.  Later calls fail at once; all ranks must destroy and re-create it.
+          ctx->x_broken = true;
+          g_last_error = "peer exchange timed out: a rank did not publish its band record (the exchange is now unusable: "
+                         "destroy and re-create it on every rank)";
           return DVO_AMD_ERR_COMM;
         }
         if ((++spins & 0xFFFFF) == 0) {
@@ -1467,7 +1604,7 @@ int match_one_banded(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_p
   rc = pyramid_selection(j.ref, cfg.intensity_derivative_threshold, cfg.depth_derivative_threshold, &j.sel);
   if (rc) return rc;
   result->n_levels = 0, result->n_iterations = 0, result->n_ticks = 0, result->n_residual_passes = 0;
-  result->alg_bytes = 0.0, result->is_nan = 0;
+  result->alg_bytes = 0.0, result->alg_bytes_discarded = 0.0, result->is_nan = 0;
   if (!result->iterations) result->iterations_capacity = 0;
   j.inc = cfg.use_initial_estimate ? se3_from_matrix(T_init) : SE3::identity();
   j.initial = j.inc;
@@ -1563,13 +1700,9 @@ int dvo_amd_context_create(int device, const dvo_amd_config *cfg, dvo_amd_contex
   if (const char *fs2 = getenv("DVO_AMD_FAULT_SLOT_ALLOC")) ctx->fault_slot_alloc = atoi(fs2);
   if (const char *sa = getenv("DVO_AMD_STEPS_AT"))
     (void)sscanf(sa, "%lld,%lld,%lld,%lld", &ctx->steps_at[0], &ctx->steps_at[1], &ctx->steps_at[2], &ctx->steps_at[3]);
-  if (const char *pb = getenv("DVO_AMD_PHYS_BLOCKS")) {
-    const int v = atoi(pb);
-    if (v >= 64) ctx->phys_block_target = v;
-  }
   if (const char *ipl = getenv("DVO_AMD_ITEMS_PER_LAUNCH")) {
     const int v = atoi(ipl);
-    if (v >= 1 && v <= kMaxTableItems) ctx->items_per_launch = v;
+    if (v >= 1 && v <= kMaxItemsPerLaunch) ctx->items_per_launch = v;
   }
   *out = ctx;
   return DVO_AMD_OK;
@@ -1585,6 +1718,12 @@ void dvo_amd_context_destroy(dvo_amd_context *ctx) {
                  (ctx->prof_submit_ns + ctx->prof_process_ns) / std::max(1LL, ctx->prof_job_ticks) * 1e-3);
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->runner) {
+    // pairs still queued are dropped (their results stay unfinished): stop the kernels, give the pyramids back
+    if (ctx->runner->resident > 0 || !ctx->runner->pending.empty()) (void)runner_fail(ctx, DVO_AMD_ERR_INVALID_ARGUMENT);
+    delete ctx->runner;
+    ctx->runner = nullptr;
+  }
   dvo_amd_comm_destroy(ctx);
   dvo_amd_exchange_destroy(ctx);
   for (hipStream_t st : ctx->extra_streams) {
@@ -1594,9 +1733,6 @@ void dvo_amd_context_destroy(dvo_amd_context *ctx) {
   if (ctx->desc_ready) (void)hipEventDestroy(ctx->desc_ready);
   release_slots(ctx);
   if (ctx->out_wire) (void)hipHostFree(ctx->out_wire);
-  if (ctx->tickets) (void)hipFree(ctx->tickets);
-  if (ctx->item_host) (void)hipHostFree(ctx->item_host);
-  if (ctx->item_dev) (void)hipFree(ctx->item_dev);
   for (auto &ev : ctx->events) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
@@ -1609,6 +1745,10 @@ int dvo_amd_configure(dvo_amd_context *ctx, const dvo_amd_config *cfg) {
   if (!ctx) return DVO_AMD_ERR_INVALID_ARGUMENT;
   int rc = check_config(cfg);
   if (rc) return rc;
+  if (ctx->runner && (ctx->runner->resident > 0 || !ctx->runner->pending.empty())) {
+    g_last_error = "dvo_amd_configure while submitted pairs are still in flight (dvo_amd_match_wait first)";
+    return DVO_AMD_ERR_INVALID_ARGUMENT;
+  }
   ctx->cfg = *cfg;
   return DVO_AMD_OK;
 }
@@ -1717,17 +1857,17 @@ int dvo_amd_pyramid_select(dvo_amd_pyramid *p, int level, float ti, float td, in
   return DVO_AMD_OK;
 }
 
-int dvo_amd_match_many(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *references, dvo_amd_pyramid *const *currents,
-                       const double *T_inits, dvo_amd_result *results, int max_in_flight) {
-  if (!ctx || n < 0 || (n > 0 && (!references || !currents || !results))) return DVO_AMD_ERR_INVALID_ARGUMENT;
-  if (n == 0) return DVO_AMD_OK;
+int dvo_amd_match_submit(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *references, dvo_amd_pyramid *const *currents,
+                         const double *T_inits, dvo_amd_result *results, int max_in_flight, unsigned long long *ticket) {
+  if (!ctx || !ticket || n < 0 || (n > 0 && (!references || !currents || !results))) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  *ticket = 0;
   const dvo_amd_config &cfg = ctx->cfg;
   int rc = check_config(&cfg);
   if (rc) return rc;
   HIP_TRY(hipSetDevice(ctx->device));
   const int need_levels = cfg.first_level + 1;  // Config::getNumLevels
   int n_pad = 0;
-  if (cfg.use_initial_estimate && !T_inits) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  if (cfg.use_initial_estimate && n > 0 && !T_inits) return DVO_AMD_ERR_INVALID_ARGUMENT;
   for (int i = 0; i < n; ++i) {
     if (!references[i] || !currents[i]) return DVO_AMD_ERR_INVALID_ARGUMENT;
     if (references[i]->device != ctx->device || currents[i]->device != ctx->device) return DVO_AMD_ERR_DEVICE_MISMATCH;
@@ -1745,74 +1885,90 @@ int dvo_amd_match_many(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *refe
       if (!std::isfinite(s)) return DVO_AMD_ERR_NAN_INIT;
     }
   }
-  const int in_flight = (max_in_flight <= 0 || max_in_flight > n) ? n : max_in_flight;
-  rc = ensure_slots(ctx, in_flight, n_pad);
+  if (!ctx->runner) ctx->runner = new Runner();
+  Runner &R = *ctx->runner;
+  if (n == 0) {  // an empty batch is complete at once
+    *ticket = R.next_batch++;
+    return DVO_AMD_OK;
+  }
+  rc = runner_configure(ctx, max_in_flight <= 0 ? n : max_in_flight, n_pad);
   if (rc) return rc;
-
-  // Pairs enter a free slot as soon as one opens up: the launch of every tick stays full although pairs need different
-  // numbers of iterations.  A pair's state machine never looks at another pair, so results do not depend on the schedule
-  // (except through the wave-segment length a tick picks, which only changes the order partial sums are taken in).
-  std::vector<Job> jobs((size_t)in_flight);
-  std::vector<int> job_of_slot((size_t)in_flight, -1);
-  for (Job &j : jobs) j.done = true;
-  // More resident pairs than one launch takes are split into groups that tick independently, each on its own stream, in
-  // round-robin: while the host advances the pairs of one group the kernels of the other groups keep the GPU busy.
-  // (Kernel timing wants every launch alone on the GPU: one group then.)
-  const int cap = std::min(std::max(ctx->items_per_launch, 1), kMaxTableItems);
-  const int n_groups = ctx->timing ? 1 : std::min(kMaxTickStreams, (in_flight + cap - 1) / cap);
-  const int per_group = (in_flight + n_groups - 1) / n_groups;
-  std::vector<GroupTick> groups((size_t)n_groups);
-  for (int g = 0; g < n_groups; ++g) {
-    groups[(size_t)g].lo = (size_t)std::min(g * per_group, in_flight);
-    groups[(size_t)g].hi = (size_t)std::min((g + 1) * per_group, in_flight);
-    groups[(size_t)g].stream_first = (size_t)g;
-    groups[(size_t)g].id = g;
+  Batch b;
+  b.id = R.next_batch++;
+  b.remaining = n;
+  R.batches.push_back(b);
+  for (int i = 0; i < n; ++i) {
+    Pending q;
+    q.ref = references[i], q.cur = currents[i], q.result = &results[i], q.batch = b.id;
+    q.has_init = cfg.use_initial_estimate != 0;
+    if (q.has_init) std::memcpy(q.T_init, T_inits + 16 * (size_t)i, sizeof(q.T_init));
+    // the queue holds its own references: the caller may release a pyramid right after submitting
+    dvo_amd_pyramid_retain(q.ref);
+    dvo_amd_pyramid_retain(q.cur);
+    R.pending.push_back(q);
   }
-  // on an error return no kernel of this call may still be running: the caller is free to release the pyramids
-  auto drain = [&](int code) {
-    (void)hipStreamSynchronize(ctx->stream);
-    for (hipStream_t st : ctx->extra_streams) (void)hipStreamSynchronize(st);
-    return code;
-  };
-  int next = 0, finished = 0;
-  int g = 0;
-  while (finished < n) {
-    GroupTick &grp = groups[(size_t)g];
-    g = (g + 1) % n_groups;
-    rc = complete_tick(ctx, jobs, grp);
-    if (rc) return drain(rc);
-    for (size_t sidx = grp.lo; sidx < grp.hi; ++sidx)
-      if (jobs[sidx].done && job_of_slot[sidx] >= 0) {
-        job_of_slot[sidx] = -1;
-        ++finished;
-      }
-    for (size_t sidx = grp.lo; sidx < grp.hi && next < n; ++sidx) {
-      Job &j = jobs[sidx];
-      if (!j.done) continue;
-      const int i = next++;
-      j = Job();
-      j.ref = references[i], j.cur = currents[i];
-      j.result = &results[i];
-      j.slot = &ctx->slots[sidx];
-      j.cfg = &ctx->cfg;
-      rc = pyramid_selection(j.ref, cfg.intensity_derivative_threshold, cfg.depth_derivative_threshold, &j.sel);
-      if (rc) return drain(rc);
-      dvo_amd_result *r = j.result;
-      r->n_levels = 0, r->n_iterations = 0, r->n_ticks = 0, r->n_residual_passes = 0, r->alg_bytes = 0.0, r->is_nan = 0;
-      if (!r->iterations) r->iterations_capacity = 0;
-      // dense_tracking.cpp:137-150
-      j.inc = cfg.use_initial_estimate ? se3_from_matrix(T_inits + 16 * (size_t)i) : SE3::identity();
-      j.initial = j.inc;
-      j.estimate = SE3::identity();
-      j.level = cfg.first_level;
-      j.done = false;
-      job_of_slot[sidx] = i;
-      start_level(j);
+  *ticket = b.id;
+  // start what can start without waiting: groups that have no tick in flight take pending pairs and launch
+  for (size_t g = 0; g < R.groups.size(); ++g)
+    if (!R.groups[g].in_flight) {
+      rc = runner_step(ctx, g);
+      if (rc) return runner_fail(ctx, rc);
     }
-    rc = submit_tick(ctx, jobs, grp);
-    if (rc) return drain(rc);
-  }
   return DVO_AMD_OK;
+}
+
+int dvo_amd_match_wait(dvo_amd_context *ctx, unsigned long long ticket) {
+  if (!ctx) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  if (!ctx->runner) return ticket == 0 ? DVO_AMD_OK : DVO_AMD_ERR_INVALID_ARGUMENT;
+  Runner &R = *ctx->runner;
+  if (ticket >= R.next_batch) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(ctx->device));
+  // ticket 0: everything submitted so far
+  auto open_batch = [&]() -> bool {
+    for (const Batch &b : R.batches)
+      if ((ticket == 0 || b.id == ticket) && b.remaining > 0) return true;
+    return false;
+  };
+  while (open_batch()) {
+    const size_t g = R.next_group;
+    R.next_group = (R.next_group + 1) % R.groups.size();
+    int rc = runner_step(ctx, g);
+    if (rc) return runner_fail(ctx, rc);
+  }
+  while (!R.batches.empty() && R.batches.front().remaining == 0) R.batches.pop_front();
+  if (R.failed_status != DVO_AMD_OK && ticket != 0 && ticket <= R.failed_upto) return R.failed_status;
+  return DVO_AMD_OK;
+}
+
+int dvo_amd_match_poll(dvo_amd_context *ctx, unsigned long long ticket, int *done) {
+  if (!ctx || !done) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  *done = 1;
+  if (!ctx->runner) return ticket == 0 ? DVO_AMD_OK : DVO_AMD_ERR_INVALID_ARGUMENT;
+  Runner &R = *ctx->runner;
+  if (ticket >= R.next_batch) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(ctx->device));
+  // advance every group whose tick has landed (or that has nothing in flight); never waits for the GPU
+  for (size_t g = 0; g < R.groups.size(); ++g) {
+    if (R.groups[g].in_flight && !tick_landed(ctx, R.jobs, R.groups[g])) continue;
+    int rc = runner_step(ctx, g);
+    if (rc) return runner_fail(ctx, rc);
+  }
+  for (const Batch &b : R.batches)
+    if ((ticket == 0 || b.id == ticket) && b.remaining > 0) *done = 0;
+  if (*done)
+    while (!R.batches.empty() && R.batches.front().remaining == 0) R.batches.pop_front();
+  if (R.failed_status != DVO_AMD_OK && ticket != 0 && ticket <= R.failed_upto) return R.failed_status;
+  return DVO_AMD_OK;
+}
+
+int dvo_amd_match_many(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *references, dvo_amd_pyramid *const *currents,
+                       const double *T_inits, dvo_amd_result *results, int max_in_flight) {
+  if (!ctx || n < 0 || (n > 0 && (!references || !currents || !results))) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  if (n == 0) return DVO_AMD_OK;
+  unsigned long long ticket = 0;
+  int rc = dvo_amd_match_submit(ctx, n, references, currents, T_inits, results, max_in_flight, &ticket);
+  if (rc) return rc;
+  return dvo_amd_match_wait(ctx, ticket);
 }
 
 int dvo_amd_match_batch(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *references, dvo_amd_pyramid *const *currents,
@@ -1897,13 +2053,17 @@ int dvo_amd_exchange_create(dvo_amd_context *ctx, int nranks, int rank, unsigned
   const size_t bytes = sizeof(FinWire) * 2 * (size_t)nranks;
   // fine-grained device memory: writes of other agents become visible to a running kernel (coarse-grained memory is only
   // coherent at kernel boundaries)
+  // (no fallback to hipMalloc: a running k_finalize would never see a peer's record there and every tick would end in the
+  // timeout -- the caller gets DVO_AMD_ERR_COMM here and uses the RCCL path, dvo_amd_comm_create, instead)
   hipError_t e = hipExtMallocWithFlags((void **)&ctx->xbuf, bytes, hipDeviceMallocFinegrained);
   if (e != hipSuccess) {
     ctx->xbuf = nullptr;
     (void)hipGetLastError();
-    e = hipMalloc((void **)&ctx->xbuf, bytes);
+    g_last_error = std::string("fine-grained device memory for the peer exchange is not available (") + hipGetErrorString(e) +
+                   "): use the RCCL exchange (dvo_amd_comm_create)";
+    return DVO_AMD_ERR_COMM;
   }
-  if (e == hipSuccess) e = hipMemset(ctx->xbuf, 0, bytes);
+  e = hipMemset(ctx->xbuf, 0, bytes);
   if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->x_host, sizeof(FinWire) * kMaxExchangeRanks, hipHostMallocMapped | hipHostMallocCoherent);
   if (e == hipSuccess) std::memset(ctx->x_host, 0, sizeof(FinWire) * kMaxExchangeRanks);
   if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->x_host_seq, 64, hipHostMallocMapped | hipHostMallocCoherent);
@@ -1975,14 +2135,20 @@ void dvo_amd_exchange_destroy(dvo_amd_context *ctx) {
   if (ctx->x_host) (void)hipHostFree(ctx->x_host);
   if (ctx->x_host_seq) (void)hipHostFree(ctx->x_host_seq);
   ctx->xbuf = nullptr, ctx->x_host = nullptr, ctx->x_host_seq = nullptr;
-  ctx->x_ranks = 0, ctx->x_seq = 0;
+  ctx->x_ranks = 0, ctx->x_seq = 0, ctx->x_broken = false;
 }
 
 int dvo_amd_match_sharded(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, const double *T_init,
                           dvo_amd_result *result) {
   if (!ctx || (!ctx->comm && ctx->x_ranks <= 0)) return DVO_AMD_ERR_COMM;
+  if (ctx->x_ranks > 0 && ctx->x_broken) {
+    g_last_error = "the peer exchange timed out earlier: destroy and re-create it on every rank";
+    return DVO_AMD_ERR_COMM;
+  }
   return match_one_banded(ctx, reference, current, T_init, result, ctx->comm_ranks, ctx->comm_rank, 1, true);
 }
+
+unsigned dvo_amd_debug_next_seq(unsigned seq) { return next_seq(seq); }
 
 int dvo_amd_debug_wire_layout(int *n_pieces, int *n_record_words) {
   if (!n_pieces || !n_record_words) return DVO_AMD_ERR_INVALID_ARGUMENT;
@@ -2069,11 +2235,9 @@ int single_tick(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyrami
   f.seg_prefix_out = s.seg_prefix[0];
   f.out = s.out;
   f.out_dev = nullptr;
-  fa.ticket = ctx->tickets;
-  f.seq = ++ctx->tick_seq;
+  f.seq = ctx->tick_seq = next_seq(ctx->tick_seq);
   if (residual_pass) {
     w.res_blocks = (uint16_t)nb;
-    w.res_phys = w.res_blocks;
     const float K[9] = {C.fx, 0.0f, C.ox, 0.0f, C.fy, C.oy, 0.0f, 0.0f, 1.0f};
     for (int i = 0; i < 3; ++i)
       for (int c = 0; c < 4; ++c)
@@ -2215,11 +2379,6 @@ int dvo_amd_bench_residual_pass_pairs(dvo_amd_context *ctx, int n_items, dvo_amd
   std::memset(&proto, 0, sizeof(proto));
   item_set_steps(proto, steps, 1);
   proto.res_blocks = (uint16_t)blocks_for(R.n, steps);
-  {
-    const long long total = (long long)proto.res_blocks * std::min(n_items, kMaxItemsPerLaunch);
-    const int walk = (int)std::min<long long>(8, std::max<long long>(1, total / ctx->phys_block_target));
-    proto.res_phys = (uint16_t)std::min<int>(proto.res_blocks, ((proto.res_blocks + walk - 1) / walk + 7) & ~7);
-  }
   proto.flags = 0;
   proto.P[0] = 1500.0f, proto.P[3] = 7000.0f;  // a typical precision: the weights take the non-trivial branch
   const int launches = (n_items + kMaxItemsPerLaunch - 1) / kMaxItemsPerLaunch;
@@ -2245,7 +2404,7 @@ int dvo_amd_bench_residual_pass_pairs(dvo_amd_context *ctx, int n_items, dvo_amd
           for (int cc = 0; cc < 4; ++cc)
             w.kt[r * 4 + cc] = (K[r * 3 + 0] * T[cc * 4 + 0] + K[r * 3 + 1] * T[cc * 4 + 1]) + K[r * 3 + 2] * T[cc * 4 + 2];
       }
-      hipError_t e = launch_tick(ta, proto.res_phys, ctx->stream, e0, e1);  // stamped by the dispatch itself
+      hipError_t e = launch_tick(ta, proto.res_blocks, ctx->stream, e0, e1);  // stamped by the dispatch itself
       if (e != hipSuccess) return fail_hip("launch_tick", e);
       HIP_TRY(hipEventSynchronize(e1));
       float ms = 0.0f;

@@ -64,7 +64,7 @@ struct TickItem {
   uint16_t res_first, ll_first;    // first logical block of the band (0 for the whole level)
   uint8_t steps_log2;              // 64-pixel steps per wave, log2: low nibble residual pass, high nibble log-likelihood pass
   uint8_t flags;                   // kItem* bits
-  uint16_t res_phys;               // physical blocks of the residual pass: block b walks logical blocks b, b + res_phys, ...
+  uint16_t reserved;
   int ll_cut_rank;                 // log-likelihood pass: keep valid pixels whose rank within the band is below this (Q6)
   float kt[12];                    // K * T[0:3,0:4], row-major, float (dense_tracking_impl.cpp:142-152)
   float P[4];                      // column-major 2x2 precision: of the iteration whose likelihood is evaluated, which is
@@ -108,15 +108,21 @@ struct FinOut {
 };
 static_assert(sizeof(FinOut) % 16 == 0, "FinOut is copied in 16-byte pieces");
 
-// How a record travels to the host: 16-byte pieces of three payload words and the tick's sequence number as a tag, each
-// written by one store instruction of one lane.  The host takes a piece with one aligned 16-byte load and accepts it when
-// the tag is the tick it waits for, so the kernel needs neither a fence behind the payload nor a separate "ready" word
-// behind the fence (that dependent chain was a quarter of k_finalize).
+// How a record travels to the host: 16-byte pieces, each written by one store instruction of one lane, made of two 8-byte
+// halves {payload word, tag} that each carry the tick's sequence number.  The host takes a piece with one aligned 16-byte
+// load and accepts it when BOTH tags are the tick it waits for, so the kernel needs neither a fence behind the payload nor a
+// separate "ready" word behind the fence (that dependent chain was a quarter of k_finalize).  What this rests on is the
+// single-copy atomicity of a naturally aligned 8-byte access, which x86-64, PCIe and xGMI guarantee; a 16-byte store that
+// arrives as two 8-byte halves at different times (never observed: scripts/probes/piece_atomicity.hip) only delays the
+// acceptance of the piece, it cannot pair a new tag with old payload.  The tag 0 is never used (buffers start zeroed).
 constexpr int kFinWords = (int)(sizeof(FinOut) / 4);
-constexpr int kFinWirePieces = (kFinWords + 2) / 3;
+constexpr int kFinWirePieces = (kFinWords + 1) / 2;
 struct alignas(16) FinWire {
-  unsigned piece[kFinWirePieces][4];  // {word 3i, word 3i+1, word 3i+2, tag}
+  unsigned piece[kFinWirePieces][4];  // {word 2i, tag, word 2i+1, tag}
 };
+// sequence numbers skip 0, the value of a fresh buffer; the wrap lands on 2 so that the parity -- the generation of an exchange
+// slot -- keeps alternating (... 0xFFFFFFFE, 0xFFFFFFFF, 2, 3 ...)
+inline unsigned next_seq(unsigned s) { return ++s == 0u ? 2u : s; }
 
 // ---- one-hop exchange of band records between the GPUs of a node (tile-sharded pairs) ------------------------------------
 // Every rank owns an exchange buffer of 2 x n_ranks record slots in fine-grained device memory that its peers have mapped
@@ -146,18 +152,16 @@ struct FinItem {
   unsigned seq;
   unsigned pad;
 };
-constexpr int kMaxFinItems = 48;  // 64 B each
+constexpr int kMaxFinItems = kMaxItemsPerLaunch;  // 64 B each: one reduce launch per tick launch
 struct FinArgs {
   int n_items;
   int pad;
-  unsigned *ticket;       // device word, zero between launches: arrival counter of this launch's blocks
   const struct ExchangeArgs *exchange;  // tile-sharded pair: push item 0's record to the peers, gather theirs (else null)
   unsigned xseq;          // sequence number of this tick's exchange
   unsigned pad2;
-  const FinItem *table;   // n_items items in device memory (uploaded in-stream with the tick's item table) instead of items[]
   FinItem items[kMaxFinItems];
 };
-static_assert(sizeof(FinArgs) <= 3800, "kernel argument block too large");
+static_assert(sizeof(FinArgs) <= 2400, "kernel argument block too large");
 
 // A tick of at most eight pairs (a single match(), the two-pair front-end step, small batches) goes out with argument blocks a tenth the size:
 // the runtime copies the kernel arguments into device-visible memory at every launch, and both launches sit on the critical
@@ -176,6 +180,8 @@ struct FinArgsSmall {
 };
 
 // ---- launch wrappers (dvo_kernels.hip) ----------------------------------------------------------------------------
+// Every wrapper takes the process-wide launch lock when DVO_AMD_LAUNCH_LOCK=1 (profiled multi-thread runs only: see
+// profiles/r03_rocprofv3_sigsegv_root_cause.md).
 // t_start / t_stop (both or neither): events that receive the begin / end time stamps of this dispatch itself
 // (hipExtLaunchKernelGGL), i.e. the kernel's own duration without the launch latency an event pair around it would add
 // grid: args.compact ? (args.group_first[n_items] * 8) blocks : (max_blocks rounded up to 8, n_items)
@@ -184,15 +190,11 @@ hipError_t launch_tick(const TickArgs &args, int max_blocks, hipStream_t stream,
 // fills group_first / compact from the items' block counts; returns the number of blocks of the compact grid
 int tick_args_layout(TickArgs &args, int max_blocks);
 int tick_args_layout(TickArgsSmall &args, int max_blocks);
-// the same kernels with the small argument blocks (only the default k_tick variant: returns hipErrorNotSupported when an
-// environment switch selected another one, and the caller falls back to the full-size launch)
+// the same kernels with the small argument blocks (only the default k_tick form: returns hipErrorNotSupported when
+// DVO_AMD_ACCUM=valu selected the register form, and the caller falls back to the full-size launch)
 hipError_t launch_tick_small(const TickArgsSmall &args, int max_blocks, hipStream_t stream, hipEvent_t t_start = nullptr,
                              hipEvent_t t_stop = nullptr);
 hipError_t launch_finalize_small(const FinArgsSmall &args, hipStream_t stream);
-// the same kernel reading its items from a device-resident table (more pairs per launch than the argument block holds)
-constexpr int kMaxTableItems = 288;
-hipError_t launch_tick_table(const TickItem *items_dev, int n_items, int max_blocks, hipStream_t stream,
-                             hipEvent_t t_start = nullptr, hipEvent_t t_stop = nullptr);
 hipError_t launch_finalize(const FinArgs &args, hipStream_t stream);
 hipError_t read_finalize_stamps(unsigned long long out[8]);
 

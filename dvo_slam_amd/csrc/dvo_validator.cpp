@@ -234,17 +234,28 @@ int worker_acquire(int device, const dvo_amd_config *cfg, dvo_amd_context **out)
   if (*out) return dvo_amd_configure(*out, cfg);
   return dvo_amd_context_create(device, cfg, out);
 }
-void worker_release(int device, dvo_amd_context *c) {
-  std::lock_guard<std::mutex> lock(worker_pool().mu);
-  worker_pool().idle[device].push_back(c);
+// A worker goes back to the pool only when its share succeeded (a context whose batch failed is destroyed: nothing of it
+// may be reused), and the pool keeps at most kMaxIdleWorkers contexts per device (each holds the scratch of its resident pairs).
+constexpr size_t kMaxIdleWorkers = 8;
+void worker_release(int device, dvo_amd_context *c, bool healthy) {
+  if (healthy) {
+    std::lock_guard<std::mutex> lock(worker_pool().mu);
+    std::vector<dvo_amd_context *> &idle = worker_pool().idle[device];
+    if (idle.size() < kMaxIdleWorkers) {
+      idle.push_back(c);
+      return;
+    }
+  }
+  dvo_amd_context_destroy(c);
 }
 int validator_threads() {
-  static int n = -1;
-  if (n < 0) {
+  static std::once_flag once;
+  static int n = 3;
+  std::call_once(once, [] {
     const char *e = getenv("DVO_AMD_VALIDATOR_THREADS");
     n = e ? atoi(e) : 3;
     n = n < 1 ? 1 : (n > 8 ? 8 : n);
-  }
+  });
   return n;
 }
 }  // namespace
@@ -355,7 +366,7 @@ int dvo_amd_validate_proposals(dvo_amd_context *ctx, int n_keyframes, const dvo_
             if (wrc[(size_t)w] != DVO_AMD_OK && rc == DVO_AMD_OK) rc = wrc[(size_t)w];
         }
         for (int w = 1; w < n_workers; ++w)
-          if (wctx[(size_t)w]) worker_release(device, wctx[(size_t)w]);
+          if (wctx[(size_t)w]) worker_release(device, wctx[(size_t)w], wrc[(size_t)w] == DVO_AMD_OK);
       }
       if (rc) break;
       for (size_t i = 0; i < n; ++i) {

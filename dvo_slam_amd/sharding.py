@@ -45,6 +45,32 @@ def aggregate(elapsed_s: float, n_pairs_local: int, dist=None, device=None) -> T
     return float(t.item()), int(n.item())
 
 
+def all_ranks(dist, value) -> list:
+    """Every rank's `value` in rank order (collective); a one-entry list without a process group."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [value]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, value)
+    return out
+
+
+def collective_stage(dist, fn, exc_type=Exception):
+    """Run fn() on every rank; the stage counts only if it succeeded on ALL ranks, so that every rank takes the same decision
+    (bench.py: the peer exchange of a tile-sharded pair falls back to RCCL when its set-up or its first tick fails anywhere).
+    Returns (fn's value or None, ok, reason): `reason` names the lowest rank that failed and is the same string on every rank."""
+    err = None
+    val = None
+    try:
+        val = fn()
+    except exc_type as exc:
+        err = str(exc) or type(exc).__name__
+    errs = all_ranks(dist, err)
+    bad = [(r, e) for r, e in enumerate(errs) if e]
+    if bad:
+        return None, False, f"rank {bad[0][0]}: {bad[0][1]}"
+    return val, True, None
+
+
 def split_for_threads(items: Sequence, n_threads: int) -> List[list]:
     """Deal a rank's items over its host threads (one tracker / HIP stream each)."""
     n_threads = max(1, min(n_threads, max(1, len(items))))
@@ -55,6 +81,13 @@ def split_for_threads(items: Sequence, n_threads: int) -> List[list]:
 # One-hop exchange of band records (tile-sharded pairs): the slot / tag protocol of exchange_records (csrc/dvo_kernels.hip),
 # restated on the host so that its ordering rules can be exercised without GPUs (tests/test_distributed.py).
 # ---------------------------------------------------------------------------------------------------------------------
+def next_seq(seq: int) -> int:
+    """Tick numbers of the exchange (csrc/dvo_types.h next_seq): 32 bits, 0 is never used (it is what a fresh buffer holds) and
+    the wrap lands on 2, so that the parity -- the generation of a slot -- keeps alternating."""
+    seq = (seq + 1) & 0xFFFFFFFF
+    return 2 if seq == 0 else seq
+
+
 def exchange_slot(seq: int, n_ranks: int, rank: int) -> int:
     """Slot of `rank`'s record of tick `seq` in every rank's exchange buffer: two generations of n_ranks slots."""
     return (seq & 1) * n_ranks + rank
@@ -62,16 +95,16 @@ def exchange_slot(seq: int, n_ranks: int, rank: int) -> int:
 
 class ExchangeBuffer:
     """One rank's exchange buffer over any writable (2 * n_ranks, pieces, 4) array (shared memory in the tests, fine-grained
-    device memory mapped by the peers on the GPUs).  A record travels as pieces of three payload words plus the tick number
-    as a tag, each piece written in one go: a piece is valid when its tag is the tick, so there is no "ready" word and no
+    device memory mapped by the peers on the GPUs).  A record travels as pieces of two halves {payload word, tick number},
+    each piece written in one go: a piece is valid when both its tags are the tick, so there is no "ready" word and no
     ordering between the pieces (csrc/dvo_types.h: FinWire)."""
 
-    PAYLOAD = 3
+    PAYLOAD = 2
 
     def __init__(self, array, n_ranks: int):
         self.a = array
         self.n = n_ranks
-        assert array.shape[0] == 2 * n_ranks and array.shape[2] == self.PAYLOAD + 1
+        assert array.shape[0] == 2 * n_ranks and array.shape[2] == 4
 
     @classmethod
     def pieces_for(cls, words: int) -> int:
@@ -82,17 +115,14 @@ class ExchangeBuffer:
         row = self.a[exchange_slot(seq, self.n, rank)]
         n = self.pieces_for(len(payload))
         for i in (range(n) if order is None else order):
-            piece = [0] * (self.PAYLOAD + 1)
-            chunk = payload[self.PAYLOAD * i:self.PAYLOAD * (i + 1)]
-            piece[:len(chunk)] = chunk
-            piece[self.PAYLOAD] = seq
-            row[i] = piece  # one store per piece
+            chunk = list(payload[self.PAYLOAD * i:self.PAYLOAD * (i + 1)]) + [0]
+            row[i] = [chunk[0], seq, chunk[1], seq]  # one store per piece
 
     def ready(self, seq: int, words: int) -> bool:
         n = self.pieces_for(words)
-        return all(all(int(t) == seq for t in self.a[exchange_slot(seq, self.n, r), :n, self.PAYLOAD]) for r in range(self.n))
+        return all(all(int(t) == seq for t in self.a[exchange_slot(seq, self.n, r), :n, 1::2].reshape(-1)) for r in range(self.n))
 
     def collect(self, seq: int, words: int):
         """the n records of tick `seq` in rank order (call once ready(seq, words))"""
         n = self.pieces_for(words)
-        return [self.a[exchange_slot(seq, self.n, r), :n, :self.PAYLOAD].reshape(-1)[:words].copy() for r in range(self.n)]
+        return [self.a[exchange_slot(seq, self.n, r), :n, 0::2].reshape(-1)[:words].copy() for r in range(self.n)]

@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define DVO_AMD_MAX_LEVELS 8
-#define DVO_AMD_ABI_VERSION 1
+#define DVO_AMD_ABI_VERSION 2
 
 typedef enum {
   DVO_AMD_OK = 0,
@@ -107,6 +107,7 @@ typedef struct {
   int n_ticks;                              /* host<->device round trips spent */
   int n_residual_passes;                    /* fused warp+residual+normal-equation launches (incl. discarded speculative ones) */
   double alg_bytes;                         /* 56 B x selected points x residual passes */
+  double alg_bytes_discarded;               /* the part of alg_bytes spent on speculative passes whose iteration was rolled back */
 } dvo_amd_result;
 
 typedef struct dvo_amd_context dvo_amd_context; /* one DenseTracker instance: one HIP stream + scratch; NOT thread-safe */
@@ -192,6 +193,25 @@ int dvo_amd_match_many(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *refe
                        const double *T_inits, dvo_amd_result *results, int max_in_flight);
 
 /*
+ * The same queue without draining between calls.  A tracker that works through proposals as they come (the loop-closure
+ * validator's tbb::parallel_reduce with grain 1 over a proposal list, keyframe_graph.cpp:587-590, called again for every new
+ * keyframe, :434-498) keeps `max_in_flight` pairs resident ACROSS calls: dvo_amd_match_submit appends n pairs to the
+ * context's queue and returns at once (pairs start as soon as a slot is free), dvo_amd_match_wait drives the queue until every
+ * pair of that submission is finished (ticket 0: everything submitted so far), dvo_amd_match_poll advances whatever has
+ * landed without waiting for the GPU and reports whether the submission is complete.  dvo_amd_match_many(...) is
+ * submit + wait.  Contract: one host thread per context, as for every entry point; `results` (and their iteration arrays)
+ * stay valid and untouched until the submission is complete; the queue retains the pyramids itself; the tracker's
+ * configuration must not change while pairs are queued (dvo_amd_configure refuses); a different max_in_flight or larger
+ * frames than the queue was laid out for let the queued pairs run to completion first.  Results are those of n dvo_amd_match()
+ * calls.  If a tick fails, every queued pair is dropped, nothing of the context is running any more when the error is
+ * returned, and the wait / poll of each dropped submission returns that status.
+ */
+int dvo_amd_match_submit(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *references, dvo_amd_pyramid *const *currents,
+                         const double *T_inits, dvo_amd_result *results, int max_in_flight, unsigned long long *ticket);
+int dvo_amd_match_wait(dvo_amd_context *ctx, unsigned long long ticket);
+int dvo_amd_match_poll(dvo_amd_context *ctx, unsigned long long ticket, int *done);
+
+/*
  * One pair tile-sharded over several GPUs (BASELINE config 4).  Every rank holds both pyramids and processes one band of
  * scan-order blocks of every level; per Gauss-Newton tick the ranks all-gather one 784-byte record per band over RCCL and
  * combine them left to right, so every rank runs the identical state machine and returns the identical result.
@@ -221,12 +241,15 @@ int dvo_amd_match_banded(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_a
  * -> {valid, S[3], S_odd[3]}; exported for the CPU tests of the multi-GPU path */
 int dvo_amd_debug_combine_bands(int n_bands, const double *bands, double *out);
 /* host-only: the receiving side of the record hand-off.  A tick's 784-byte record reaches the host (and, for a sharded pair,
- * the peers) as `*n_pieces` pieces of 16 bytes -- three payload words and the tick number -- each written by one store of
- * the device; a piece counts when its tag is the tick waited for, in whatever order the pieces arrive.
+ * the peers) as `*n_pieces` pieces of 16 bytes -- two 8-byte halves {payload word, tick number} -- each written by one store
+ * of the device; a piece counts when BOTH its tags are the tick waited for, in whatever order the pieces arrive (so a piece
+ * that should ever arrive as two 8-byte halves is simply not accepted until both are there).
  * dvo_amd_debug_wire_layout reports the piece and payload-word counts; dvo_amd_debug_take_wire copies the payload of the
  * pieces from `from_piece` on that carry `tick` out of `wire` (16-byte aligned, 4 words per piece) into `record_words`
  * and returns the index of the first piece that does not (n_pieces when the record is complete), or minus an error code.
  * Exported for the CPU tests. */
+/* host-only: the successor of a tick number (32 bits; never 0, the value of a fresh buffer; the wrap keeps the parity alternating) */
+unsigned dvo_amd_debug_next_seq(unsigned seq);
 int dvo_amd_debug_wire_layout(int *n_pieces, int *n_record_words);
 int dvo_amd_debug_take_wire(const unsigned *wire, unsigned tick, int from_piece, unsigned *record_words);
 

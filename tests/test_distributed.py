@@ -72,6 +72,72 @@ def test_two_gloo_ranks_partition_and_aggregate():
         assert weak == [[0, 1, 2, 3, 4], [5, 6, 7, 8, 9]]
 
 
+def _fallback_worker(rank, world, port, out_q):
+    import torch.distributed as dist
+
+    from dvo_slam_amd import sharding
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    class CommError(RuntimeError):
+        pass
+
+    log = []
+    # stage 1 succeeds everywhere; stage 2 (the attach) fails on rank 1 only; a third stage would only run after a success
+    handle, ok, why = sharding.collective_stage(dist, lambda: f"handle-of-{rank}", CommError)
+    log.append((ok, why, sharding.all_ranks(dist, handle)))
+
+    def attach():
+        if rank == 1:
+            raise CommError("hipIpcOpenMemHandle: invalid argument")
+        return "attached"
+    val, ok, why = sharding.collective_stage(dist, attach, CommError)
+    log.append((val, ok, why))
+    used = "peer" if ok else "rccl"  # bench.py's decision
+    # an exception of another type is not a reason to fall back: it propagates (here: caught to report it)
+    try:
+        sharding.collective_stage(dist, lambda: 1 // 0 if rank == 0 else 1, CommError)
+        other = None
+    except ZeroDivisionError:
+        other = "raised"
+        sharding.all_ranks(dist, None)  # keep the collective of the surviving rank company
+    out_q.put((rank, log, used, other))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_gloo_ranks_agree_on_the_exchange_fallback():
+    """bench.py --gpus N measures BASELINE config 4 with the one-hop peer exchange when it comes up on every rank and falls back
+    to the RCCL all-gather otherwise: a failure on ONE rank (allocation, hipIpc attach, first-tick timeout) must make EVERY rank
+    fall back, with the same reason, or the ranks would wait for each other in different protocols."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 2
+    procs = [ctx.Process(target=_fallback_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict((r, rest) for r, *rest in (q.get(timeout=120) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        log, used, other = results[rank]
+        assert log[0] == (True, None, ["handle-of-0", "handle-of-1"])
+        assert log[1] == (None, False, "rank 1: hipIpcOpenMemHandle: invalid argument")  # also on rank 0, whose attach worked
+        assert used == "rccl"
+    assert results[0][2] == "raised" and results[1][2] is None
+    # without a process group the stage is just a try / except
+    from dvo_slam_amd import sharding
+
+    assert sharding.collective_stage(None, lambda: 5) == (5, True, None)
+    assert sharding.collective_stage(None, lambda: [][1], IndexError)[1:] == (False, "rank 0: list index out of range")
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # tile-shard exchange: the ordered combine of band records (host code of the multi-GPU path)
 # ---------------------------------------------------------------------------------------------------------------------
@@ -220,6 +286,23 @@ def test_exchange_slots_never_collide_within_one_tick_of_lead():
         assert mine == {sharding.exchange_slot(seq + 2, n, r) for r in range(n)}  # ... and two ticks ahead cannot happen
 
 
+def test_tick_numbers_skip_zero_and_keep_alternating_generations_across_the_wrap():
+    """a 32-bit tick counter wraps after ~27 h of single-pair tracking; 0 is what a fresh wire buffer holds, so
+    it must never be a tick, and the two generations of the exchange must keep alternating across the wrap."""
+    from dvo_slam_amd import capi, sharding
+
+    seq = 0xFFFFFFFC
+    seen = []
+    for _ in range(8):
+        nxt = sharding.next_seq(seq)
+        assert nxt == capi.lib().dvo_amd_debug_next_seq(seq)  # the library's counter and its host restatement agree
+        assert nxt != 0 and (nxt & 1) != (seq & 1)
+        seen.append(nxt)
+        seq = nxt
+    assert seen == [0xFFFFFFFD, 0xFFFFFFFE, 0xFFFFFFFF, 2, 3, 4, 5, 6]
+    assert sharding.next_seq(0) == 1 == capi.lib().dvo_amd_debug_next_seq(0)
+
+
 def _exchange_worker(rank, world, port, shm_paths, out_q):
     import time
 
@@ -270,7 +353,7 @@ def test_two_gloo_ranks_run_the_exchange_protocol(tmp_path):
     paths = []
     for r in range(world):
         pth = str(tmp_path / f"xbuf{r}.bin")
-        np.zeros((2 * world, 4, 4), np.float64).tofile(pth)  # 10 words = 4 pieces of 3 + tag
+        np.zeros((2 * world, 5, 4), np.float64).tofile(pth)  # 10 words = 5 pieces of two {word, tag} halves
         paths.append(pth)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

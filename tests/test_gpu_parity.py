@@ -763,25 +763,74 @@ def test_speculative_level_start_gives_the_same_results(capi, synth, pair640, mo
     assert all(synth.pose_error(ref.Transformation, o.Transformation) <= POSE_TOL for o in batch)
 
 
-def test_item_table_launches_give_the_same_results(capi, synth, pair640, monkeypatch):
-    """DVO_AMD_ITEMS_PER_LAUNCH > 36: the work items of a tick go through a device-resident table uploaded in-stream instead
-    of the kernel arguments (up to 288 pairs per launch)."""
-    monkeypatch.setenv("DVO_AMD_ITEMS_PER_LAUNCH", "100")
-    table = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0))
-    monkeypatch.delenv("DVO_AMD_ITEMS_PER_LAUNCH")
-    plain = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0))
-    n = 230  # three launches of <= 100 pairs per tick, then a shrinking tail
-    refs = [pair640["gr"] if i % 2 else pair640["gc"] for i in range(n)]
-    curs = [pair640["gc"] if i % 2 else pair640["gr"] for i in range(n)]
-    out = table.match_batch(refs, curs, stats=False, raw=True)
+def test_queue_keeps_pairs_resident_across_submissions(capi, synth, pair640):
+    """dvo_amd_match_submit / _wait / _poll: pairs queued while the tracker is still working enter the slots that open up, so
+    the tracker never drains between submissions (the shape of tbb::parallel_reduce over a proposal list that keeps growing,
+    keyframe_graph.cpp:587-590).  Every result is the one a single match() gives."""
+    cfg = capi.Config(FirstLevel=3, LastLevel=0)
+    trk, plain = capi.DenseTracker(cfg), capi.DenseTracker(cfg)
     fwd, bwd = plain.match(pair640["gr"], pair640["gc"]), plain.match(pair640["gc"], pair640["gr"])
-    for i in range(n):
-        T = np.array(out[i].transformation[:]).reshape(4, 4).T
-        assert synth.pose_error((fwd if i % 2 else bwd).Transformation, T) <= POSE_TOL
-    rolling = table.match_batch(refs, curs, stats=False, in_flight=150, raw=True)  # two groups of 75, both table launches
-    for i in range(n):
-        T = np.array(rolling[i].transformation[:]).reshape(4, 4).T
-        assert synth.pose_error((fwd if i % 2 else bwd).Transformation, T) <= POSE_TOL
+
+    def pairs(n, phase):
+        refs = [pair640["gr"] if (i + phase) % 2 else pair640["gc"] for i in range(n)]
+        curs = [pair640["gc"] if (i + phase) % 2 else pair640["gr"] for i in range(n)]
+        return refs, curs
+
+    def check(results, n, phase):
+        for i in range(n):
+            want = fwd if (i + phase) % 2 else bwd
+            assert synth.pose_error(want.Transformation, results[i].Transformation) <= POSE_TOL
+
+    # three submissions back to back, 40 resident pairs (two groups): the second and third are queued while the first runs
+    subs = [trk.submit(*pairs(n, ph), in_flight=40) for n, ph in ((50, 0), (7, 1), (90, 0))]
+    ticks_before_wait = sum(r.n_ticks for r in subs[0].results(raw=True))
+    assert ticks_before_wait > 0  # submit() started the work without waiting for it
+    check(trk.wait(subs[1]), 7, 1)      # out of order: the small one in the middle first
+    check(trk.wait(subs[0]), 50, 0)
+    # poll never waits for the GPU; it completes the submission all the same
+    spins = 0
+    while not trk.poll(subs[2]):
+        spins += 1
+        assert spins < 10_000_000
+    check(subs[2].results(), 90, 0)
+    assert trk.poll() and trk.wait() is None  # nothing left: ticket 0 = "everything submitted so far"
+    # an empty submission is complete at once; match_many (= submit + wait) still works on the same tracker afterwards
+    assert trk.poll(trk.submit([], [], in_flight=40))
+    check(trk.match_batch(*pairs(9, 1), in_flight=40), 9, 1)
+    # a different residency lets what is queued finish in the old layout first, then re-lays the tracker out
+    a = trk.submit(*pairs(30, 0), in_flight=40)
+    b = trk.submit(*pairs(30, 1), in_flight=12)
+    check(trk.wait(b), 30, 1)
+    check(trk.wait(a), 30, 0)
+    # the configuration is frozen while pairs are queued
+    c = trk.submit(*pairs(20, 0), in_flight=12)
+    with pytest.raises(capi.DvoAmdError):
+        trk.configure(capi.Config(FirstLevel=3, LastLevel=1))
+    check(trk.wait(c), 20, 0)
+    trk.configure(capi.Config(FirstLevel=3, LastLevel=1))
+    assert len(trk.match(pair640["gr"], pair640["gc"]).Levels) == 3
+
+
+def test_queue_holds_its_own_pyramid_references(capi, synth):
+    """The queue retains the pyramids of a submission: the caller may drop its handles right after submitting (the reference's
+    callers hand boost::shared_ptr copies to their TBB tasks the same way, keyframe_graph.cpp:576-593)."""
+    (Ir, Zr), (Ic, Zc), Tgt = synth.make_pair(320, 240, xi_gt=synth.XI_GT_PAIR * 0.5)
+    K = synth.intrinsics_for(320, 240)
+    cfg = capi.Config(FirstLevel=2, LastLevel=0)
+    trk = capi.DenseTracker(cfg)
+    ref, cur = capi.RgbdImagePyramid(Ir, Zr, K, 3), capi.RgbdImagePyramid(Ic, Zc, K, 3)
+    want = capi.DenseTracker(cfg).match(ref, cur)
+    sub = trk.submit([ref] * 12, [cur] * 12, in_flight=4)
+    del ref, cur
+    for r in trk.wait(sub):
+        assert synth.pose_error(want.Transformation, r.Transformation) <= POSE_TOL
+    # a tracker destroyed with pairs still queued stops its kernels and gives the pyramids back
+    ref, cur = capi.RgbdImagePyramid(Ir, Zr, K, 3), capi.RgbdImagePyramid(Ic, Zc, K, 3)
+    doomed = capi.DenseTracker(cfg)
+    keep = doomed.submit([ref] * 30, [cur] * 30, in_flight=4)
+    del doomed
+    assert keep.n == 30
+    assert synth.pose_error(want.Transformation, capi.DenseTracker(cfg).match(ref, cur).Transformation) <= POSE_TOL
 
 
 def test_small_argument_blocks_change_nothing(capi, synth, pair640, monkeypatch):
