@@ -641,15 +641,28 @@ __device__ void loglik_pass(const TickItem &it, const LevelPairDesc &d, const in
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
   const int seg = lb * kWavesPerBlock + wave;
+  // Merged segments (kItemLlMerge): a likelihood wave covers `merge` consecutive wave segments of the residual pass that filled
+  // the buffer (a likelihood step is a tenth of a residual step's work: segments as short as the residual pass's make blocks
+  // that are all prologue and hold a block slot for it).  The prefix table is indexed by residual segments; segments past the
+  // end of that pass were not written in this iteration and are not read.
+  const bool merged = (it.flags & kItemLlMerge) != 0;
+  const int merge = merged ? (int)it.reserved : 1;
+  const int res_segs_left = merged ? (int)it.ll_first * kWavesPerBlock - seg * merge : merge;
+  int steps = item_ll_steps(it);
+  if (merged) {
+    const int sub = steps / merge;  // steps of one residual segment
+    steps = res_segs_left >= merge ? steps : (res_segs_left > 0 ? res_segs_left * sub : 0);
+  }
   // valid pixels of this band that precede the segment (written by k_finalize of the residual pass that filled the buffer)
-  const int seg_before = ((const DVO_GLOBAL int *)((it.flags & kItemLlBuf) ? d.seg_prefix[1] : d.seg_prefix[0]))[seg];
+  const int seg_before =
+      steps > 0 ? ((const DVO_GLOBAL int *)((it.flags & kItemLlBuf) ? d.seg_prefix[1] : d.seg_prefix[0]))[seg * merge] : 0;
   const int cut_rank = it.ll_cut_rank;
   const float P0 = it.P[0], P1 = it.P[1], P2 = it.P[2], P3 = it.P[3];
   const unsigned long long below = (1ull << lane) - 1ull;
   double total = 0.0;
-  if (seg_before < cut_rank) {
-    const int steps = item_ll_steps(it);
-    const DVO_GLOBAL v2f *src = (const DVO_GLOBAL v2f *)((it.flags & kItemLlBuf) ? d.res[1] : d.res[0]) + seg * (kStepPx * steps) + lane;
+  if (steps > 0 && seg_before < cut_rank) {
+    const DVO_GLOBAL v2f *src =
+        (const DVO_GLOBAL v2f *)((it.flags & kItemLlBuf) ? d.res[1] : d.res[0]) + seg * (kStepPx * item_ll_steps(it)) + lane;
     int run_count = seg_before;
     // up to four steps (256 pixels) per trip; one log per lane of the product of up to 16 terms (four trips), like the
     // reference takes one log per 50 residuals (dense_tracking_impl.cpp:415-419): a term is 1 + 0.2 r^T P r >= 1, and
@@ -661,10 +674,10 @@ __device__ void loglik_pass(const TickItem &it, const LevelPairDesc &d, const in
       v2f r[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if (k < per_trip) r[k] = src[(step + k) * kWave];
+        if (k < per_trip && step + k < steps) r[k] = src[(step + k) * kWave];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if (k >= per_trip) break;
+        if (k >= per_trip || step + k >= steps) break;
         const bool valid = r[k].x == r[k].x;
         if (all_below_cut) {  // only the segment(s) around rank 50 * floor(V / 50) need ranks: Q6 drops at most 49 residuals
           if (valid) {
@@ -731,7 +744,7 @@ __device__ __forceinline__ void tick_body(const TickItem &it, const int bx) {
   if (bx < rb)
     residual_pass<ACC>(it, d, it.res_first + xcd_contiguous_block(bx, rb));
   else
-    loglik_pass(it, d, it.ll_first + (bx - rb));
+    loglik_pass(it, d, ((it.flags & kItemLlMerge) ? 0 : (int)it.ll_first) + (bx - rb));
 }
 
 // Which item owns this block, and which of the item's blocks is it?  Two-dimensional grid: (block, item).  One-dimensional

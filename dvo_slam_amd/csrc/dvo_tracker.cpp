@@ -447,6 +447,7 @@ struct dvo_amd_context {
   SlotDesc *slot_desc = nullptr;       // device, [slot]
   Runner *runner = nullptr;            // resident pairs + pending queue (dvo_amd_match_submit / _wait, dvo_amd_match_many)
   int items_per_launch = kMaxItemsPerLaunch;           // DVO_AMD_ITEMS_PER_LAUNCH (<= kMaxItemsPerLaunch: tuning)
+  int ll_merge = 4;                                    // residual wave segments per likelihood wave segment (DVO_AMD_LL_MERGE=1|2|4|8)
   int spec_levels = -1;                                // start the next level speculatively in the tick of a level's last
                                                        // likelihood: -2..3 ticks per pair, but a converged level's last likelihood is
                                                        // rejected about half the time (+3 % residual work).  -1 (default): only
@@ -1061,18 +1062,27 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
     f.records = nullptr, f.n_blocks = 0, f.block_first = 0, f.n_ll_blocks = 0, f.ll_first = 0;
     f.ll_partials = j.slot->ll_partials;
     f.seg_prefix_out = j.slot->seg_prefix[0], f.out = j.slot->out, f.out_dev = nullptr, f.seq = seq, f.pad = 0;
-    if (j.have_a) {
-      w.ll_blocks = (uint16_t)j.a.n_blocks;
-      ll_steps = j.a.steps;
-      if (j.a.buf) w.flags |= kItemLlBuf;
-      w.ll_cut_rank = j.a.cut_rank;
-      f.n_ll_blocks = w.ll_blocks;
-      j.sub_ll = true;
-    }
     if (j.have_b) {
       j.b.steps = steps_now;
       while (j.b.steps < kMaxSteps && blocks_for(j.ref->lv[j.level].n, j.b.steps) > 2048) j.b.steps *= 2;
       j.b.n_blocks = blocks_for(j.ref->lv[j.level].n, j.b.steps);
+    }
+    if (j.have_a) {
+      if (j.a.buf) w.flags |= kItemLlBuf;
+      w.ll_cut_rank = j.a.cut_rank;
+      // the likelihood blocks walk the residuals in merged wave segments: up to ll_merge residual segments per wave (not for
+      // small ticks: a single pair wants many short blocks).  Measured: 45.8k -> 48.1k pairs/s at 4; folding the likelihood
+      // into the residual-pass waves of the next iteration instead (no likelihood blocks at all) gave nothing on top of it and
+      // cost 22 registers and 5 % single-pair latency
+      int merge = 1;
+      while (active_pairs > kSpecLevelsMaxPairs && merge < ctx->ll_merge && j.a.steps * merge * 2 <= kMaxSteps) merge *= 2;
+      w.ll_blocks = (uint16_t)((j.a.n_blocks + merge - 1) / merge);
+      ll_steps = j.a.steps * merge;
+      if (merge > 1) w.flags |= kItemLlMerge, w.ll_first = (uint16_t)j.a.n_blocks, w.reserved = (uint16_t)merge;
+      f.n_ll_blocks = w.ll_blocks;
+      j.sub_ll = true;
+    }
+    if (j.have_b) {
       w.res_blocks = (uint16_t)j.b.n_blocks;
       res_steps = j.b.steps;
       if (j.b.buf) w.flags |= kItemResBuf;
@@ -1700,6 +1710,10 @@ int dvo_amd_context_create(int device, const dvo_amd_config *cfg, dvo_amd_contex
   if (const char *fs2 = getenv("DVO_AMD_FAULT_SLOT_ALLOC")) ctx->fault_slot_alloc = atoi(fs2);
   if (const char *sa = getenv("DVO_AMD_STEPS_AT"))
     (void)sscanf(sa, "%lld,%lld,%lld,%lld", &ctx->steps_at[0], &ctx->steps_at[1], &ctx->steps_at[2], &ctx->steps_at[3]);
+  if (const char *lm = getenv("DVO_AMD_LL_MERGE")) {
+    const int v = atoi(lm);
+    if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ctx->ll_merge = v;
+  }
   if (const char *ipl = getenv("DVO_AMD_ITEMS_PER_LAUNCH")) {
     const int v = atoi(ipl);
     if (v >= 1 && v <= kMaxItemsPerLaunch) ctx->items_per_launch = v;

@@ -61,10 +61,11 @@ struct TickItem {
   const CurLevelDesc *cur;
   const SlotDesc *slot;
   uint16_t res_blocks, ll_blocks;  // blocks this item runs (a band of the level when the pair is sharded), <= 2048 each
-  uint16_t res_first, ll_first;    // first logical block of the band (0 for the whole level)
+  uint16_t res_first, ll_first;    // first logical block of the band (0 for the whole level); with kItemLlMerge ll_first is
+                                   // instead the number of blocks of the residual pass that filled the buffer
   uint8_t steps_log2;              // 64-pixel steps per wave, log2: low nibble residual pass, high nibble log-likelihood pass
   uint8_t flags;                   // kItem* bits
-  uint16_t reserved;
+  uint16_t reserved;               // kItemLlMerge: residual wave segments per likelihood wave segment (a power of two)
   int ll_cut_rank;                 // log-likelihood pass: keep valid pixels whose rank within the band is below this (Q6)
   float kt[12];                    // K * T[0:3,0:4], row-major, float (dense_tracking_impl.cpp:142-152)
   float P[4];                      // column-major 2x2 precision: of the iteration whose likelihood is evaluated, which is
@@ -81,6 +82,7 @@ inline void item_set_steps(TickItem &it, int res_steps, int ll_steps) {
 constexpr unsigned kItemResBuf = 1;       // which residual buffer the residual pass writes
 constexpr unsigned kItemLlBuf = 2;        // which residual buffer the log-likelihood pass reads
 constexpr unsigned kItemUnitWeights = 4;  // first iteration on a level: weights = 1 (dense_tracking.cpp:286-289)
+constexpr unsigned kItemLlMerge = 8;      // the likelihood pass runs merged wave segments (see loglik_pass)
 static_assert(sizeof(TickItem) == 104, "TickItem is packed to fit many items into one kernel-argument block");
 
 constexpr int kMaxItemsPerLaunch = 36;
