@@ -47,7 +47,7 @@ class CIterationStats(C.Structure):
     _fields_ = [("id", C.c_int), ("valid_constraints", C.c_int), ("tdist_loglik", C.c_double),
                 ("tdist_mean", C.c_double * 2), ("tdist_precision", C.c_double * 4), ("prior_loglik", C.c_double),
                 ("increment", C.c_double * 6), ("information", C.c_double * 36), ("has_increment", C.c_int),
-                ("reserved", C.c_int)]
+                ("reserved", C.c_int), ("estimate", C.c_double * 16), ("initial", C.c_double * 16)]
 
 
 class CLevelStats(C.Structure):
@@ -344,6 +344,8 @@ class Result:
                     "PriorLogLikelihood": it.prior_loglik, "has_increment": bool(it.has_increment),
                     "EstimateIncrement": np.array(it.increment[:]),
                     "EstimateInformation": np.array(it.information[:]).reshape(6, 6).T.copy(),
+                    "estimate": np.array(it.estimate[:]).reshape(4, 4).T.copy(),  # instrumentation, not a reference field
+                    "initial": np.array(it.initial[:]).reshape(4, 4).T.copy(),    # likewise
                 })
             self.Levels.append({"Id": L.id, "MaxValidPixels": L.max_valid_pixels, "ValidPixels": L.valid_pixels,
                                 "TerminationCriterion": L.termination, "Iterations": iters})

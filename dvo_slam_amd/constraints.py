@@ -41,7 +41,8 @@ class CVote(C.Structure):
 
 class CProposal(C.Structure):
     _fields_ = [("reference", C.c_int), ("current", C.c_int), ("initial_transformation", C.c_double * 16),
-                ("tracking_result", capi.CResult), ("n_votes", C.c_int), ("votes", CVote * MAX_VOTERS)]
+                ("tracking_result", capi.CResult), ("n_votes", C.c_int), ("votes", CVote * MAX_VOTERS),
+                ("origin", C.c_int), ("reserved", C.c_int)]
 
 
 _bound = False
@@ -257,6 +258,7 @@ class ConstraintProposalValidator:
                                    np.array(c.initial_transformation[:]).reshape(4, 4).T)
             p.TrackingResult = capi.Result(c.tracking_result, None)
             p.Votes = [Vote(c.votes[k]) for k in range(c.n_votes)]
+            p.origin = c.origin  # instrumentation: index of the input proposal it descends from, -(i + 1) for its inverse
             out.append(p)
         proposals[:] = out
         return proposals

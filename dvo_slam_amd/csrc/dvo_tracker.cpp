@@ -721,6 +721,8 @@ float loglik_from_sum(int n, const float P[4], double ll_sum) {
 void process_residual(Job &j, IterCtx &it, const FinOut &o) {
   dvo_amd_iteration_stats *e = stats_push(j);
   e->id = it.k;
+  se3_matrix(it.estimate_after, e->estimate);
+  se3_matrix(it.initial_after, e->initial);
   it.n = o.valid;
   it.cut_rank = 50 * (it.n / 50);
   e->valid_constraints = it.n;

@@ -288,6 +288,7 @@ int dvo_amd_validate_proposals(dvo_amd_context *ctx, int n_keyframes, const dvo_
     live[(size_t)i].p = proposals[i];
     live[(size_t)i].p.tracking_result.iterations = nullptr;
     live[(size_t)i].p.tracking_result.iterations_capacity = 0;
+    live[(size_t)i].p.origin = i, live[(size_t)i].p.reserved = 0;
     live[(size_t)i].uid = next_uid++;
   }
 
@@ -310,6 +311,7 @@ int dvo_amd_validate_proposals(dvo_amd_context *ctx, int n_keyframes, const dvo_
         inv.p.reference = live[idx].p.current, inv.p.current = live[idx].p.reference;  // createInverseProposal, :88-96
         const Mat4 init = affine_inverse(mat4_load(live[idx].p.initial_transformation));
         std::memcpy(inv.p.initial_transformation, init.m, sizeof(init.m));
+        inv.p.origin = -(live[idx].p.origin + 1);  // the inverse of input i is -(i + 1), the inverse of that i again
         inv.uid = next_uid++;
         pairs[(size_t)v].emplace_back(live[idx].uid, inv.uid);
         live.push_back(inv);

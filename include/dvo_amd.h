@@ -80,6 +80,10 @@ typedef struct {
   double information[36];     /* EstimateInformation; valid if has_increment */
   int has_increment;          /* 0 for the iteration a level broke out of (TooFewConstraints / LogLikelihoodDecreased) */
   int reserved;
+  /* instrumentation (not in the reference): estimate().matrix() of this iteration, column-major 4x4 -- the transform whose
+   * float cast the residual stage used (dense_tracking.cpp:263).  The parity tests replay single iterations from it. */
+  double estimate[16];
+  double initial[16];         /* likewise initial() of this iteration (dense_tracking.cpp:260,302,346: the prior term) */
 } dvo_amd_iteration_stats;
 
 /* DenseTracker::LevelStats, dense_tracking.h:103-116 */
@@ -314,6 +318,11 @@ typedef struct {
   dvo_amd_result tracking_result;  /* of the last stage the proposal went through; iterations is ignored (set to NULL) */
   int n_votes;
   dvo_amd_vote votes[DVO_AMD_MAX_VOTERS];
+  /* instrumentation (not in the reference), out only: which input proposal a survivor descends from -- its index i in the
+   * array passed to dvo_amd_validate_proposals, or -(i + 1) if it is that proposal's cross-validation inverse.  Lets a checker
+   * compare a survivor with the alignment of the SAME (reference, current, initial transformation) on its own side. */
+  int origin;
+  int reserved;
 } dvo_amd_constraint_proposal;
 
 /* the two stages KeyframeGraph builds (keyframe_graph.cpp:500-523) with the tracker configs of configureValidationTracking

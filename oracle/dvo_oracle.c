@@ -68,6 +68,8 @@ void orc_default_config(orc_config *c) {
   c->intensity_derivative_threshold = 0.0f;
   c->depth_derivative_threshold = 0.0f;
   c->rcp_mode = ORC_RCP_SSE;
+  c->sum_mode = ORC_SUM_REFERENCE;
+  c->ll_guard = 0;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -425,11 +427,21 @@ static void tdist_weights(const float *res, int n, const float *P, int rcp_mode,
     w[i] = (float)((2.0 + 5.0f) / (5.0f + mahalanobis(res + 2 * i, P)));
 }
 
+/* test instrumentation: the summation order of orc_match on this thread (orc_config.sum_mode); every other entry point
+ * sums like the reference */
+static __thread int g_sum_mode = ORC_SUM_REFERENCE;
+static __thread int g_ll_guard = 0; /* orc_config.ll_guard of the orc_match running on this thread */
+/* partial sums over this many consecutive points (ORC_SUM_BLOCKED: 256, ORC_SUM_BLOCKED_32: 32, ORC_SUM_BLOCKED_2048: 2048) */
+static int sum_block(void) { return g_sum_mode == ORC_SUM_BLOCKED_32 ? 32 : g_sum_mode == ORC_SUM_BLOCKED_2048 ? 2048 : 256; }
+static int sum_blocked(void) { return g_sum_mode >= ORC_SUM_BLOCKED; }
+
 /* computeScaleSse, dense_tracking_impl.cpp:590-638, including Q5 (first residual of a pair used twice) */
 static void tdist_scale(const float *res, int n, const float *w, float cov[4], int clean) {
   const int n2 = n - (n % 2);
   const float scale = 1.0f / (float)(size_t)(n - 2 - 1);
   float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  double acc64[4] = {0.0, 0.0, 0.0, 0.0};
+  float blk[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   for (int i = 0; i < n2; i += 2) {
     const float x = res[2 * i], y = res[2 * i + 1];
     const float f[4] = {x * x, y * x, x * y, y * y}; /* fac1*fac2, :608-612 */
@@ -439,9 +451,18 @@ static void tdist_scale(const float *res, int n, const float *w, float cov[4], i
     for (int k = 0; k < 4; ++k) {
       const float p1 = scale * (w[i] * f[k]);
       const float p2 = scale * (w[i + 1] * g[k]);
-      acc[k] = acc[k] + (p1 + p2);
+      if (g_sum_mode == ORC_SUM_FP64)
+        acc64[k] += (double)(p1 + p2);
+      else if (sum_blocked())
+        blk[k] = blk[k] + (p1 + p2);
+      else
+        acc[k] = acc[k] + (p1 + p2);
     }
+    if (sum_blocked() && ((i + 2) % sum_block() == 0 || i + 2 >= n2))
+      for (int k = 0; k < 4; ++k) acc[k] += blk[k], blk[k] = 0.0f;
   }
+  if (g_sum_mode == ORC_SUM_FP64)
+    for (int k = 0; k < 4; ++k) acc[k] = (float)acc64[k];
   cov[0] = acc[0];
   cov[1] = acc[1]; /* (1,0) */
   cov[2] = acc[1]; /* (0,1) */
@@ -472,6 +493,10 @@ static float tdist_loglik(const float *res, int n, const float *P, int clean) {
   double error_sum = 0.0, error_acc = 1.0;
   for (int i = 0; i < n; ++i, ++c) {
     error_acc *= (1.0 + 0.2 * mahalanobis(res + 2 * i, P));
+    if (g_ll_guard && error_acc > 1e200) { /* instrumentation only: same sum, no overflow (orc_config.ll_guard) */
+      error_sum += log(error_acc);
+      error_acc = 1.0;
+    }
     if ((c % 50) == 0) {
       error_sum += log(error_acc);
       error_acc = 1.0;
@@ -595,6 +620,38 @@ static void normal_equations(const orc_record *points_error, int n, const float 
                              float acc[24], float bvec[6]) {
   memset(acc, 0, 24 * sizeof(float));
   memset(bvec, 0, 6 * sizeof(float));
+  if (g_sum_mode != ORC_SUM_REFERENCE) { /* the same per-point terms, added up in another order (ORC_SUM_*) */
+    double acc64[24] = {0}, b64[6] = {0};
+    float blk[24] = {0}, bblk[6] = {0};
+    for (int i = 0; i < n; ++i) {
+      float J[12], W[4], term[24] = {0}, bt[6];
+      point_jacobian(points_error + i, J);
+      for (int k = 0; k < 4; ++k) W[k] = weights[i] * precision[k];
+      rank_update_2x6(term, J, W);
+      const float r0 = points_error[i].e[0], r1 = points_error[i].e[1];
+      for (int k = 0; k < 6; ++k) {
+        const float t0 = J[2 * k] * W[0] + J[2 * k + 1] * W[1];
+        const float t1 = J[2 * k] * W[2] + J[2 * k + 1] * W[3];
+        bt[k] = t0 * r0 + t1 * r1;
+      }
+      if (g_sum_mode == ORC_SUM_FP64) {
+        for (int k = 0; k < 24; ++k) acc64[k] += (double)term[k];
+        for (int k = 0; k < 6; ++k) b64[k] -= (double)bt[k];
+      } else {
+        for (int k = 0; k < 24; ++k) blk[k] += term[k];
+        for (int k = 0; k < 6; ++k) bblk[k] -= bt[k];
+        if ((i + 1) % sum_block() == 0 || i + 1 == n) {
+          for (int k = 0; k < 24; ++k) acc[k] += blk[k], blk[k] = 0.0f;
+          for (int k = 0; k < 6; ++k) bvec[k] += bblk[k], bblk[k] = 0.0f;
+        }
+      }
+    }
+    if (g_sum_mode == ORC_SUM_FP64) {
+      for (int k = 0; k < 24; ++k) acc[k] = (float)acc64[k];
+      for (int k = 0; k < 6; ++k) bvec[k] = (float)b64[k];
+    }
+    return;
+  }
   for (int i = 0; i < n; ++i) {
     float J[12], W[4];
     point_jacobian(points_error + i, J);
@@ -935,6 +992,8 @@ int orc_match(const orc_config *cfg, orc_pyramid *ref, orc_pyramid *cur, const d
     return -3;
   }
   int last_level_first_iter = 0;
+  g_sum_mode = cfg->sum_mode; /* (reset before the single return below) */
+  g_ll_guard = cfg->ll_guard;
 
   for (int level = cfg->first_level; level >= cfg->last_level; --level) {
     orc_level_stats *ls = &res->levels[res->n_levels++];
@@ -1080,6 +1139,8 @@ int orc_match(const orc_config *cfg, orc_pyramid *ref, orc_pyramid *cur, const d
   for (int i = 0; i < 36; ++i) si += res->information[i];
   res->is_nan = !(isfinite(s) && isfinite(si));
 
+  g_sum_mode = ORC_SUM_REFERENCE;
+  g_ll_guard = 0;
   if (its_own) free(its);
   (void)its_cap;
   free(points_error);

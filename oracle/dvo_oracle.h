@@ -33,6 +33,19 @@ enum {
                         there to report how far the bug-compatible result is from the intended algorithm */
 };
 
+/* In what order the oracle adds up the SAME fp32 terms of the scale estimate (computeScaleSse) and of the normal equations
+ * (rankUpdate / b -= J^T W r).  ORC_SUM_REFERENCE is the reference's order: one sequential fp32 accumulator in scan order
+ * (dense_tracking_impl.cpp:590-638, math_sse.cpp:117).  The other two re-associate the sum -- what any implementation that
+ * does not run the pixels strictly one after the other does -- and exist so that the tests can show how far the reference
+ * algorithm's OWN answer moves under a different summation order (the fork criterion of tests/test_gpu_parity.py). */
+enum {
+  ORC_SUM_REFERENCE = 0,
+  ORC_SUM_FP64 = 1,     /* the same fp32 products, accumulated in double */
+  ORC_SUM_BLOCKED = 2,  /* fp32 partial sums over blocks of 256 consecutive points, the partial sums added up in fp32 */
+  ORC_SUM_BLOCKED_32 = 3,   /* ... blocks of 32 */
+  ORC_SUM_BLOCKED_2048 = 4  /* ... blocks of 2048 */
+};
+
 /* dense_tracking.h:71-81 */
 enum {
   ORC_TERM_ITERATIONS_EXCEEDED = 0,
@@ -52,6 +65,13 @@ typedef struct {
   float intensity_derivative_threshold;
   float depth_derivative_threshold;
   int rcp_mode;
+  int sum_mode; /* ORC_SUM_* below; not a reference option: test instrumentation (default ORC_SUM_REFERENCE) */
+  int ll_guard; /* test instrumentation, default 0 = the reference: computeCompleteDataLogLikelihood multiplies 50 terms
+                   (1 + 0.2 r^T P r) in a double before it takes one log (dense_tracking_impl.cpp:413-419); when 50 consecutive
+                   residuals all have a Mahalanobis distance above ~7e6 (noise-free synthetic depth gives precisions of 1e9 and
+                   more; sensor data never does) that product overflows, the likelihood is -inf and the iteration is rejected.
+                   1: the same sum without the overflow (a log is taken early whenever the running product passes 1e200), to tell
+                   this artefact apart from everything else when a GPU run and the oracle part ways. */
 } orc_config;
 
 /* DenseTracker::IterationStats (dense_tracking.h:83-100) + the linear system of that iteration */

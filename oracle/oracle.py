@@ -15,6 +15,8 @@ _LIB_PATH = os.path.join(_HERE, "_build", "libdvo_oracle.so")
 
 MAX_LEVELS = 8
 RCP_SSE, RCP_EXACT, RCP_CLEAN = 0, 1, 2
+# orc_config.sum_mode: the order the same fp32 terms are added up in (test instrumentation)
+SUM_REFERENCE, SUM_FP64, SUM_BLOCKED, SUM_BLOCKED_32, SUM_BLOCKED_2048 = 0, 1, 2, 3, 4
 TERMINATION = {0: "IterationsExceeded", 1: "IncrementTooSmall", 2: "LogLikelihoodDecreased", 3: "TooFewConstraints", -1: "Unset"}
 
 
@@ -70,7 +72,7 @@ class Config(C.Structure):
     _fields_ = [("first_level", C.c_int), ("last_level", C.c_int), ("max_iterations_per_level", C.c_int),
                 ("precision", C.c_double), ("mu", C.c_double), ("use_initial_estimate", C.c_int),
                 ("intensity_derivative_threshold", C.c_float), ("depth_derivative_threshold", C.c_float),
-                ("rcp_mode", C.c_int)]
+                ("rcp_mode", C.c_int), ("sum_mode", C.c_int), ("ll_guard", C.c_int)]
 
 
 class IterationStats(C.Structure):

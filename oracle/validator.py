@@ -85,6 +85,7 @@ class ConstraintProposal:
         self.InitialTransformation = np.asarray(initial, dtype=np.float64)
         self.TrackingResult = None
         self.Votes = []
+        self.origin = None  # test instrumentation: index of the input proposal this one descends from, -(i + 1) for its inverse
 
     @staticmethod
     def createWithIdentity(reference, current):  # :31-39
@@ -104,7 +105,9 @@ class ConstraintProposal:
         return any(v.Decision == REJECT for v in self.Votes)
 
     def createInverseProposal(self):  # :88-96
-        return ConstraintProposal(self.Current, self.Reference, np.linalg.inv(self.InitialTransformation))
+        inv = ConstraintProposal(self.Current, self.Reference, np.linalg.inv(self.InitialTransformation))
+        inv.origin = None if self.origin is None else -(self.origin + 1)
+        return inv
 
     def isConstraintBetweenSameFrames(self, other):  # :98-101
         return ((self.Reference.id == other.Reference.id and self.Current.id == other.Current.id) or
@@ -225,12 +228,16 @@ class ConstraintProposalValidator:
     def __init__(self):
         self.stages = []
         self.n_matches = 0
+        self.history = []  # test instrumentation: (stage id, origin, reference id, current id, initial transformation, result)
+                           # of EVERY alignment, also of the proposals that do not survive
 
     def createStage(self, id):
         self.stages.append(Stage(id))
         return self.stages[-1]
 
     def validate(self, proposals):  # :69-102, in place
+        for i, p in enumerate(proposals):
+            p.origin = i
         for stage in self.stages:
             for p in proposals:
                 p.Votes = []
@@ -263,6 +270,7 @@ class ConstraintProposalValidator:
         for p in proposals:
             p.TrackingResult = orc.match(stage.TrackingConfig, p.Reference.image, p.Current.image, p.InitialTransformation)
             self.n_matches += 1
+            self.history.append((stage.Id, p.origin, p.Reference.id, p.Current.id, p.InitialTransformation.copy(), p.TrackingResult))
         for p in proposals:
             for v in stage.Voters:
                 p.Votes.append(v.vote(p))

@@ -18,9 +18,12 @@ POSE_TOL = 1e-5  # BASELINE.json: ||log(T_ref^-1 T_gpu)|| <= 1e-5
 # computeScaleSse (quirk Q5) and moves the V % 50 tail the likelihood drops (Q6); the likelihood jumps by ~1e4 and the
 # accept / reject decision of that iteration can flip, so one path takes a last step the other does not.
 # tests/test_oracle.py::test_reference_algorithm_is_chaotic shows the oracle doing this to itself.  When GPU and oracle
-# take the same path (same iteration count and termination per level) the 1e-5 bar applies; otherwise both must still
-# agree to the size of such a last step.
-DIVERGED_PATH_TOL = 3e-4
+# take the same path (same iteration count and termination per level) the 1e-5 bar applies.  When they fork, the fork is
+# adjudicated on its own evidence (tests/fork_criterion.py): the GPU may be as far from the oracle as the oracle lands from
+# ITSELF when only the order of its fp32 sums changes, and the decision that flipped must be a coin flip of the oracle's own
+# rounding or follow from the reference arithmetic at the GPU's own poses.  There is no blanket tolerance for forked paths
+# and no budget of allowed forks any more.
+MODE_DISTANCE_TOL = 3e-4  # only for the oracle's OTHER modes (host-specific rcpps, quirk-free CLEAN): different algorithms
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -151,6 +154,7 @@ def test_weighted_iteration_stages_match_the_oracle(capi, orc, synth, pair640, l
 
 
 from stage_f64 import f64_iteration as _f64_iteration  # noqa: E402  (tests/stage_f64.py)
+import fork_criterion  # noqa: E402  (tests/fork_criterion.py)
 
 
 # Tolerances of the teacher-forced stage comparison.
@@ -255,9 +259,9 @@ def test_weighted_stage_tails(capi, orc, synth, n_drop):
 # ---------------------------------------------------------------------------------------------------------------------
 # full match(): pose parity, statistics, quirks
 # ---------------------------------------------------------------------------------------------------------------------
-# which configurations took the same iteration path as the oracle and which forked (see DIVERGED_PATH_TOL); the last test
+# which configurations took the same iteration path as the oracle and which forked (tests/fork_criterion.py); the last test
 # of this file asserts that the number of forks does not grow
-_PATHS = {"same": [], "forked": [], "fork_err": []}
+_PATHS = {"same": [], "forked": [], "fork_err": [], "reports": []}
 # Per-iteration checks of a free-running match() against the oracle's (dense_tracking.cpp:273-352 per iteration:
 # ValidConstraints, TDistributionPrecision, TDistributionLogLikelihood, EstimateIncrement).  The first iteration of the first
 # level sees identical inputs: summation-order tolerances.  Every later iteration starts from a pose that has drifted by
@@ -319,6 +323,11 @@ def _check_match(capi, orc, synth, g_ref, g_cur, o_ref, o_cur, cfg_kw, T_init=No
                               intensity_derivative_threshold=gcfg.IntensityDerivativeThreshold,
                               depth_derivative_threshold=gcfg.DepthDerivativeThreshold, rcp_mode=orc.RCP_EXACT)
     ro = orc.match(ocfg, o_ref, o_cur, T_init)
+    ro, artefact = fork_criterion.without_overflow(orc, ocfg, o_ref, o_cur, T_init, ro)  # (the one stated deviation)
+    if artefact:
+        _PATHS["reports"].append((label, [artefact]))
+        _PATHS["forked"].append(label + " (overflow artefact)")
+        _PATHS["fork_err"].append(float("nan"))
     err = synth.pose_error(ro["T"], rg.Transformation)
     same_path = all(Lg["TerminationCriterion"] == Lo["termination"] and len(Lg["Iterations"]) == len(Lo["iterations"])
                     for Lg, Lo in zip(rg.Levels, ro["levels"]))
@@ -331,7 +340,9 @@ def _check_match(capi, orc, synth, g_ref, g_cur, o_ref, o_cur, cfg_kw, T_init=No
         n_it, n_same_v = _compare_iterations(rg.Levels, _oracle_levels(ro), label)
         print(f"[iterations] {label}: {n_it} compared, {n_same_v} with identical ValidConstraints, pose err {err:.2e}")
     else:
-        assert err <= DIVERGED_PATH_TOL, err
+        # no blanket tolerance: the fork must be legitimate on its own evidence (tests/fork_criterion.py)
+        report = fork_criterion.adjudicate(orc, synth, ocfg, o_ref, o_cur, T_init, rg, ro, err, tol)
+        _PATHS["reports"].append((label, report))
         # up to the fork both ran the same iterations: compare the common prefix of every level up to the first level whose
         # iteration count differs
         for Lg, Lo in zip(rg.Levels, ro["levels"]):
@@ -366,7 +377,7 @@ def test_match_640x480_4_levels(capi, orc, synth, pair640):
     assert np.allclose(rg.Information, src["EstimateInformation"] * 0.008 * 0.008)
     assert rg.LogLikelihood == src["TDistributionLogLikelihood"] + src["PriorLogLikelihood"]
     # the final information matrix carries the scale P of the last accepted iteration; if GPU and oracle end on different
-    # iterations of the last level (forked path, see DIVERGED_PATH_TOL) it is only comparable to the size of that step
+    # iterations of the last level (forked path, tests/fork_criterion.py) it is only comparable to the size of that step
     same_path = all(Lg["TerminationCriterion"] == Lo["termination"] and len(Lg["Iterations"]) == len(Lo["iterations"])
                     for Lg, Lo in zip(rg.Levels, ro["levels"]))
     tol = 5e-3 if same_path else 0.15
@@ -392,7 +403,7 @@ def test_headline_parity_against_all_oracle_modes(capi, orc, synth, size, capsys
         print(f"\n[parity {w}x{h}] vs exact-reciprocal oracle {err['exact']:.2e}, vs rcpps oracle (this host) {err['rcpps']:.2e}, "
               f"vs CLEAN oracle {err['clean']:.2e}, vs ground truth {synth.pose_error(Tgt, g.Transformation):.2e}")
     assert err["exact"] <= POSE_TOL
-    assert err["rcpps"] <= DIVERGED_PATH_TOL and err["clean"] <= DIVERGED_PATH_TOL
+    assert err["rcpps"] <= MODE_DISTANCE_TOL and err["clean"] <= MODE_DISTANCE_TOL
     assert synth.pose_error(Tgt, g.Transformation) < 2e-5
 
 
@@ -493,7 +504,18 @@ def test_match_against_committed_golden_vectors(capi, synth, name):
         _compare_iterations([L], [per_level], name, first_is_identical=li == 0)
     _PATHS["forked" if forked else "same"].append("golden " + name)
     if forked:
-        _PATHS["fork_err"].append(synth.pose_error(want["T"], rg.Transformation))
+        # the committed vectors hold no poses per iteration: adjudicate the fork against the live oracle (whose final pose
+        # must be the committed one)
+        from oracle import oracle as orc
+
+        ocfg = orc.default_config(first_level=first, last_level=last, mu=mu, use_initial_estimate=int(use_init),
+                                  max_iterations_per_level=50, rcp_mode=orc.RCP_EXACT)
+        o_ref, o_cur = orc.Pyramid(Ir, Zr, K, levels), orc.Pyramid(Ic, Zc, K, levels)
+        ro = orc.match(ocfg, o_ref, o_cur, T0)
+        assert synth.pose_error(want["T"], ro["T"]) <= 1e-12
+        err = synth.pose_error(want["T"], rg.Transformation)
+        _PATHS["fork_err"].append(err)
+        _PATHS["reports"].append(("golden " + name, fork_criterion.adjudicate(orc, synth, ocfg, o_ref, o_cur, T0, rg, ro, err, POSE_TOL)))
     else:
         assert np.allclose(rg.Information, want["information"], rtol=5e-3, atol=5e-3 * np.abs(want["information"]).max())
     assert [gr.select(l)[0] for l in range(levels)] == list(want["sel_counts"])
@@ -551,7 +573,14 @@ def test_control_flow_corner_cases_follow_the_oracle(capi, orc, synth, pair640, 
             assert abs(ig["ValidConstraints"] - io["valid_constraints"]) <= ITER_COUNT_SLACK
             assert abs(ig["PriorLogLikelihood"] - io["prior_loglik"]) <= 1e-5 * max(1.0, abs(io["prior_loglik"]))
     if not ro["is_nan"]:
-        assert synth.pose_error(ro["T"], rg.Transformation) <= (POSE_TOL if same_path else DIVERGED_PATH_TOL)
+        err = synth.pose_error(ro["T"], rg.Transformation)
+        if same_path:
+            assert err <= POSE_TOL
+        else:
+            _PATHS["forked"].append("control flow " + repr(sorted(cfg_kw.items())))
+            _PATHS["fork_err"].append(err)
+            _PATHS["reports"].append((_PATHS["forked"][-1], fork_criterion.adjudicate(
+                orc, synth, ocfg, pair640["orr"], pair640["occ"], T0, rg, ro, err, POSE_TOL)))
         if same_path:
             assert np.allclose(rg.Information, ro["information"], rtol=5e-3, atol=5e-3 * np.abs(ro["information"]).max())
 
@@ -951,8 +980,19 @@ def test_track_frame_equals_oracle_and_two_single_matches(capi, orc, synth):
         last_kf_pose = poses[5] @ synth.se3_exp(np.array([0.002, -0.001, 0.001, 0.0005, 0.001, -0.0005]))  # a slightly-off estimate
         rk, ro, crit = trk.track_frame(g[0], g[1], g[2], last_kf_pose)
         ok, oo, ocrit = frontend.track_frame(ocfg, o[0], o[1], o[2], last_kf_pose)
-        assert synth.pose_error(rk.Transformation, ok["T"]) <= DIVERGED_PATH_TOL
-        assert synth.pose_error(ro.Transformation, oo["T"]) <= DIVERGED_PATH_TOL
+        # both alignments against the oracle's of the same (reference, current, initial transformation): 1e-5, or -- when the
+        # paths forked -- as far as the oracle lands from itself under re-associated sums (tests/fork_criterion.py)
+        init_kf = np.linalg.inv(last_kf_pose)
+        for got, want, o_ref, T0 in ((rk, ok, o[0], init_kf), (ro, oo, o[1], np.eye(4))):
+            err = synth.pose_error(got.Transformation, want["T"])
+            if [(L["TerminationCriterion"], len(L["Iterations"])) for L in got.Levels] == \
+                    [(L["termination"], len(L["iterations"])) for L in want["levels"]]:
+                assert err <= POSE_TOL, err
+            else:
+                _PATHS["forked"].append(f"track_frame {sorted(cfg_kw.items())} {'keyframe' if got is rk else 'odometry'}")
+                _PATHS["fork_err"].append(err)
+                _PATHS["reports"].append((_PATHS["forked"][-1], fork_criterion.adjudicate(
+                    orc, synth, ocfg, o_ref, o[2], T0, got, want, err, POSE_TOL)))
         assert synth.pose_error(rk.Transformation, poses[6]) < 1e-3 and synth.pose_error(ro.Transformation, poses[6] @ np.linalg.inv(poses[5])) < 1e-3
         # the likelihood is discontinuous in the valid-constraint count (Q5 re-pairing, Q6 tail): +-1 constraint moves it by
         # ~1e4 of ~4e6 even on the same iteration path, so it is only comparable to a few percent (chaos caveat above)
@@ -1019,21 +1059,38 @@ def test_sharded_match_with_single_rank_peer_exchange(capi, synth, pair640, monk
 # ---------------------------------------------------------------------------------------------------------------------
 # keep last: the fork budget
 # ---------------------------------------------------------------------------------------------------------------------
-MAX_FORKED_CONFIGS = 6  # round 2 baseline: 6 of the 15 oracle-checked configurations part ways at some level
-MAX_WAIVED_CONFIGS = 1  # of those, configurations whose final pose is further than 1e-5 from the oracle's (the DIVERGED bound)
-
-
-def test_zz_forked_paths_do_not_grow(capsys):
+def test_zz_every_fork_was_adjudicated(capsys):
     """Every _check_match() above recorded whether GPU and oracle took the same iteration path (same termination and
-    iteration count on every level).  A fork is legitimate -- at a converged level the likelihood difference between two
-    iterations is summation noise, so the last accept / reject is a coin flip on both sides, and the reference algorithm
-    amplifies 1e-9 into such a flip (tests/test_oracle.py::test_reference_algorithm_is_chaotic) -- but only a fork whose
-    final pose also leaves the 1e-5 bar waives that bar, so both numbers are pinned."""
-    waived = [e for e in _PATHS["fork_err"] if e > POSE_TOL]
+    iteration count on every level).  A fork is only legitimate on its own evidence (tests/fork_criterion.py): each one was
+    adjudicated where it happened -- an illegitimate fork failed its test there -- and the verdicts are printed here.  There is
+    no budget of allowed forks: how many configurations fork, and which, changes with any change of summation order."""
     with capsys.disabled():
-        print(f"\n[paths] same: {len(_PATHS['same'])}, forked: {len(_PATHS['forked'])}, forked beyond 1e-5: {len(waived)}; "
-              f"pose errors of the forked configurations: {['%.1e' % e for e in _PATHS['fork_err']]} {_PATHS['forked']}")
+        print(f"\n[paths] same: {len(_PATHS['same'])}, forked: {len(_PATHS['forked'])} (accumulator: "
+              f"{os.environ.get('DVO_AMD_ACCUM', 'mfma')}); pose errors of the forked configurations: "
+              f"{['%.1e' % e for e in _PATHS['fork_err']]}")
+        for label, report in _PATHS["reports"]:
+            print(f"[fork] {label}")
+            for line in report:
+                print(f"        {line}")
     if not _PATHS["same"] and not _PATHS["forked"]:
         pytest.skip("no match configuration ran in this session")
-    assert len(_PATHS["forked"]) <= MAX_FORKED_CONFIGS, _PATHS["forked"]
-    assert len(waived) <= MAX_WAIVED_CONFIGS, _PATHS
+    assert len(_PATHS["reports"]) == len(_PATHS["forked"])  # none slipped through without a verdict
+
+
+def test_zz_parity_suite_under_the_register_accumulator():
+    """The shipped alternative accumulator (DVO_AMD_ACCUM=valu: 87 fp32 registers per lane instead of the Gram matrix on the
+    matrix pipe) sums in another order, so other configurations fork.  Under the old fork budget it would have turned the
+    suite red; under the per-fork criterion every one of its forks must be legitimate too.  Runs the match-level tests of this
+    file once more in a child process with the switch set (the kernel form is chosen once per process)."""
+    import subprocess
+    import sys
+
+    if os.environ.get("DVO_AMD_ACCUM"):
+        pytest.skip("already the child run")
+    env = dict(os.environ, DVO_AMD_ACCUM="valu")
+    sel = "test_match or test_odd_sizes or test_headline or test_control_flow or test_zz_every_fork"
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-s", "-x", "-k", sel,
+                          "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
+    tail = "\n".join(res.stdout.splitlines()[-40:])
+    print(tail)
+    assert res.returncode == 0, tail + res.stderr[-2000:]

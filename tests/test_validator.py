@@ -174,33 +174,72 @@ def test_validate_rejects_bad_arguments_without_touching_the_gpu():
 # ---------------------------------------------------------------------------------------------------------------------
 # GPU parity: the batched native validator against the oracle
 # ---------------------------------------------------------------------------------------------------------------------
-POSE_TOL, DIVERGED_PATH_TOL = 1e-5, 3e-4  # see tests/test_gpu_parity.py
+POSE_TOL = 1e-5  # BASELINE.json: ||log(T_ref^-1 T_gpu)|| <= 1e-5
+import fork_criterion  # noqa: E402  (tests/fork_criterion.py: what a forked alignment may differ by)
 
 
 def _summary_oracle(props):
     return [(p.Reference.id, p.Current.id, [v.Decision for v in p.Votes], [v.Value for v in p.Votes],
-             p.TrackingResult["T"], p.TotalScore()) for p in props]
+             p.TrackingResult["T"], p.TotalScore(), p.origin) for p in props]
 
 
 def _summary_gpu(props):
     return [(p.Reference.id, p.Current.id, [v.Decision for v in p.Votes], [v.Value for v in p.Votes],
-             p.TrackingResult.Transformation, p.TotalScore()) for p in props]
+             p.TrackingResult.Transformation, p.TotalScore(), p.origin) for p in props]
 
 
-def _compare(synth, got, want):
-    assert [(g[0], g[1]) for g in got] == [(w[0], w[1]) for w in want]
+def _like_with_like(orc, synth, ov, stage, g_props, notes):
+    """Every GPU survivor of `stage` against the oracle's alignment of the SAME proposal -- same (reference, current) and same
+    initialisation lineage (`origin`), whether or not the oracle's own keepBest / cross-validation kept it -- under the fork
+    rule of tests/fork_criterion.py: 1e-5, or as far as the oracle lands from itself under re-associated sums.
+    ov.history holds every alignment the oracle validator ran."""
+    hist = {h[1]: h for h in ov.history if h[0] == stage.Id}
     worst = 0.0
-    for g, w in zip(got, want):
-        assert g[2] == w[2], (g[0], g[1], g[2], w[2], g[3], w[3])
-        # the likelihood of a finished alignment moves by ~1e-3 relative when GPU and oracle fork by one accepted step
-        # (chaos caveat of tests/test_gpu_parity.py); thresholds are placed mid-gap so that decisions cannot flip on that
-        # (the cross-validation value is the norm of a pose difference: absolute tolerance = two forked alignments)
-        assert np.allclose(g[3], w[3], rtol=1e-2, atol=2 * DIVERGED_PATH_TOL), (g[3], w[3])
-        assert abs(g[5] - w[5]) <= 1e-2 * max(1.0, abs(w[5]))
-        err = synth.pose_error(g[4], w[4])
-        assert err <= DIVERGED_PATH_TOL, err
+    for p in g_props:
+        assert p.origin in hist, (p.origin, sorted(hist))
+        _, _, rid, cid, init, ro = hist[p.origin]
+        assert (rid, cid) == (p.Reference.id, p.Current.id)
+        ro, artefact = fork_criterion.without_overflow(orc, stage.TrackingConfig, ov.images[rid], ov.images[cid], init, ro)
+        if artefact:
+            notes.append(f"{rid}->{cid} origin {p.origin}: {artefact}")
+        err = synth.pose_error(ro["T"], p.TrackingResult.Transformation)
+        bar, note = fork_criterion.pose_bar(orc, synth, stage.TrackingConfig, ov.images[rid], ov.images[cid], init, ro, err, POSE_TOL)
+        if note:
+            notes.append(f"{rid}->{cid} origin {p.origin}: {note}")
+        assert err <= bar, (rid, cid, p.origin, err, bar, note)
         worst = max(worst, err)
     return worst
+
+
+def _compare(orc, synth, ov, got_props, want_props, notes):
+    """Survivors, their order, every vote decision; vote values within the heuristic band of a likelihood ratio.  Poses are
+    compared like with like for a single stage only: in a free-running two-stage run each side starts stage 2 from its OWN
+    stage-1 estimate (validator.cpp:95-100), so the two sides align different proposals there -- the second stage is compared
+    teacher-forced instead (_teacher_forced_second_stage)."""
+    got, want = _summary_gpu(got_props), _summary_oracle(want_props)
+    assert [(g[0], g[1]) for g in got] == [(w[0], w[1]) for w in want]
+    for g, w in zip(got, want):
+        assert g[2] == w[2], (g[0], g[1], g[2], w[2], g[3], w[3])
+        # vote values are likelihood ratios (and the norm of a pose difference): they move by ~1e-3 relative when the two sides
+        # fork by one accepted step; thresholds are placed mid-gap so that decisions cannot flip on that
+        assert np.allclose(g[3], w[3], rtol=1e-2, atol=6e-4), (g[3], w[3])
+        assert abs(g[5] - w[5]) <= 1e-2 * max(1.0, abs(w[5]))
+    if len(ov.stages) == 1:
+        return _like_with_like(orc, synth, ov, ov.stages[0], got_props, notes)
+    return 0.0
+
+
+def _teacher_forced_second_stage(orc, synth, Cn, V, make_validators, o_stage1, gkf, okf, notes):
+    """Stage 2 alone on both sides, both starting from the ORACLE's stage-1 survivors (reference, current, initial transformation
+    = inverse of the oracle's stage-1 estimate): every GPU survivor against the oracle's alignment of the same proposal.
+    make_validators() -> (GPU validator, oracle validator) holding the second stage only."""
+    gv2, ov2 = make_validators()
+    gp2 = [Cn.ConstraintProposal(gkf[q.Reference.id], gkf[q.Current.id], q.InitialTransformation) for q in o_stage1]
+    op2 = [V.ConstraintProposal(okf[q.Reference.id], okf[q.Current.id], q.InitialTransformation) for q in o_stage1]
+    g2, o2 = gv2.validate(gp2), ov2.validate(op2)
+    assert len(ov2.history) == len(o_stage1)
+    assert {frozenset((p.Reference.id, p.Current.id)) for p in g2} == {frozenset((p.Reference.id, p.Current.id)) for p in o2}
+    return g2, o2, _like_with_like(orc, synth, ov2, ov2.stages[0], g2, notes)
 
 
 @pytest.mark.gpu
@@ -215,13 +254,17 @@ def test_gpu_validator_equals_oracle(orc, V, synth, kind):
     gkey, gcands = S.gpu_keyframes(capi, Cn, synth, 640, 480, n_cand, getattr(Cn, kind + "TrackingResultEvaluation"))
     assert abs(gkey.evaluation.average - okey.evaluation.average) <= 1e-4 * abs(okey.evaluation.average)
 
+    notes = []
+    images = {k.id: k.image for k in [okey] + ocands}
+
     def run(thresholds, stages=2):
         ov = V.create_constraint_proposal_validator(**thresholds)
         gv = Cn.createConstraintProposalValidator(**thresholds)
         ov.stages, gv.stages = ov.stages[:stages], gv.stages[:stages]
+        ov.images = images
         o = ov.validate(V.proposals_for_candidates(okey, ocands))
         g = gv.validate(Cn.proposalsForCandidates(gkey, gcands))
-        worst = _compare(synth, _summary_gpu(g), _summary_oracle(o))
+        worst = _compare(orc, synth, ov, g, o, notes)
         return o, worst
 
     # (1) stage 1 alone, nothing rejected by a ratio: the observed coarse ratios give a threshold that splits the proposals
@@ -239,7 +282,20 @@ def test_gpu_validator_equals_oracle(orc, V, synth, kind):
     run(dict(min_constraint_ratio=S.mid_gap_threshold(ratios), ratio_coarse=coarse, ratio_fine=-1e300))
     # (4) the reference's default thresholds (config.cpp:38-43)
     run(dict(min_constraint_ratio=0.2, ratio_coarse=0.7, ratio_fine=0.9))
-    assert worst <= DIVERGED_PATH_TOL
+    # (5) the second stage like with like: both sides start it from the oracle's stage-1 survivors
+    gkf = {k.id: k for k in [gkey] + gcands}
+    okf = {k.id: k for k in [okey] + ocands}
+
+    def second_stage_only():
+        ov = V.create_constraint_proposal_validator(**PERMISSIVE)
+        gv = Cn.createConstraintProposalValidator(**PERMISSIVE)
+        ov.stages, gv.stages = ov.stages[1:], gv.stages[1:]
+        ov.images = images
+        return gv, ov
+    _, _, worst2 = _teacher_forced_second_stage(orc, synth, Cn, V, second_stage_only, o1, gkf, okf, notes)
+    print(f"[validator {kind}] second stage, teacher-forced: worst pose error vs the oracle's alignment of the same proposal {worst2:.2e}")
+    for n in notes:
+        print("[validator fork]", n)
 
 
 @pytest.mark.gpu
@@ -266,40 +322,53 @@ def test_config5_full_size_32_candidates_against_the_oracle(orc, V, synth):
     gkey, okey = both(key)
     pairs = [both(c) for c in cands]
     gcands, ocands = [p[0] for p in pairs], [p[1] for p in pairs]
-    gprops, oprops = Cn.proposalsForCandidates(gkey, gcands), V.proposals_for_candidates(okey, ocands)
-    assert len(gprops) == len(oprops) == 64
+    gkf = {k.id: k for k in [gkey] + gcands}
+    okf = {k.id: k for k in [okey] + ocands}
+    images = {k.id: k.image for k in [okey] + ocands}
     th = dict(min_constraint_ratio=0.2, ratio_coarse=-1e300, ratio_fine=-1e300)
-    gv = Cn.createConstraintProposalValidator(tracker=trk, max_in_flight=72, **th)
-    ov = V.create_constraint_proposal_validator(**th)
-    for st in gv.stages:  # "all First=3, Last=0 for the metric" 
-        st.TrackingConfig.FirstLevel, st.TrackingConfig.LastLevel = 3, 0
-    for st in ov.stages:
-        st.TrackingConfig.first_level, st.TrackingConfig.last_level = 3, 0
-    g, o = gv.validate(gprops), ov.validate(oprops)
+
+    def validators(first_stage, n_stages):
+        gv = Cn.createConstraintProposalValidator(tracker=trk, max_in_flight=72, **th)
+        ov = V.create_constraint_proposal_validator(**th)
+        for st in gv.stages:  # "all First=3, Last=0 for the metric" 
+            st.TrackingConfig.FirstLevel, st.TrackingConfig.LastLevel = 3, 0
+        for st in ov.stages:
+            st.TrackingConfig.first_level, st.TrackingConfig.last_level = 3, 0
+        gv.stages, ov.stages = gv.stages[first_stage:first_stage + n_stages], ov.stages[first_stage:first_stage + n_stages]
+        ov.images = images
+        return gv, ov
+
+    notes = []
+    # ---- (1) stage 1 alone: 64 proposals + 64 cross-validation inverses, every GPU survivor against the oracle's alignment of
+    # the SAME (reference, current, initial transformation) -- the oracle ran all 128 -- under the 1e-5 / fork rule
+    gv1, ov1 = validators(0, 1)
+    g1 = gv1.validate(Cn.proposalsForCandidates(gkey, gcands))
+    o1 = ov1.validate(V.proposals_for_candidates(okey, ocands))
+    assert len(ov1.history) == 128 and len(g1) == len(o1) == 64
+    worst1 = _like_with_like(orc, synth, ov1, ov1.stages[0], g1, notes)
+    # ---- (2) stage 2 alone, teacher-forced: both sides start from the ORACLE's stage-1 survivors (stage 2 starts from stage 1's
+    # estimate, validator.cpp:95-100: in a free-running run each side would start from its own), keepBest, like with like
+    g2, o2, worst2 = _teacher_forced_second_stage(orc, synth, Cn, V, lambda: validators(1, 1), o1, gkf, okf, notes)
+    assert len(g2) == len(o2) == n_cand
+    same_survivor = sum(p.origin == q.origin for p, q in zip(g2, o2))
+    print(f"[config 5] like with like: stage 1 worst {worst1:.2e} over {len(g1)} survivors, stage 2 (teacher-forced) worst "
+          f"{worst2:.2e} over {len(g2)}; keepBest picked the same initialisation on both sides for {same_survivor} of {n_cand}; "
+          f"{len(notes)} alignments beyond 1e-5, all within the oracle's own re-association distance:")
+    for n in notes:
+        print("    [validator fork]", n)
+    # ---- (3) end to end, free running: same pairs survive with the same vote decisions
+    gv, ov = validators(0, 2)
+    g, o = gv.validate(Cn.proposalsForCandidates(gkey, gcands)), ov.validate(V.proposals_for_candidates(okey, ocands))
     assert len(g) == len(o) == n_cand  # keepBest: one constraint per candidate survives
     # keepBest chooses between a proposal and its cross-validation inverse by a likelihood-ratio score; the two scores of a
-    # pair are within ~1 % of each other and GPU / oracle likelihoods differ by that much when their last iterations differ
-    # (chaos caveat), so the surviving DIRECTION may differ: compare per unordered pair, inverting where it does
+    # pair are within ~1 % of each other and GPU / oracle likelihoods differ by that much when their last iterations differ,
+    # so the surviving DIRECTION (and initialisation) may differ: decisions are compared per unordered pair, poses like with
+    # like in (1) and (2)
     og = {frozenset((p.Reference.id, p.Current.id)): p for p in o}
     assert {frozenset((p.Reference.id, p.Current.id)) for p in g} == set(og)
-    # (likewise which of the two initialisations of a direction survives.)  Different survivors are different alignments of
-    # the same pair: they agree to the estimator's accuracy (2e-3 here), identical survivors to the forked-path bound.
-    same_direction = close = 0
     for p in g:
         q = og[frozenset((p.Reference.id, p.Current.id))]
         assert [v.Decision for v in p.Votes] == [v.Decision for v in q.Votes]
-        Tq = q.TrackingResult["T"]
-        if (p.Reference.id, p.Current.id) == (q.Reference.id, q.Current.id):
-            same_direction += 1
-        else:
-            Tq = np.linalg.inv(Tq)
-        err = synth.pose_error(p.TrackingResult.Transformation, Tq)
-        assert err <= 2e-3
-        close += err <= DIVERGED_PATH_TOL
-        # (the scores themselves are likelihood ratios taken at level 0, where the noise-free synthetic depth makes the
-        #  likelihood move by 10 % and more with a 1e-7 change of the pose -- tests/test_gpu_parity.py, DRIFT tolerances --
-        #  so only the decisions they lead to are compared here; the 6-candidate tests above compare the values at levels 3..1)
-    assert same_direction >= n_cand // 2 and close >= n_cand // 2, (same_direction, close)
     truth = {c["id"]: c["pose_true"] for c in cands}
     truth[key["id"]] = np.eye(4)
     for p in g:  # and every kept constraint is the right relative pose (cur <- ref, dense_tracking.cpp:371)
