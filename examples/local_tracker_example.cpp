@@ -12,6 +12,7 @@
 #include <vector>
 
 #include <dvo/core/point_selection.h>
+#include <dvo/core/point_selection_predicates.h>  // local_tracker.cpp:24
 #include <dvo/core/rgbd_image.h>
 #include <dvo/dense_tracking.h>
 

@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <iostream>
 #include <limits>
 #include <memory>
 #include <ostream>
@@ -115,6 +116,72 @@ inline const double *data(const AffineTransformd &T) { return T.mat.data(); }
 inline double *data(AffineTransformd &T) { return T.mat.data(); }
 inline double *data(Matrix6d &m) { return m.data(); }
 #endif
+
+// weight_calculation.h:107-119,191-203.  DenseTracker::configure stores these in Config and match() never reads them (the
+// bivariate t-distribution with 5 degrees of freedom is hard-coded); they exist here so that
+// dvo_ros' updateConfigFromDynamicReconfigure (configtools.h:34-79) and the Config stream operator compile unchanged.
+struct ScaleEstimators {
+  typedef enum { Unit, NormalDistribution, TDistribution, MAD } enum_t;
+  static const char *str(enum_t type) {  // weight_calculation.cpp:255-273
+    switch (type) {
+      case Unit: return "Unit";
+      case TDistribution: return "TDistribution";
+      case MAD: return "MAD";
+      case NormalDistribution: return "NormalDistribution";
+      default: break;
+    }
+    return "";
+  }
+};
+struct InfluenceFunctions {
+  typedef enum { Unit, Tukey, TDistribution, Huber } enum_t;
+  static const char *str(enum_t type) {  // weight_calculation.cpp:373-391
+    switch (type) {
+      case Unit: return "Unit";
+      case TDistribution: return "TDistribution";
+      case Tukey: return "Tukey";
+      case Huber: return "Huber";
+      default: break;
+    }
+    return "";
+  }
+};
+// TDistributionScaleEstimator::DEFAULT_DOF / TDistributionInfluenceFunction::DEFAULT_DOF (weight_calculation.cpp)
+static const float kTDistributionDefaultDof = 5.0f;
+
+namespace linalg {
+// eigenvalues of a symmetric 6x6 matrix (column-major) in ascending order by cyclic Jacobi rotations: what
+// Eigen::EigenSolver + std::sort give DenseTracker::IterationStats::InformationEigenValues (dense_tracking_config.cpp:123-128)
+// for the symmetric EstimateInformation
+inline void symmetric_eigenvalues6(const double *A_colmajor, double ev[6]) {
+  double a[6][6];
+  for (int r = 0; r < 6; ++r)
+    for (int c = 0; c < 6; ++c) a[r][c] = 0.5 * (A_colmajor[c * 6 + r] + A_colmajor[r * 6 + c]);
+  for (int sweep = 0; sweep < 64; ++sweep) {
+    double off = 0.0, diag = 0.0;
+    for (int r = 0; r < 6; ++r)
+      for (int c = 0; c < 6; ++c) (r == c ? diag : off) += a[r][c] * a[r][c];
+    if (off <= 1e-30 * diag || off == 0.0) break;
+    for (int p = 0; p < 5; ++p)
+      for (int q = p + 1; q < 6; ++q) {
+        if (a[p][q] == 0.0) continue;
+        const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 6; ++k) {  // columns p, q
+          const double akp = a[k][p], akq = a[k][q];
+          a[k][p] = c * akp - s * akq, a[k][q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < 6; ++k) {  // rows p, q
+          const double apk = a[p][k], aqk = a[q][k];
+          a[p][k] = c * apk - s * aqk, a[q][k] = s * apk + c * aqk;
+        }
+      }
+  }
+  for (int i = 0; i < 6; ++i) ev[i] = a[i][i];
+  std::sort(ev, ev + 6);
+}
+}  // namespace linalg
 
 // intrinsic_matrix.h:33-64
 class IntrinsicMatrix {
@@ -409,6 +476,30 @@ class PointSelection {
   bool debug_;
 };
 
+// surface_pyramid.h:34-49 / surface_pyramid.cpp:44-105: uint16 raw depth -> float metres, 0 -> NaN, one fp32 multiply per pixel.
+// Host-side shim for callers that build the float depth image themselves (camera_dense_tracking.cpp:233-236); the same
+// conversion runs on the GPU when a pyramid is created straight from the raw frame (dvo_amd_pyramid_create_raw).  Both reference entry points give the same values; the Sse one needs 16-byte aligned rows of a
+// multiple of 8 pixels, which this shim does not.
+class SurfacePyramid {
+ public:
+  static void convertRawDepthImage(const unsigned short *input, float *output, size_t n_pixels, float scale) {
+    const float nan = std::numeric_limits<float>::quiet_NaN();
+    for (size_t i = 0; i < n_pixels; ++i) output[i] = input[i] == 0 ? nan : (float)input[i] * scale;
+  }
+  static void convertRawDepthImageSse(const unsigned short *input, float *output, size_t n_pixels, float scale) {
+    convertRawDepthImage(input, output, n_pixels, scale);
+  }
+#ifdef DVO_AMD_HAVE_OPENCV
+  static void convertRawDepthImage(const cv::Mat &input, cv::Mat &output, float scale) {
+    output.create(input.rows, input.cols, CV_32FC1);
+    for (int y = 0; y < input.rows; ++y) convertRawDepthImage(input.ptr<unsigned short>(y), output.ptr<float>(y), (size_t)input.cols, scale);
+  }
+  static void convertRawDepthImageSse(const cv::Mat &input, cv::Mat &output, float scale) { convertRawDepthImage(input, output, scale); }
+#endif
+  SurfacePyramid() {}
+  virtual ~SurfacePyramid() {}
+};
+
 // rgbd_image.h:127-144
 class RgbdCameraPyramid {
  public:
@@ -454,15 +545,25 @@ class DenseTracker {
     double Precision;
     double Mu;
     bool UseInitialEstimate;
-    bool UseWeighting;  // never read by match() in the reference either
+    // The next six fields are declared by the reference (dense_tracking.h:51-60), assigned by its callers (configtools.h:70-79)
+    // and never read by match(): kept so that those call sites compile; they do not cross the C ABI.
+    bool UseWeighting;
+    bool UseParallel;  // (not even initialised by the reference's constructor; false here)
+    core::InfluenceFunctions::enum_t InfluenceFuntionType;  // [sic]
+    float InfluenceFunctionParam;
+    core::ScaleEstimators::enum_t ScaleEstimatorType;
+    float ScaleEstimatorParam;
     float IntensityDerivativeThreshold;
     float DepthDerivativeThreshold;
 
-    Config() {
+    Config() {  // dense_tracking_config.cpp:27-42
       dvo_amd_config c;
       dvo_amd_default_config(&c);
       FirstLevel = c.first_level, LastLevel = c.last_level, MaxIterationsPerLevel = c.max_iterations_per_level;
       Precision = c.precision, Mu = c.mu, UseInitialEstimate = c.use_initial_estimate != 0, UseWeighting = true;
+      UseParallel = false;
+      InfluenceFuntionType = core::InfluenceFunctions::TDistribution, InfluenceFunctionParam = core::kTDistributionDefaultDof;
+      ScaleEstimatorType = core::ScaleEstimators::TDistribution, ScaleEstimatorParam = core::kTDistributionDefaultDof;
       IntensityDerivativeThreshold = c.intensity_derivative_threshold;
       DepthDerivativeThreshold = c.depth_derivative_threshold;
     }
@@ -483,6 +584,18 @@ class DenseTracker {
     double PriorLogLikelihood;
     core::Vector6d EstimateIncrement;
     core::Matrix6d EstimateInformation;
+
+    // dense_tracking_config.cpp:123-136 (caller: keyframe_graph.cpp:370-371)
+    void InformationEigenValues(core::Vector6d &eigenvalues) const {
+      double ev[6];
+      core::linalg::symmetric_eigenvalues6(EstimateInformation.data(), ev);
+      for (int i = 0; i < 6; ++i) eigenvalues(i) = ev[i];
+    }
+    double InformationConditionNumber() const {
+      core::Vector6d ev;
+      InformationEigenValues(ev);
+      return std::abs(ev(5) / ev(0));
+    }
   };
   typedef std::vector<IterationStats> IterationStatsVector;
 
@@ -498,12 +611,17 @@ class DenseTracker {
                              : 1;
       return Iterations.size() >= min;
     }
+    // dense_tracking_config.cpp:138-172 (the reference prints "awkward" + the level and asserts; no assert crosses this adaptor)
     const IterationStats &LastIterationWithIncrement() const {
       if (!HasIterationWithIncrement()) throw std::logic_error("LevelStats: no iteration with an increment");
       return TerminationCriterion == TerminationCriteria::LogLikelihoodDecreased ? Iterations[Iterations.size() - 2]
                                                                                   : Iterations[Iterations.size() - 1];
     }
+    IterationStats &LastIterationWithIncrement() {
+      return const_cast<IterationStats &>(static_cast<const LevelStats *>(this)->LastIterationWithIncrement());
+    }
     const IterationStats &LastIteration() const { return Iterations.back(); }
+    IterationStats &LastIteration() { return Iterations.back(); }
   };
   typedef std::vector<LevelStats> LevelStatsVector;
 
@@ -698,14 +816,53 @@ class DenseTracker {
 
 }  // namespace dvo
 
+// dense_tracking.h:215-237
 template <typename CharT, typename Traits>
-std::basic_ostream<CharT, Traits> &operator<<(std::basic_ostream<CharT, Traits> &out, const dvo::DenseTracker::Config &c) {
-  out << "First Level = " << c.FirstLevel << ", Last Level = " << c.LastLevel
-      << ", Max Iterations per Level = " << c.MaxIterationsPerLevel << ", Precision = " << c.Precision << ", Mu = " << c.Mu
-      << ", Use Initial Estimate = " << (c.UseInitialEstimate ? "true" : "false")
-      << ", Intensity Derivative Threshold = " << c.IntensityDerivativeThreshold
-      << ", Depth Derivative Threshold = " << c.DepthDerivativeThreshold;
+std::ostream &operator<<(std::basic_ostream<CharT, Traits> &out, const dvo::DenseTracker::Config &config) {
+  out << "First Level = " << config.FirstLevel << ", Last Level = " << config.LastLevel
+      << ", Max Iterations per Level = " << config.MaxIterationsPerLevel << ", Precision = " << config.Precision
+      << ", Mu = " << config.Mu << ", Use Initial Estimate = " << (config.UseInitialEstimate ? "true" : "false")
+      << ", Use Weighting = " << (config.UseWeighting ? "true" : "false")
+      << ", Scale Estimator = " << dvo::core::ScaleEstimators::str(config.ScaleEstimatorType)
+      << ", Scale Estimator Param = " << config.ScaleEstimatorParam
+      << ", Influence Function = " << dvo::core::InfluenceFunctions::str(config.InfluenceFuntionType)
+      << ", Influence Function Param = " << config.InfluenceFunctionParam
+      << ", Intensity Derivative Threshold = " << config.IntensityDerivativeThreshold
+      << ", Depth Derivative Threshold = " << config.DepthDerivativeThreshold;
   return out;
+}
+
+// dense_tracking.h:239-245
+template <typename CharT, typename Traits>
+std::ostream &operator<<(std::basic_ostream<CharT, Traits> &o, const dvo::DenseTracker::IterationStats &s) {
+  o << "Iteration: " << s.Id << " ValidConstraints: " << s.ValidConstraints << " DataLogLikelihood: " << s.TDistributionLogLikelihood
+    << " PriorLogLikelihood: " << s.PriorLogLikelihood << std::endl;
+  return o;
+}
+
+// dense_tracking.h:247-279
+template <typename CharT, typename Traits>
+std::ostream &operator<<(std::basic_ostream<CharT, Traits> &o, const dvo::DenseTracker::LevelStats &s) {
+  std::string termination;
+  switch (s.TerminationCriterion) {
+    case dvo::DenseTracker::TerminationCriteria::IterationsExceeded: termination = "IterationsExceeded"; break;
+    case dvo::DenseTracker::TerminationCriteria::IncrementTooSmall: termination = "IncrementTooSmall"; break;
+    case dvo::DenseTracker::TerminationCriteria::LogLikelihoodDecreased: termination = "LogLikelihoodDecreased"; break;
+    case dvo::DenseTracker::TerminationCriteria::TooFewConstraints: termination = "TooFewConstraints"; break;
+    default: break;
+  }
+  o << "Level: " << s.Id << " Pixel: " << s.ValidPixels << "/" << s.MaxValidPixels << " Termination: " << termination
+    << " Iterations: " << s.Iterations.size() << std::endl;
+  for (dvo::DenseTracker::IterationStatsVector::const_iterator it = s.Iterations.begin(); it != s.Iterations.end(); ++it) o << *it;
+  return o;
+}
+
+// dense_tracking.h:281-291
+template <typename CharT, typename Traits>
+std::ostream &operator<<(std::basic_ostream<CharT, Traits> &o, const dvo::DenseTracker::Stats &s) {
+  o << s.Levels.size() << " levels" << std::endl;
+  for (dvo::DenseTracker::LevelStatsVector::const_iterator it = s.Levels.begin(); it != s.Levels.end(); ++it) o << *it;
+  return o;
 }
 
 #endif  // DVO_AMD_DENSE_TRACKING_HPP_

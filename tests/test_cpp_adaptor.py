@@ -62,6 +62,25 @@ def test_local_tracker_written_like_the_reference_compiles_against_the_forwardin
         assert os.path.exists(os.path.join(ROOT, "include", "dvo_amd_compat", fwd)), fwd
 
 
+def test_reference_call_sites_that_round_2_broke_compile_and_run():
+    """examples/boundary_callsites.cpp holds the bodies of dvo_ros' updateConfigFromDynamicReconfigure (configtools.h:32-82: every
+    Config field, the five dead ones and the two weight_calculation.h enums included) and of the statistics dump in
+    keyframe_graph.cpp:364-371 (stream operators of Stats / LevelStats / IterationStats, non-const LastIterationWithIncrement(),
+    InformationConditionNumber()) as the reference writes them, plus the includes <dvo/core/surface_pyramid.h> and
+    <dvo/core/point_selection_predicates.h>.  It needs no GPU: compiled with -Werror and RUN here."""
+    exe = _compile("boundary_callsites")
+    res = subprocess.run([exe], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    assert "boundary call sites ok" in res.stdout
+    # the statistics went through the reference's stream format (dense_tracking.h:239-291)
+    assert "2 levels" in res.stderr and "Termination: LogLikelihoodDecreased" in res.stderr and "kappa fine: " in res.stderr
+    assert "Iteration: 2 ValidConstraints: 3898 DataLogLikelihood: -10002 PriorLogLikelihood: 0" in res.stderr
+    for fwd in ("dvo/core/surface_pyramid.h", "dvo/core/point_selection_predicates.h", "dvo/core/weight_calculation.h"):
+        assert os.path.exists(os.path.join(ROOT, "include", "dvo_amd_compat", fwd)), fwd
+    text = open(os.path.join(ROOT, "examples", "local_tracker_example.cpp")).read()
+    assert "#include <dvo/core/point_selection_predicates.h>" in text  # local_tracker.cpp:24, dropped in round 2
+
+
 CEXE = os.path.join(ROOT, "examples", "_build", "c_abi_example")
 
 
