@@ -1014,17 +1014,19 @@ __device__ __forceinline__ void finalize_block(const FinItem &it, const bool sta
     const int b_end = (t + 1) * per < nb ? (t + 1) * per : nb;
     // four records' headers (64 bytes each) in flight at a time; the per-wave counts of the first four are kept in registers
     // for the prefix pass below, so a lane with at most four records (every level up to 256 blocks) reads its headers once
+    // (the 256-thread batch form keeps two in flight: it is built for 96 registers, see k_finalize)
+    constexpr int kHdr = NT == kFinThreadsBatch ? 2 : 4;
     unsigned cw_first[4][4] = {};
-    for (int b0 = t * per; b0 < b_end; b0 += 4) {
-      v4f h0[4], h1[4], h2[4], h3[4];
+    for (int b0 = t * per; b0 < b_end; b0 += kHdr) {
+      v4f h0[kHdr], h1[kHdr], h2[kHdr], h3[kHdr];
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
+      for (int k = 0; k < kHdr; ++k)
         if (b0 + k < b_end) {
           const gcf4 hp = reinterpret_cast<gcf4>(recs + (size_t)(b0 + k) * kRecStride);
           h0[k] = hp[0], h1[k] = hp[1], h2[k] = hp[2], h3[k] = hp[3];
         }
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
+      for (int k = 0; k < kHdr; ++k)
         if (b0 + k < b_end) {
           SegRec q;
           q.c = (int)f2u(h0[k].x);
@@ -1032,7 +1034,10 @@ __device__ __forceinline__ void finalize_block(const FinItem &it, const bool sta
           q.s0[0] = h1[k].x, q.s0[1] = h1[k].y, q.s0[2] = h1[k].z;
           q.s1[0] = h1[k].w, q.s1[1] = h2[k].x, q.s1[2] = h2[k].y;
           r = seg_combine(r, q);
-          if (b0 == t * per) cw_first[k][0] = f2u(h2[k].z), cw_first[k][1] = f2u(h2[k].w), cw_first[k][2] = f2u(h3[k].x), cw_first[k][3] = f2u(h3[k].y);
+          const int j = b0 - t * per + k;  // the lane's j-th record
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+            if (j == jj) cw_first[jj][0] = f2u(h2[k].z), cw_first[jj][1] = f2u(h2[k].w), cw_first[jj][2] = f2u(h3[k].x), cw_first[jj][3] = f2u(h3[k].y);
         }
     }
     const int own_total = r.c;
@@ -1104,7 +1109,7 @@ __device__ __forceinline__ void finalize_block(const FinItem &it, const bool sta
     if (c4 * 4 < kNumAcc) {
       const gcf base = recs + kRecAcc + c4 * 4;
       int b = chunk;
-      for (; b + 7 * kFinChunks < nb; b += 8 * kFinChunks) {  // eight independent 16-byte loads in flight per thread
+      for (; NT != kFinThreadsBatch && b + 7 * kFinChunks < nb; b += 8 * kFinChunks) {  // eight independent 16-byte loads in flight per thread (four in the 96-register batch form)
         v4f r[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) r[k] = *reinterpret_cast<gcf4>(base + (size_t)(b + k * kFinChunks) * kRecStride);
@@ -1180,8 +1185,11 @@ __device__ __forceinline__ void finalize_block(const FinItem &it, const bool sta
   DVO_FIN_STAMP(3);
 }
 
+// The batch form (256 threads) is built for 96 registers: next to four k_tick waves of 104 registers a SIMD has 96 left, so a
+// reducer block can start on a CU that is full of k_tick blocks (its 11 KB of LDS fit beside their 4 x 36.5 KB) instead of
+// waiting for one of them to retire.
 template <int NT, bool EXCHANGE>
-__global__ __launch_bounds__(NT) void k_finalize(const FinArgs args) {
+__global__ __launch_bounds__(NT, NT == kFinThreadsBatch ? 5 : 1) void k_finalize(const FinArgs args) {
   finalize_block<NT, EXCHANGE>(args.items[blockIdx.x], args.pad == 0x57A3 && blockIdx.x == 0,
                                EXCHANGE && blockIdx.x == 0 ? args.exchange : nullptr, args.xseq);
 }
@@ -1277,9 +1285,12 @@ hipError_t launch_level_planes(const float *i_plane, const float *z_plane, int w
 }
 
 // ValidPointAndGradientThresholdPredicate::isPointOk (point_selection.h:63-66) applied in place: zsel = z where the pixel
-// is selected, NaN elsewhere (and in the padding)
-__global__ void k_select(const float *__restrict__ zp, const float4 *__restrict__ c_a, const float2 *__restrict__ c_b, int n,
-                         int n_pad, float ti, float td, float *__restrict__ zsel, int *__restrict__ counters) {
+// is selected, NaN elsewhere (and in the padding).  Count and last selected index (selectPointsFromImage's running output
+// pointer, point_selection.cpp:119-152) leave every block as one {count, last index} pair -- no atomics: 10 000 same-address
+// atomics of a 640x480 level serialise to 100 us, the kernel streams its 9 MB in a tenth of that.
+__global__ __launch_bounds__(256) void k_select(const float *__restrict__ zp, const float4 *__restrict__ c_a,
+                                                const float2 *__restrict__ c_b, int n, int n_pad, float ti, float td,
+                                                float *__restrict__ zsel, int2 *__restrict__ block_partials) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   float out = u2f(0x7fc00000u);
   bool ok = false;
@@ -1292,31 +1303,53 @@ __global__ void k_select(const float *__restrict__ zp, const float4 *__restrict_
     if (ok) out = z;
   }
   if (i < n_pad) zsel[i] = out;
-  // count and last index (selectPointsFromImage's running output pointer, point_selection.cpp:119-152): one ballot per wave,
-  // one atomic pair per wave that selected anything -- the highest selected lane of a wave holds the wave's largest index
+  __shared__ int sh_cnt[4], sh_last[4];
   const unsigned long long m = __ballot(ok);
-  if (m != 0ull && (threadIdx.x & (kWave - 1)) == 63 - __builtin_clzll(m)) {
-    atomicAdd(&counters[0], __popcll(m));
-    atomicMax(&counters[1], i);
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    sh_cnt[wave] = __popcll(m);
+    sh_last[wave] = m ? (int)(blockIdx.x * blockDim.x) + wave * kWave + (63 - __builtin_clzll(m)) : -1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int c = 0, last = -1;
+    for (int w = 0; w < 4; ++w) c += sh_cnt[w], last = sh_last[w] > last ? sh_last[w] : last;
+    block_partials[blockIdx.x] = make_int2(c, last);
   }
 }
 
-// Q3: computeResidualsSse walks the selection two points at a time and never looks at an odd trailing point
-// (dense_tracking_impl.cpp:169-171)
-__global__ void k_select_drop_odd(float *zsel, const int *counters) {
-  if ((counters[0] & 1) && counters[1] >= 0) zsel[counters[1]] = u2f(0x7fc00000u);
+// one block: the level's count and last selected index from the block partials, then Q3 -- computeResidualsSse walks the
+// selection two points at a time and never looks at an odd trailing point (dense_tracking_impl.cpp:169-171)
+__global__ __launch_bounds__(256) void k_select_finish(const int2 *__restrict__ block_partials, int n_blocks, float *zsel,
+                                                       int *__restrict__ counters) {
+  int c = 0, last = -1;
+  for (int b = threadIdx.x; b < n_blocks; b += 256) {
+    const int2 p = block_partials[b];
+    c += p.x, last = p.y > last ? p.y : last;
+  }
+  __shared__ int sh_c[256], sh_l[256];
+  sh_c[threadIdx.x] = c, sh_l[threadIdx.x] = last;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      sh_c[threadIdx.x] += sh_c[threadIdx.x + s];
+      sh_l[threadIdx.x] = sh_l[threadIdx.x + s] > sh_l[threadIdx.x] ? sh_l[threadIdx.x + s] : sh_l[threadIdx.x];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    counters[0] = sh_c[0], counters[1] = sh_l[0];
+    if ((sh_c[0] & 1) && sh_l[0] >= 0) zsel[sh_l[0]] = u2f(0x7fc00000u);
+  }
 }
 
 hipError_t launch_select(const float *z_plane, const float4 *c_a, const float2 *c_b, int n, int n_pad, float ti, float td,
-                         float *zsel, int *counters, hipStream_t stream) {
+                         float *zsel, int *counters, int2 *block_partials, hipStream_t stream) {
   LaunchGuard guard;
-  hipError_t e = hipMemsetAsync(counters, 0, sizeof(int), stream);
-  if (e != hipSuccess) return e;
-  e = hipMemsetAsync(counters + 1, 0xFF, sizeof(int), stream);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_select, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, stream, z_plane, c_a, c_b, n, n_pad, ti,
-                     td, zsel, counters);
-  hipLaunchKernelGGL(k_select_drop_odd, dim3(1), dim3(1), 0, stream, zsel, (const int *)counters);
+  const int n_blocks = (n_pad + 255) / 256;
+  hipLaunchKernelGGL(k_select, dim3((unsigned)n_blocks), dim3(256), 0, stream, z_plane, c_a, c_b, n, n_pad, ti, td, zsel,
+                     block_partials);
+  hipLaunchKernelGGL(k_select_finish, dim3(1), dim3(256), 0, stream, (const int2 *)block_partials, n_blocks, zsel, counters);
   return hipGetLastError();
 }
 

@@ -160,6 +160,7 @@ struct dvo_amd_pyramid {
   void *slab = nullptr;
   size_t slab_bytes = 0;
   int *counters = nullptr;  // device, [levels][2], inside the slab
+  int2 *sel_partials = nullptr;  // device scratch of the selection kernels (level 0's block count), inside the slab
   void *desc_entry = nullptr;         // this pyramid's entry of the device's descriptor arena
   CurLevelDesc *cur_desc = nullptr;   // device, [levels], in desc_entry
   RefLevelDesc *ref_desc0 = nullptr;  // device, [levels], in desc_entry: room for the first selection's descriptors
@@ -192,6 +193,7 @@ size_t pyramid_layout(dvo_amd_pyramid *p, char *base) {
     L.ty = (float *)carve(sizeof(float) * L.h);
   }
   p->counters = (int *)carve(sizeof(int) * 2 * DVO_AMD_MAX_LEVELS);
+  p->sel_partials = (int2 *)carve(sizeof(int2) * (size_t)(p->lv[0].n_pad / 256 + 1));
   static_assert(sizeof(CurLevelDesc) * DVO_AMD_MAX_LEVELS <= 640 && 640 + sizeof(RefLevelDesc) * DVO_AMD_MAX_LEVELS <= kDescEntryBytes,
                 "a pyramid's level descriptors fit one arena entry");
   return off;
@@ -400,7 +402,7 @@ int pyramid_selection(dvo_amd_pyramid *p, float ti, float td, const Selection **
   if (e != hipSuccess) return fail("selection descriptors", e);
   for (int l = 0; l < p->n_levels; ++l) {
     const LevelData &L = p->lv[l];
-    e = launch_select(L.z_plane, L.c_a, L.c_b, L.n, L.n_pad, ti, td, s.zsel[l], p->counters + 2 * l, st);
+    e = launch_select(L.z_plane, L.c_a, L.c_b, L.n, L.n_pad, ti, td, s.zsel[l], p->counters + 2 * l, p->sel_partials, st);
     if (e != hipSuccess) return fail("select", e);
   }
   int host_counters[2 * DVO_AMD_MAX_LEVELS];

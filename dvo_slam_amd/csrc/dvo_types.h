@@ -208,8 +208,9 @@ hipError_t launch_level_planes(const float *i_plane, const float *z_plane, int w
                                float *tx, float *ty, int ty_len, hipStream_t stream);
 // selection: writes zsel (n_pad floats), counters[0] = count, counters[1] = index of last selected pixel (or -1);
 // then un-selects the last selected pixel if count is odd (Q3).
+// block_partials: scratch of n_pad / 256 int2 (per-block count and last index; no atomics)
 hipError_t launch_select(const float *z_plane, const float4 *c_a, const float2 *c_b, int n, int n_pad, float ti, float td,
-                         float *zsel, int *counters, hipStream_t stream);
+                         float *zsel, int *counters, int2 *block_partials, hipStream_t stream);
 // raw frame -> float base planes of level 0 (uint8 gray or BGR, uint16 depth with 0 = invalid)
 hipError_t launch_ingest(const unsigned char *img, int channels, int img_stride_bytes, const unsigned short *raw_z,
                          int z_stride, float z_scale, float *i_plane, float *z_plane, int w, int h, hipStream_t stream);

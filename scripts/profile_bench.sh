@@ -21,9 +21,13 @@ for s in $steps; do
       DVO_AMD_EXCHANGE=peer python3 "$R/bench.py" --tile-shard --steps 8 --warmup 3 > "$R/$out/bench_tileshard_peer.json" 2> "$R/$out/bench_tileshard_peer.err" || exit 1
       DVO_AMD_EXCHANGE=rccl python3 "$R/bench.py" --tile-shard --steps 8 --warmup 3 > "$R/$out/bench_tileshard_rccl.json" 2> "$R/$out/bench_tileshard_rccl.err" || exit 1 ;;
     stats1) rocprofv3 --kernel-trace --stats -d "$R/$out/stats_t1" -o bench --output-format csv -- python3 "$R/bench.py" --threads 1 --batch 72 --in-flight 36 --steps 10 --warmup 2 --no-extras --no-cpu-baseline > "$R/$out/bench_t1.json" 2> "$R/$out/bench_t1.err" || exit 1 ;;
-    stats) rocprofv3 --kernel-trace --stats -d "$R/$out/stats" -o bench --output-format csv -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-extras --no-cpu-baseline > "$R/$out/bench_stats.json" 2> "$R/$out/bench_stats.err" || exit 1 ;;
-    # the profiler itself has crashed (SIGSEGV inside its launch interception) on the 8-thread command; 4 host threads as a fallback
-    stats4) rocprofv3 --kernel-trace --stats -d "$R/$out/stats4" -o bench --output-format csv -- python3 "$R/bench.py" --steps 20 --warmup 5 --threads 4 --in-flight 144 --no-extras --no-cpu-baseline > "$R/$out/bench_stats4.json" 2> "$R/$out/bench_stats4.err" || exit 1 ;;
+    # The driver's 8-thread command under the kernel trace.  DVO_AMD_LAUNCH_LOCK=1: rocprofv3's queue interceptor reads past
+    # the end of an AQL ring when two host threads publish packets to one hardware queue across the ring's wrap
+    # (profiles/r03_rocprofv3_sigsegv_root_cause.md: the two SIGSEGVs of round 2); under the lock every doorbell finds one packet.
+    # DVO_BENCH_MAPS: /proc/self/maps of the run, so that any raw-address stack is attributable.
+    stats) export DVO_AMD_LAUNCH_LOCK=1 DVO_BENCH_MAPS="$R/$out/bench_stats.maps"
+      rocprofv3 --kernel-trace --stats -d "$R/$out/stats" -o bench --output-format csv -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-extras --no-cpu-baseline > "$R/$out/bench_stats.json" 2> "$R/$out/bench_stats.err" || exit 1
+      unset DVO_AMD_LAUNCH_LOCK DVO_BENCH_MAPS ;;
   esac
 done
 # the per-dispatch traces are large: keep the stats and drop the traces unless asked
