@@ -61,9 +61,9 @@ def parse():
     ap.add_argument("--prime", type=int, default=2,
                     help="untimed priming steps run as part of set-up before the W warm-up steps: the first calls grow "
                          "scratch buffers, streams and the HIP runtime's internal pools (a one-off ~40 ms stall)")
-    ap.add_argument("--in-flight", type=int, default=72,
+    ap.add_argument("--in-flight", type=int, default=96,
                     help="pairs resident per tracker at a time (0 = the whole share in lock step)")
-    ap.add_argument("--threads", type=int, default=8,
+    ap.add_argument("--threads", type=int, default=6,
                     help="host threads per GPU, each with its own tracker (HIP stream) and an equal share of the batch")
     ap.add_argument("--drain-between-steps", action="store_true",
                     help="one dvo_amd_match_many call per step and thread (the tracker drains to empty at the end of every step) "

@@ -122,6 +122,7 @@ struct LevelPairDesc {
   float2 *res[2];
   float *records;
   double *ll_partials;
+  float *ll_qmax;
   int *seg_prefix[2];
   int w, h;
   float wc[6], wr[4], ub_x, ub_y;
@@ -660,6 +661,12 @@ __device__ void loglik_pass(const TickItem &it, const LevelPairDesc &d, const in
   const float P0 = it.P[0], P1 = it.P[1], P2 = it.P[2], P3 = it.P[3];
   const unsigned long long below = (1ull << lane) - 1ull;
   double total = 0.0;
+  // The largest Mahalanobis distance among the residuals that count: the reference multiplies 50 consecutive terms
+  // 1 + 0.2 q in a double before it takes a log (dense_tracking_impl.cpp:413-419), and that product overflows -- likelihood
+  // -inf, iteration rejected -- when 50 consecutive q are all above ~7e6 (noise-free synthetic depth; never sensor data).
+  // Here a log is taken per 16 terms, so nothing overflows; the host is told the largest q of the pass and, only if one
+  // group of 50 COULD have overflowed, asks k_ll_overflow for the exact answer (dvo_tracker.cpp: ll_overflowed).
+  float qmax = 0.0f;
   if (steps > 0 && seg_before < cut_rank) {
     const DVO_GLOBAL v2f *src =
         (const DVO_GLOBAL v2f *)((it.flags & kItemLlBuf) ? d.res[1] : d.res[0]) + seg * (kStepPx * item_ll_steps(it)) + lane;
@@ -685,6 +692,7 @@ __device__ void loglik_pass(const TickItem &it, const LevelPairDesc &d, const in
             const float t1 = r[k].x * P2 + r[k].y * P3;
             const float q = t0 * r[k].x + t1 * r[k].y;
             prod *= (1.0 + 0.2 * (double)q);
+            qmax = __builtin_fmaxf(qmax, q);
           }
           continue;
         }
@@ -695,6 +703,7 @@ __device__ void loglik_pass(const TickItem &it, const LevelPairDesc &d, const in
           const float t1 = r[k].x * P2 + r[k].y * P3;
           const float q = t0 * r[k].x + t1 * r[k].y;
           prod *= (1.0 + 0.2 * (double)q);
+          qmax = __builtin_fmaxf(qmax, q);
         }
         run_count += __popcll(b);
       }
@@ -706,10 +715,78 @@ __device__ void loglik_pass(const TickItem &it, const LevelPairDesc &d, const in
     if (prod != 1.0) total += log(prod);
   }
   total = wave_sum_double(total);
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) qmax = __builtin_fmaxf(qmax, __shfl_xor(qmax, m, 64));
   __shared__ double smd[kWavesPerBlock];
-  if (lane == 0) smd[wave] = total;
+  __shared__ float smq[kWavesPerBlock];
+  if (lane == 0) smd[wave] = total, smq[wave] = qmax;
   __syncthreads();
-  if (threadIdx.x == 0) ((DVO_GLOBAL double *)d.ll_partials)[lb] = (smd[0] + smd[1]) + (smd[2] + smd[3]);
+  if (threadIdx.x == 0) {
+    ((DVO_GLOBAL double *)d.ll_partials)[lb] = (smd[0] + smd[1]) + (smd[2] + smd[3]);
+    ((DVO_GLOBAL float *)d.ll_qmax)[lb] = __builtin_fmaxf(__builtin_fmaxf(smq[0], smq[1]), __builtin_fmaxf(smq[2], smq[3]));
+  }
+}
+
+// The exact answer to "did the reference's 50-term likelihood product overflow?" for one residual buffer, asked only when the
+// pass above saw a Mahalanobis distance large enough to make it possible.  A block is ONE wave and owns the groups of fifty
+// consecutive valid residuals (in rank order) that START inside its chunk of `segs_per_block` wave segments of the residual
+// pass: the prefix table gives the rank of the chunk's first valid pixel, the wave skips what is left of the previous chunk's
+// last group, walks on in scan order -- past the end of its chunk until its last group is complete -- compacts the terms
+// 1 + 0.2 q into LDS in rank order, and lane g multiplies group g's fifty terms one after the other in a double: the
+// reference's own loop (error_acc *= ..., dense_tracking_impl.cpp:415-417), so the decision is the reference's bit for bit.
+constexpr int kOvfGroups = 64, kOvfWindow = kOvfGroups * 50;
+__global__ __launch_bounds__(kWave) void k_ll_overflow(const float2 *__restrict__ res, const int *__restrict__ seg_prefix, int seg_first,
+                                                       int n_segs, int segs_per_block, int seg_px, int rank_offset, int n_px,
+                                                       int cut_rank, float P0, float P1, float P2, float P3,
+                                                       unsigned *__restrict__ result_host) {
+  __shared__ double terms[kOvfWindow + kWave];
+  const int lane = threadIdx.x;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const int s0 = seg_first + (int)blockIdx.x * segs_per_block;      // first wave segment of the chunk
+  const int s1 = s0 + segs_per_block < seg_first + n_segs ? s0 + segs_per_block : seg_first + n_segs;
+  const int a = rank_offset + seg_prefix[s0];                        // global rank of the chunk's first valid pixel
+  // rank of the first valid pixel BEHIND the chunk (only the chunk's own segments are known to hold this pass's residuals)
+  const int e = s1 < seg_first + n_segs ? rank_offset + seg_prefix[s1] : 0x7fffffff;
+  const int first = a + (50 - a % 50) % 50;                          // first group that starts in the chunk
+  const int stop = e < cut_rank ? e + (50 - e % 50) % 50 : cut_rank; // ... and the end of the last one (cut_rank is a multiple of 50)
+  if (first >= stop) return;
+  int run = a, base = first;  // rank of the next valid pixel; rank of terms[0]
+  bool overflow = false;
+  auto flush = [&](int n_groups) {  // lanes 0 .. n_groups - 1 multiply one group each
+    __syncthreads();
+    if (lane < n_groups) {
+      double acc = 1.0;
+      for (int i = 0; i < 50; ++i) acc *= terms[lane * 50 + i];
+      overflow = overflow || !(acc <= 1.7976931348623157e308);
+    }
+    __syncthreads();
+  };
+  for (int i0 = s0 * seg_px; i0 < n_px && run < stop; i0 += kWave) {
+    const float2 r = res[i0 + lane];  // (the buffer is padded to whole wave segments)
+    const bool valid = r.x == r.x;
+    const unsigned long long b = __ballot(valid);
+    const int rank = run + __popcll(b & below);
+    if (valid && rank >= first && rank < stop) {
+      const float t0 = r.x * P0 + r.y * P1;
+      const float t1 = r.x * P2 + r.y * P3;
+      const float q = t0 * r.x + t1 * r.y;
+      terms[rank - base] = 1.0 + 0.2 * (double)q;
+    }
+    run += __popcll(b);
+    const int have = (run < stop ? run : stop) - base;
+    if (have >= kOvfWindow) {
+      flush(kOvfGroups);
+      const double t = terms[kOvfWindow + lane];  // at most 63 terms of the next window: move them to the front
+      __syncthreads();
+      if (lane < have - kOvfWindow) terms[lane] = t;
+      __syncthreads();
+      base += kOvfWindow;
+    }
+  }
+  const int left = (run < stop ? run : stop) - base;
+  if (left >= 50) flush(left / 50);  // (a last group cut short by the end of the buffer cannot exist: cut_rank <= V)
+  const unsigned long long any = __ballot(overflow);
+  if (lane == 0 && any) __hip_atomic_store(result_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Copy the descriptors into registers once, through the constant address space (scalar loads).  Read through plain global
@@ -731,7 +808,7 @@ __device__ __forceinline__ LevelPairDesc load_desc(const TickItem &it) {
   for (int i = 0; i < 4; ++i) d.wr[i] = c->wr[i];
   d.ub_x = c->ub_x, d.ub_y = c->ub_y;
   d.res[0] = s->res[0], d.res[1] = s->res[1];
-  d.records = s->records, d.ll_partials = s->ll_partials;
+  d.records = s->records, d.ll_partials = s->ll_partials, d.ll_qmax = s->ll_qmax;
   d.seg_prefix[0] = s->seg_prefix[0], d.seg_prefix[1] = s->seg_prefix[1];
   return d;
 }
@@ -1063,7 +1140,7 @@ __device__ __forceinline__ void finalize_block(const FinItem &it, const bool sta
         sh_out.valid = a.c;
         sh_out.has_res = 1;
         for (int i = 0; i < 3; ++i) sh_out.S[i] = a.s0[i], sh_out.S_odd[i] = a.s1[i];
-        sh_out.first_w = a.first_w, sh_out.last_r0 = a.l0, sh_out.last_r1 = a.l1, sh_out.pad_f = 0.0f;
+        sh_out.first_w = a.first_w, sh_out.last_r0 = a.l0, sh_out.last_r1 = a.l1;
       }
       // exclusive scan of the valid counts over the band's wave segments: the log-likelihood pass needs each pixel's
       // rank to honour the V % 50 cut (Q6)
@@ -1100,7 +1177,7 @@ __device__ __forceinline__ void finalize_block(const FinItem &it, const bool sta
       sh_out.valid = 0;
       sh_out.has_res = 0;
       for (int i = 0; i < 3; ++i) sh_out.S[i] = 0.0, sh_out.S_odd[i] = 0.0;
-      sh_out.first_w = sh_out.last_r0 = sh_out.last_r1 = sh_out.pad_f = 0.0f;
+      sh_out.first_w = sh_out.last_r0 = sh_out.last_r1 = 0.0f;
     }
   } else if (t >= kFinAccFirst && (t - kFinAccFirst) / kFinCol4 < kFinChunks) {
     // moments: 16-byte loads (4 columns), rows strided by the 32 chunks, four independent loads in flight per thread
@@ -1139,7 +1216,10 @@ __device__ __forceinline__ void finalize_block(const FinItem &it, const bool sta
       // the two spare column groups x 32 chunks sum the log-likelihood partials
       const int lane64 = chunk * 2 + (c4 - (kNumAcc + 3) / 4);
       const DVO_GLOBAL double *llp = (const DVO_GLOBAL double *)it.ll_partials + it.ll_first;
-      for (int b = lane64; b < it.n_ll_blocks; b += kFinChunks * 2) s0 += llp[b];
+      const DVO_GLOBAL float *qp = (const DVO_GLOBAL float *)((const DVO_GLOBAL double *)it.ll_partials + it.ll_qmax_off) + it.ll_first;
+      float qm = 0.0f;
+      for (int b = lane64; b < it.n_ll_blocks; b += kFinChunks * 2) s0 += llp[b], qm = __builtin_fmaxf(qm, qp[b]);
+      s1 = (double)qm;  // (rides in the second column of the spare group)
     }
     sh_acc[chunk][c4 * 4 + 0] = s0, sh_acc[chunk][c4 * 4 + 1] = s1;
     sh_acc[chunk][c4 * 4 + 2] = s2, sh_acc[chunk][c4 * 4 + 3] = s3;
@@ -1155,8 +1235,14 @@ __device__ __forceinline__ void finalize_block(const FinItem &it, const bool sta
   }
   if (t == kFinAccFirst + kNumAcc) {
     double s = 0.0;
-    for (int c = 0; c < kFinChunks; ++c) s += sh_acc[c][88] + sh_acc[c][92];  // first lanes of the two spare groups
+    double qm = 0.0;
+    for (int c = 0; c < kFinChunks; ++c) {  // first lanes of the two spare groups
+      s += sh_acc[c][88] + sh_acc[c][92];
+      qm = sh_acc[c][89] > qm ? sh_acc[c][89] : qm;
+      qm = sh_acc[c][93] > qm ? sh_acc[c][93] : qm;
+    }
     sh_out.ll_sum = s;
+    sh_out.ll_qmax = (float)qm;
     sh_out.has_ll = it.n_ll_blocks > 0 ? 1 : 0;
   }
   __syncthreads();
@@ -1219,6 +1305,17 @@ hipError_t launch_finalize(const FinArgs &args, hipStream_t stream) {
     hipLaunchKernelGGL((k_finalize<kFinThreadsBatch, false>), dim3((unsigned)args.n_items), dim3(kFinThreadsBatch), 0, stream, args);
   else
     hipLaunchKernelGGL((k_finalize<kFinThreads, false>), dim3((unsigned)args.n_items), dim3(kFinThreads), 0, stream, args);
+  return hipGetLastError();
+}
+
+hipError_t launch_ll_overflow(const float2 *res, const int *seg_prefix, int seg_first, int n_segs, int seg_px, int rank_offset,
+                              int n_px, int cut_rank, const float P[4], unsigned *result_host, hipStream_t stream) {
+  if (n_segs <= 0) return hipSuccess;
+  LaunchGuard guard;
+  const int segs_per_block = 8;
+  hipLaunchKernelGGL(k_ll_overflow, dim3((unsigned)((n_segs + segs_per_block - 1) / segs_per_block)), dim3(kWave), 0, stream, res,
+                     seg_prefix, seg_first, n_segs, segs_per_block, seg_px, rank_offset, n_px, cut_rank, P[0], P[1], P[2], P[3],
+                     result_host);
   return hipGetLastError();
 }
 

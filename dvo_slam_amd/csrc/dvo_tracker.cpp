@@ -428,6 +428,8 @@ struct JobSlot {
   float2 *res[2] = {nullptr, nullptr};
   float *records = nullptr;
   double *ll_partials = nullptr;
+  float *ll_qmax = nullptr;   // per likelihood block: the largest Mahalanobis distance it took (behind ll_partials)
+  unsigned ll_qmax_off = 0;   // ... its distance from ll_partials in doubles
   int *seg_prefix[2] = {nullptr, nullptr};
   FinWire *out = nullptr;     // pinned host memory as the device sees it: the record arrives here as tagged pieces
   FinOut *out_dev = nullptr;  // device staging of the record
@@ -478,6 +480,8 @@ struct dvo_amd_context {
   ncclResult_t (*p_allgather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*p_comm_destroy)(ncclComm_t) = nullptr;
   unsigned tick_seq = 0;
+  unsigned *ovf_host = nullptr, *ovf_dev = nullptr;  // pinned word for the verdict of k_ll_overflow (rare path)
+  long long ovf_checks = 0, ovf_hits = 0;            // how often the exact overflow check ran / said yes (diagnostic)
   // wave-step counts from which a tick takes 2 / 4 / 8 / 16 steps per wave.  Tuned on the throughput of several streams at once:
   // a launch that runs alone on the GPU would like segments half as long (more blocks to fill it), kernels that share the
   // GPU with three others gain more from fewer prologues and epilogues (+6 % pairs/s against 2048, 8192, 32768, 262144)
@@ -714,8 +718,10 @@ void system_from_moments(const FinOut &o, const float P[4], double mu, const dou
 }
 
 // computeCompleteDataLogLikelihood's last line, dense_tracking_impl.cpp:424
-float loglik_from_sum(int n, const float P[4], double ll_sum) {
+// `overflowed`: one of the reference's 50-term products ran past the double range: its error_sum is +inf (:416-419)
+float loglik_from_sum(int n, const float P[4], double ll_sum, bool overflowed = false) {
   const float det = P[0] * P[3] - P[1] * P[2];
+  if (overflowed) ll_sum = HUGE_VAL;
   return (float)(0.5 * (double)(size_t)n * (double)std::log(det) - 0.5 * (5.0 + 2.0) * ll_sum);
 }
 
@@ -765,10 +771,10 @@ void process_residual(Job &j, IterCtx &it, const FinOut &o) {
 }
 
 // the likelihood of iteration a came back: dense_tracking.cpp:297-322 and the tail of the loop (:351-357)
-void process_loglik(Job &j, const FinOut *outs) {
+void process_loglik(Job &j, const FinOut *outs, bool ll_overflowed = false) {
   IterCtx &a = j.a;
   const FinOut &o = outs[0];
-  const float ll = loglik_from_sum(a.n, a.P, o.ll_sum);
+  const float ll = loglik_from_sum(a.n, a.P, o.ll_sum, ll_overflowed);
   dvo_amd_iteration_stats *e = &j.recent[j.recent_count - 1];
   e->tdist_loglik = -(double)ll;
   e->tdist_mean[0] = e->tdist_mean[1] = 0.0;
@@ -847,10 +853,10 @@ int ensure_slots_impl(dvo_amd_context *ctx, int n_jobs, int n_pad) {
   const int max_blocks = new_pad / (kStepPx * kWavesPerBlock);  // one-step segments: the most blocks a level can have
   const size_t b_res = align_up(sizeof(float2) * new_pad, 256);
   const size_t b_rec = align_up(sizeof(float) * kRecStride * max_blocks, 256);
-  const size_t b_ll = align_up(sizeof(double) * max_blocks, 256);
+  const size_t b_ll = align_up(sizeof(double) * max_blocks, 256), b_lq = align_up(sizeof(float) * max_blocks, 256);
   const size_t b_sp = align_up(sizeof(int) * kWavesPerBlock * max_blocks, 256);
   const size_t b_out = align_up(sizeof(FinOut), 256);
-  const size_t total = 2 * b_res + b_rec + b_ll + 2 * b_sp + b_out;
+  const size_t total = 2 * b_res + b_rec + b_ll + b_lq + 2 * b_sp + b_out;
   ctx->slots.resize(n_slots);
   for (int i = 0; i < n_slots; ++i) {
     JobSlot &s = ctx->slots[i];
@@ -864,6 +870,8 @@ int ensure_slots_impl(dvo_amd_context *ctx, int n_jobs, int n_pad) {
     s.res[1] = (float2 *)p, p += b_res;
     s.records = (float *)p, p += b_rec;
     s.ll_partials = (double *)p, p += b_ll;
+    s.ll_qmax = (float *)p, p += b_lq;
+    s.ll_qmax_off = (unsigned)(b_ll / sizeof(double));
     s.seg_prefix[0] = (int *)p, p += b_sp;
     s.seg_prefix[1] = (int *)p, p += b_sp;
     s.out_dev = (FinOut *)p, p += b_out;
@@ -872,7 +880,7 @@ int ensure_slots_impl(dvo_amd_context *ctx, int n_jobs, int n_pad) {
     s.out = dev_out;
     SlotDesc &sd = slot_host[(size_t)i];
     sd.res[0] = s.res[0], sd.res[1] = s.res[1];
-    sd.records = s.records, sd.ll_partials = s.ll_partials;
+    sd.records = s.records, sd.ll_partials = s.ll_partials, sd.ll_qmax = s.ll_qmax;
     sd.seg_prefix[0] = s.seg_prefix[0], sd.seg_prefix[1] = s.seg_prefix[1];
   }
   HIP_TRY(hipMemcpy(ctx->slot_desc, slot_host.data(), sizeof(SlotDesc) * n_slots, hipMemcpyHostToDevice));
@@ -1065,7 +1073,8 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
     FinItem f;
     f.records = nullptr, f.n_blocks = 0, f.block_first = 0, f.n_ll_blocks = 0, f.ll_first = 0;
     f.ll_partials = j.slot->ll_partials;
-    f.seg_prefix_out = j.slot->seg_prefix[0], f.out = j.slot->out, f.out_dev = nullptr, f.seq = seq, f.pad = 0;
+    f.seg_prefix_out = j.slot->seg_prefix[0], f.out = j.slot->out, f.out_dev = nullptr, f.seq = seq;
+    f.ll_qmax_off = j.slot->ll_qmax_off;
     if (j.have_b) {
       j.b.steps = steps_now;
       while (j.b.steps < kMaxSteps && blocks_for(j.ref->lv[j.level].n, j.b.steps) > 2048) j.b.steps *= 2;
@@ -1209,6 +1218,38 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
   return DVO_AMD_OK;
 }
 
+// The reference's log-likelihood multiplies 50 consecutive terms 1 + 0.2 r^T P r in a double before it takes a log
+// (dense_tracking_impl.cpp:413-419); with precisions of 1e9 and more (noise-free synthetic depth) and a run of 50 large residuals
+// that product overflows, the likelihood is -inf and the iteration is rejected (:312).  The likelihood pass reports the largest
+// r^T P r it saw; only when a group of fifty COULD have overflowed (kLlOverflowScreen) this asks k_ll_overflow, which redoes
+// the reference's own multiplications group by group over the iteration's residual buffer (still intact: the next residual pass
+// wrote the other one).  Blocking and slow (0.2 ms for a 640x480 level), and rare: never on sensor data.
+struct OvfBand {  // a band of the residual pass: wave segments [seg_first, seg_first + n_segs), valid pixels in earlier bands
+  int seg_first, n_segs, rank_offset;
+};
+int ll_overflowed(dvo_amd_context *ctx, const float2 *res, const int *seg_prefix, int n_blocks, int steps, int cut_rank,
+                  const float P[4], const OvfBand *bands, int n_bands, bool *overflowed) {
+  *overflowed = false;
+  if (cut_rank < 50) return DVO_AMD_OK;
+  if (!ctx->ovf_host) {
+    HIP_TRY(hipHostMalloc((void **)&ctx->ovf_host, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_TRY(hipHostGetDevicePointer((void **)&ctx->ovf_dev, ctx->ovf_host, 0));
+  }
+  __atomic_store_n(ctx->ovf_host, 0u, __ATOMIC_RELEASE);
+  const int seg_px = kStepPx * steps, n_px = n_blocks * kWavesPerBlock * seg_px;
+  const OvfBand whole = {0, n_blocks * kWavesPerBlock, 0};
+  for (int b = 0; b < (bands ? n_bands : 1); ++b) {
+    const OvfBand &B = bands ? bands[b] : whole;
+    hipError_t e = launch_ll_overflow(res, seg_prefix, B.seg_first, B.n_segs, seg_px, B.rank_offset, n_px, cut_rank, P, ctx->ovf_dev,
+                                      ctx->stream);
+    if (e != hipSuccess) return fail_hip("launch_ll_overflow", e);
+  }
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  *overflowed = __atomic_load_n(ctx->ovf_host, __ATOMIC_ACQUIRE) != 0u;
+  ctx->ovf_checks++, ctx->ovf_hits += *overflowed ? 1 : 0;
+  return DVO_AMD_OK;
+}
+
 int complete_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
   if (!grp.in_flight) return DVO_AMD_OK;
   grp.in_flight = false;
@@ -1228,7 +1269,13 @@ int complete_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) 
     if (j.done || !(j.sub_ll || j.sub_res)) continue;
     const FinOut *o = ctx->out_host + (j.slot - ctx->slots.data());
     if (j.sub_ll) {
-      process_loglik(j, o);
+      bool overflowed = false;
+      if (o->ll_qmax >= kLlOverflowScreen) {
+        int rc = ll_overflowed(ctx, j.slot->res[j.a.buf], j.slot->seg_prefix[j.a.buf], j.a.n_blocks, j.a.steps, j.a.cut_rank, j.a.P,
+                               nullptr, 0, &overflowed);
+        if (rc) return rc;
+      }
+      process_loglik(j, o, overflowed);
     } else {
       IterCtx b = j.b;
       process_residual(j, b, *o);
@@ -1446,6 +1493,7 @@ void combine_bands(const FinOut *const *recs, int n, FinOut &out) {
     out.has_res |= r.has_res, out.has_ll |= r.has_ll;
     for (int i = 0; i < kNumAcc; ++i) out.acc[i] += r.acc[i];
     out.ll_sum += r.ll_sum;
+    out.ll_qmax = r.ll_qmax > out.ll_qmax ? r.ll_qmax : out.ll_qmax;
     if (!r.has_res || r.valid == 0) continue;
     if (c == 0) {
       for (int i = 0; i < 3; ++i) s0[i] = r.S[i], s1[i] = r.S_odd[i];
@@ -1496,6 +1544,7 @@ int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, i
     w.slot = ctx->slot_desc;  // every band works in slot 0's buffers (logical block indexing), disjoint ranges
     FinItem &f = fa.items[li];
     f.ll_partials = ctx->slots[0].ll_partials;
+    f.ll_qmax_off = ctx->slots[0].ll_qmax_off;
     f.seg_prefix_out = ctx->slots[0].seg_prefix[0];
     f.out = ctx->slots[(size_t)li].out;
     f.out_dev = exchange ? ctx->slots[(size_t)li].out_dev : nullptr;  // device copy: source of the all-gather / peer exchange
@@ -1582,7 +1631,23 @@ int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, i
   if (j.sub_res)
     for (int b = 0; b < n_bands; ++b) j.b.band_valid[b] = recs[b]->valid;
   if (j.sub_ll) {
-    process_loglik(j, &comb);
+    bool overflowed = false;
+    if (comb.ll_qmax >= kLlOverflowScreen && !exchange) {
+      // (all bands of the level were computed on this GPU, in slot 0's buffers: the exact check sees the whole level.  A pair
+      //  sharded over several GPUs holds only its own band here: the overflow artefact is not emulated on that path.)
+      OvfBand ob[kMaxBands];
+      int before = 0;
+      for (int b = 0; b < n_bands; ++b) {  // the prefix table is relative to each band (band_range of the pass's blocks)
+        int first = 0, count = 0;
+        band_range(j.a.n_blocks, n_bands, b, &first, &count);
+        ob[b].seg_first = first * kWavesPerBlock, ob[b].n_segs = count * kWavesPerBlock, ob[b].rank_offset = before;
+        before += j.a.band_valid[b];
+      }
+      int rc = ll_overflowed(ctx, ctx->slots[0].res[j.a.buf], ctx->slots[0].seg_prefix[j.a.buf], j.a.n_blocks, j.a.steps, j.a.cut_rank,
+                             j.a.P, ob, n_bands, &overflowed);
+      if (rc) return rc;
+    }
+    process_loglik(j, &comb, overflowed);
   } else {
     IterCtx bcopy = j.b;
     process_residual(j, bcopy, comb);
@@ -1734,6 +1799,9 @@ void dvo_amd_context_destroy(dvo_amd_context *ctx) {
                  ctx->prof_ticks, ctx->prof_job_ticks, ctx->prof_submit_ns / ctx->prof_ticks * 1e-3,
                  ctx->prof_wait_ns / ctx->prof_ticks * 1e-3, ctx->prof_process_ns / ctx->prof_ticks * 1e-3,
                  (ctx->prof_submit_ns + ctx->prof_process_ns) / std::max(1LL, ctx->prof_job_ticks) * 1e-3);
+  if (ctx->host_prof && ctx->ovf_checks > 0)
+    std::fprintf(stderr, "[dvo_amd host profile] exact likelihood-overflow checks: %lld (%lld said the reference's product overflowed)\n",
+                 ctx->ovf_checks, ctx->ovf_hits);
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->runner) {
@@ -1751,6 +1819,7 @@ void dvo_amd_context_destroy(dvo_amd_context *ctx) {
   if (ctx->desc_ready) (void)hipEventDestroy(ctx->desc_ready);
   release_slots(ctx);
   if (ctx->out_wire) (void)hipHostFree(ctx->out_wire);
+  if (ctx->ovf_host) (void)hipHostFree(ctx->ovf_host);
   for (auto &ev : ctx->events) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
@@ -2250,6 +2319,7 @@ int single_tick(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyrami
   fa.n_items = 1;
   FinItem &f = fa.items[0];
   f.ll_partials = s.ll_partials;
+  f.ll_qmax_off = s.ll_qmax_off;
   f.seg_prefix_out = s.seg_prefix[0];
   f.out = s.out;
   f.out_dev = nullptr;
@@ -2348,7 +2418,15 @@ int dvo_amd_debug_iteration(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dv
   rc = take_record_synced(ctx, 0, ctx->tick_seq);
   if (rc) return rc;
   out->loglik_sum = ctx->out_host[0].ll_sum;
-  out->loglik = loglik_from_sum(o.valid, P, out->loglik_sum);
+  bool overflowed = false;
+  if (ctx->out_host[0].ll_qmax >= kLlOverflowScreen) {
+    int st = pick_steps(ctx, R.n);  // (the geometry single_tick used)
+    while (st < kMaxSteps && blocks_for(R.n, st) > 2048) st *= 2;
+    rc = ll_overflowed(ctx, ctx->slots[0].res[0], ctx->slots[0].seg_prefix[0], blocks_for(R.n, st), st, 50 * (o.valid / 50), P, nullptr, 0,
+                       &overflowed);
+    if (rc) return rc;
+  }
+  out->loglik = loglik_from_sum(o.valid, P, out->loglik_sum, overflowed);
   return DVO_AMD_OK;
 }
 

@@ -50,6 +50,7 @@ struct SlotDesc {  // one per job slot of a context: scratch of the pair being a
   float2 *res[2];       // residual buffers (double buffered by iteration parity), NaN = invalid
   float *records;       // residual pass: n_blocks x kRecStride floats
   double *ll_partials;  // log-likelihood pass: one double per block
+  float *ll_qmax;       // ... and the largest Mahalanobis distance the block took (see loglik_pass)
   int *seg_prefix[2];   // per wave segment: valid pixels before it within its band, for the pass that filled res[i]
 };
 
@@ -104,7 +105,8 @@ struct FinOut {
   unsigned seq;    // written last (system scope): the tick number this record belongs to
   double S[3];     // sum over pairs (w_2j + w_2j+1) r_2j r_2j^T  (xx, xy, yy), unscaled (Q5 pairing), band starts even
   double S_odd[3]; // the same if the band's first valid pixel had an odd global rank (used when bands are combined)
-  float first_w, last_r0, last_r1, pad_f;  // boundary data of the band for the ordered combine
+  float first_w, last_r0, last_r1;  // boundary data of the band for the ordered combine
+  float ll_qmax;   // the largest Mahalanobis distance r^T P r among the residuals of the likelihood pass (overflow screen)
   double acc[kNumAcc];
   double ll_sum;   // sum of log(1 + 0.2 r^T P r) over the first 50*floor(V/50) valid residuals (Q6)
 };
@@ -152,7 +154,7 @@ struct FinItem {
   FinWire *out;           // host (pinned, device-visible): where the record is published, as tagged pieces
   FinOut *out_dev;        // optional device copy of the record (multi-GPU exchange), or null
   unsigned seq;
-  unsigned pad;
+  unsigned ll_qmax_off;   // the per-block maxima of the likelihood pass live ll_qmax_off doubles behind ll_partials
 };
 constexpr int kMaxFinItems = kMaxItemsPerLaunch;  // 64 B each: one reduce launch per tick launch
 struct FinArgs {
@@ -198,6 +200,14 @@ hipError_t launch_tick_small(const TickArgsSmall &args, int max_blocks, hipStrea
                              hipEvent_t t_stop = nullptr);
 hipError_t launch_finalize_small(const FinArgsSmall &args, hipStream_t stream);
 hipError_t launch_finalize(const FinArgs &args, hipStream_t stream);
+// exact emulation of the reference's overflowing 50-term likelihood product over (a band of) one residual buffer (rare; see
+// k_ll_overflow): wave segments [seg_first, seg_first + n_segs) of seg_px pixels each, seg_prefix = the pass's prefix table
+// (valid pixels before each segment, relative to the band), rank_offset = valid pixels in earlier bands, n_px = pixels the
+// pass wrote.  *result_host (pinned, zeroed by the caller) is set to 1 when a group of fifty overflowed.
+hipError_t launch_ll_overflow(const float2 *res, const int *seg_prefix, int seg_first, int n_segs, int seg_px, int rank_offset,
+                              int n_px, int cut_rank, const float P[4], unsigned *result_host, hipStream_t stream);
+// a Mahalanobis distance below this cannot make a group of fifty terms 1 + 0.2 q overflow a double (50 log2(1 + 0.2 q) < 1024)
+constexpr float kLlOverflowScreen = 7.0e6f;
 hipError_t read_finalize_stamps(unsigned long long out[8]);
 
 // prep (pyramid construction) kernels

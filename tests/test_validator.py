@@ -199,7 +199,7 @@ def _like_with_like(orc, synth, ov, stage, g_props, notes):
         assert p.origin in hist, (p.origin, sorted(hist))
         _, _, rid, cid, init, ro = hist[p.origin]
         assert (rid, cid) == (p.Reference.id, p.Current.id)
-        ro, artefact = fork_criterion.without_overflow(orc, stage.TrackingConfig, ov.images[rid], ov.images[cid], init, ro)
+        artefact = fork_criterion.overflow_note(ro)
         if artefact:
             notes.append(f"{rid}->{cid} origin {p.origin}: {artefact}")
         err = synth.pose_error(ro["T"], p.TrackingResult.Transformation)
