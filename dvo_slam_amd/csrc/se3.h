@@ -9,13 +9,21 @@
 #include <cmath>
 #include <cstring>
 
+// every source of the library is compiled as HIP: the helpers are callable from device code as well (used by the one-lane
+// cost probe of a device-side Gauss-Newton loop, scripts/probes/gn_lane_cost.hip; the product keeps them on the host)
+#if defined(__HIPCC__)
+#define DVO_HD __host__ __device__
+#else
+#define DVO_HD
+#endif
+
 namespace dvo_amd {
 
 struct SE3 {
   double q[4];
   double t[3];
 
-  static SE3 identity() {
+  DVO_HD static SE3 identity() {
     SE3 a;
     a.q[0] = 1.0, a.q[1] = a.q[2] = a.q[3] = 0.0;
     a.t[0] = a.t[1] = a.t[2] = 0.0;
@@ -26,26 +34,26 @@ struct SE3 {
 namespace se3_detail {
 constexpr double kEps = 1e-10;  // Sophus::SophusConstants<double>::epsilon()
 
-inline void rotation_of(const double q[4], double R[3][3]) {
+DVO_HD inline void rotation_of(const double q[4], double R[3][3]) {
   const double w = q[0], x = q[1], y = q[2], z = q[3];
   R[0][0] = 1 - 2 * (y * y + z * z), R[0][1] = 2 * (x * y - w * z), R[0][2] = 2 * (x * z + w * y);
   R[1][0] = 2 * (x * y + w * z), R[1][1] = 1 - 2 * (x * x + z * z), R[1][2] = 2 * (y * z - w * x);
   R[2][0] = 2 * (x * z - w * y), R[2][1] = 2 * (y * z + w * x), R[2][2] = 1 - 2 * (x * x + y * y);
 }
 
-inline void rotate(const double q[4], const double v[3], double out[3]) {
+DVO_HD inline void rotate(const double q[4], const double v[3], double out[3]) {
   double R[3][3];
   rotation_of(q, R);
   for (int i = 0; i < 3; ++i) out[i] = R[i][0] * v[0] + R[i][1] * v[1] + R[i][2] * v[2];
 }
 
-inline void normalize(double q[4]) {
+DVO_HD inline void normalize(double q[4]) {
   const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
   for (int i = 0; i < 4; ++i) q[i] /= n;
 }
 
 // skew(w) and skew(w)^2
-inline void skew_pair(const double w[3], double O[3][3], double O2[3][3]) {
+DVO_HD inline void skew_pair(const double w[3], double O[3][3], double O2[3][3]) {
   O[0][0] = 0, O[0][1] = -w[2], O[0][2] = w[1];
   O[1][0] = w[2], O[1][1] = 0, O[1][2] = -w[0];
   O[2][0] = -w[1], O[2][1] = w[0], O[2][2] = 0;
@@ -55,7 +63,7 @@ inline void skew_pair(const double w[3], double O[3][3], double O2[3][3]) {
 }  // namespace se3_detail
 
 // a * b
-inline SE3 se3_compose(const SE3 &a, const SE3 &b) {
+DVO_HD inline SE3 se3_compose(const SE3 &a, const SE3 &b) {
   SE3 o;
   o.q[0] = a.q[0] * b.q[0] - a.q[1] * b.q[1] - a.q[2] * b.q[2] - a.q[3] * b.q[3];
   o.q[1] = a.q[0] * b.q[1] + a.q[1] * b.q[0] + a.q[2] * b.q[3] - a.q[3] * b.q[2];
@@ -68,7 +76,7 @@ inline SE3 se3_compose(const SE3 &a, const SE3 &b) {
   return o;
 }
 
-inline SE3 se3_inverse(const SE3 &a) {
+DVO_HD inline SE3 se3_inverse(const SE3 &a) {
   SE3 o;
   o.q[0] = a.q[0], o.q[1] = -a.q[1], o.q[2] = -a.q[2], o.q[3] = -a.q[3];
   const double nt[3] = {-a.t[0], -a.t[1], -a.t[2]};
@@ -77,7 +85,7 @@ inline SE3 se3_inverse(const SE3 &a) {
 }
 
 // column-major 4x4
-inline void se3_matrix(const SE3 &a, double T[16]) {
+DVO_HD inline void se3_matrix(const SE3 &a, double T[16]) {
   double R[3][3];
   se3_detail::rotation_of(a.q, R);
   for (int c = 0; c < 3; ++c) {
@@ -88,7 +96,7 @@ inline void se3_matrix(const SE3 &a, double T[16]) {
   T[15] = 1.0;
 }
 
-inline SE3 se3_from_matrix(const double T[16]) {
+DVO_HD inline SE3 se3_from_matrix(const double T[16]) {
   double R[3][3];
   for (int c = 0; c < 3; ++c)
     for (int r = 0; r < 3; ++r) R[r][c] = T[c * 4 + r];
@@ -117,7 +125,7 @@ inline SE3 se3_from_matrix(const double T[16]) {
 }
 
 // Sophus::SE3d::exp: xi = (upsilon, omega)
-inline SE3 se3_exp(const double xi[6]) {
+DVO_HD inline SE3 se3_exp(const double xi[6]) {
   using namespace se3_detail;
   const double *ups = xi, *om = xi + 3;
   const double th2 = om[0] * om[0] + om[1] * om[1] + om[2] * om[2];
@@ -147,7 +155,7 @@ inline SE3 se3_exp(const double xi[6]) {
 }
 
 // Sophus::SE3d::log
-inline void se3_log(const SE3 &a, double xi[6]) {
+DVO_HD inline void se3_log(const SE3 &a, double xi[6]) {
   using namespace se3_detail;
   const double n2 = a.q[1] * a.q[1] + a.q[2] * a.q[2] + a.q[3] * a.q[3];
   const double n = std::sqrt(n2), w = a.q[0];
@@ -176,14 +184,14 @@ inline void se3_log(const SE3 &a, double xi[6]) {
 }
 
 // Eigen::Matrix2f::inverse() (compute_inverse_size2_helper), column-major, float arithmetic
-inline void inverse2x2f(const float m[4], float r[4]) {
+DVO_HD inline void inverse2x2f(const float m[4], float r[4]) {
   const float det = m[0] * m[3] - m[1] * m[2];
   const float inv = 1.0f / det;
   r[0] = m[3] * inv, r[1] = -m[1] * inv, r[2] = -m[2] * inv, r[3] = m[0] * inv;
 }
 
 // x = A^-1 b through a diagonally pivoted L D L^T, as Eigen::LDLT<Matrix6d>::solve.  A column-major, symmetric.
-inline void solve_ldlt6(const double A_in[36], const double b[6], double x[6]) {
+DVO_HD inline void solve_ldlt6(const double A_in[36], const double b[6], double x[6]) {
   double A[6][6];
   int p[6];
   for (int i = 0; i < 6; ++i) {
@@ -195,9 +203,16 @@ inline void solve_ldlt6(const double A_in[36], const double b[6], double x[6]) {
     for (int i = k + 1; i < 6; ++i)
       if (std::fabs(A[i][i]) > std::fabs(A[piv][piv])) piv = i;
     if (piv != k) {
-      for (int j = 0; j < 6; ++j) std::swap(A[k][j], A[piv][j]);
-      for (int i = 0; i < 6; ++i) std::swap(A[i][k], A[i][piv]);
-      std::swap(p[k], p[piv]);
+      for (int j = 0; j < 6; ++j) {
+        const double tmp = A[k][j];
+        A[k][j] = A[piv][j], A[piv][j] = tmp;
+      }
+      for (int i = 0; i < 6; ++i) {
+        const double tmp = A[i][k];
+        A[i][k] = A[i][piv], A[i][piv] = tmp;
+      }
+      const int tp = p[k];
+      p[k] = p[piv], p[piv] = tp;
     }
     const double d = A[k][k];
     if (d == 0.0) continue;
@@ -218,7 +233,7 @@ inline void solve_ldlt6(const double A_in[36], const double b[6], double x[6]) {
   for (int i = 0; i < 6; ++i) x[p[i]] = y[i];
 }
 
-inline double inf_norm6(const double x[6]) {
+DVO_HD inline double inf_norm6(const double x[6]) {
   double m = std::fabs(x[0]);
   for (int i = 1; i < 6; ++i)
     if (std::fabs(x[i]) > m) m = std::fabs(x[i]);
