@@ -368,8 +368,8 @@ def main():
                                "upper-level view, not the bytes HBM actually moved: see `traffic` and `issue`",
                 "speculation_waste": {"discarded_fraction_of_submitted_bytes": (discarded_k / alg_bytes_k) if alg_bytes_k else None,
                                       "achieved_counting_discarded_passes": alg_bytes_k / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0},
-                "traffic": traffic_from_profiles(),
-                "traffic_source": traffic_source(),
+                "traffic": traffic_from_profiles(args),
+                "traffic_source": traffic_source(args),
                 "kernel": "k_tick (fused warp+residual+weights+normal equations, with the log-likelihood items of the tick)",
                 "launches": int(k_launches),
                 "avg_launch_us": (k_ms * 1e3 / k_launches) if k_launches else None,
@@ -604,10 +604,18 @@ def pin_to_gpu_numa_node(device):
 TRAFFIC_FILE = "r03_traffic.json"
 
 
-def traffic_from_profiles():
-    """HBM-side bytes per k_tick launch from the committed PMC passes (profiles/r02_traffic.json: rocprofv3 --pmc FETCH_SIZE
+def profiled_workload(args):
+    """The counter passes ran the default workload (the driver's command): their figure says nothing about another one."""
+    return (args.width, args.height, args.batch, args.distinct, args.distinct_refs, args.threads, args.in_flight) == \
+           (640, 480, 1152, 96, 12, 6, 96) and not args.no_stats and not args.drain_between_steps
+
+
+def traffic_from_profiles(args):
+    """HBM-side bytes per k_tick launch from the committed PMC passes (profiles/r03_traffic.json: rocprofv3 --pmc FETCH_SIZE
     and WRITE_SIZE in separate runs of the default command, gfx950 correction applied); counters cannot be read from inside
-    the bench, so this is the figure of the profiled run (see traffic_source), not of this one."""
+    the bench, so this is the figure of the profiled run (see traffic_source), not of this one.  null for any other workload."""
+    if not profiled_workload(args):
+        return None
     try:
         here = os.path.dirname(os.path.abspath(__file__))
         return json.load(open(os.path.join(here, "profiles", TRAFFIC_FILE)))["traffic_bytes_per_launch"]
@@ -615,7 +623,9 @@ def traffic_from_profiles():
         return None
 
 
-def traffic_source():
+def traffic_source(args):
+    if not profiled_workload(args):
+        return None
     try:
         here = os.path.dirname(os.path.abspath(__file__))
         d = json.load(open(os.path.join(here, "profiles", TRAFFIC_FILE)))
