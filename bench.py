@@ -123,6 +123,28 @@ def plumbing_only(args):
         dist.destroy_process_group()
 
 
+def run_with_deadline(fn, seconds, what):
+    """fn() on its own daemon thread -> (result, hung).  An exception becomes {"error": ...}; a call still running at the
+    deadline becomes ({"error": ...}, True) and keeps its thread: the caller must then leave through os._exit once its output
+    is written (a rank stuck inside a collective cannot be cancelled)."""
+    import threading
+
+    box = {}
+
+    def run():
+        try:
+            box["out"] = fn()
+        except BaseException as exc:  # a side measurement never fails the bench line
+            box["out"] = {"error": repr(exc)}
+
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        return {"error": f"the {what} did not finish within {seconds:g} s (a rank failed inside a collective?); dropped"}, True
+    return box.get("out"), False
+
+
 def pair_index(i, n_refs, n_curs):
     """pair i of a step -> (keyframe, frame): all n_refs * n_curs combinations before any repeats"""
     return i % n_refs, (i // n_refs) % n_curs
@@ -294,20 +316,31 @@ def main():
         alg_bytes_k = sum(o.alg_bytes for o in out)
         discarded_k = sum(o.alg_bytes_discarded for o in out)
     elapsed_local = elapsed
-    tile_shard = None
-    if world > 1 and (not args.rehearse_on_one_gpu or os.environ.get("DVO_AMD_EXCHANGE") == "peer"):
-        # (a one-GPU rehearsal can only exercise the peer exchange: RCCL refuses two ranks on one device)
-        # BASELINE config 4 from the driver's own multi-GPU command: every rank takes part (the exchange is collective)
-        del trackers[1:]
-        try:
-            tile_shard = tile_shard_measure(args, capi, synth, dist, rank, world, device, K, levels, first_level,
-                                            steps=max(2, args.steps // 4), warmup=1)
-        except Exception as exc:  # pragma: no cover - a side measurement never fails the bench line
-            tile_shard = {"error": repr(exc)}
     # MAX over ranks of the elapsed time, SUM over ranks of the pairs aligned
     elapsed, pairs = sharding.aggregate(elapsed, B * args.steps, dist,
                                         None if dist is None else ("cpu" if args.rehearse_on_one_gpu else "cuda"))
     value = pairs / elapsed
+
+    tile_shard = None
+    side_hung = False
+    if world > 1 and (not args.rehearse_on_one_gpu or os.environ.get("DVO_AMD_EXCHANGE") == "peer"):
+        # (a one-GPU rehearsal can only exercise the peer exchange: RCCL refuses two ranks on one device)
+        # BASELINE config 4 from the driver's own multi-GPU command: every rank takes part (the exchange is collective).
+        # The headline figure above is complete at this point.  The side measurement runs under a deadline on its own thread:
+        # a collective that one rank never enters cannot be cancelled, so a rank whose measurement is still running at the
+        # deadline reports that, prints the line (rank 0) and leaves with os._exit -- the bench line is never lost to it.
+        del trackers[1:]
+
+        def side():
+            import torch
+
+            if torch.cuda.is_available():
+                torch.cuda.set_device(device)
+            return tile_shard_measure(args, capi, synth, dist, rank, world, device, K, levels, first_level,
+                                      steps=max(2, args.steps // 4), warmup=1)
+
+        tile_shard, side_hung = run_with_deadline(side, float(os.environ.get("DVO_BENCH_SIDE_DEADLINE_S", "120")),
+                                                  "tile-shard side measurement on rank %d" % rank)
 
     if rank == 0:
         if T == 1:
@@ -429,6 +462,9 @@ def main():
                 except Exception as exc:  # pragma: no cover - side measurements never fail the bench line
                     line[name] = {"error": repr(exc)}
         print(json.dumps(line), flush=True)
+    if side_hung:  # a thread of this process is stuck inside a collective: no orderly teardown is possible
+        sys.stdout.flush()
+        os._exit(0)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -258,6 +258,30 @@ def test_bench_gpus_flag_spawns_the_ranks_itself():
         assert line["metric"].startswith("frame-pairs/s") and line["scaling"] == "weak"
 
 
+def test_bench_side_measurement_cannot_take_the_bench_line_with_it():
+    """The multi-GPU side measurement (tile shard, collective) runs under a deadline: a result comes back as it is, an exception
+    as an error entry, and a call that never returns -- a rank stuck in a collective another rank never entered -- is reported
+    as hung so that the bench prints its line and leaves."""
+    import importlib.util
+    import threading
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.run_with_deadline(lambda: {"us_per_tick": 24.0}, 5.0, "x") == ({"us_per_tick": 24.0}, False)
+
+    def boom():
+        raise RuntimeError("hipIpcOpenMemHandle failed")
+
+    out, hung = bench.run_with_deadline(boom, 5.0, "x")
+    assert not hung and "hipIpcOpenMemHandle failed" in out["error"]
+    never = threading.Event()
+    out, hung = bench.run_with_deadline(lambda: never.wait(60.0), 0.2, "tile-shard side measurement on rank 1")
+    assert hung and "rank 1" in out["error"] and "did not finish" in out["error"]
+    never.set()
+
+
 def test_bench_pair_index_covers_every_combination_before_repeating():
     import importlib.util
 
