@@ -210,6 +210,7 @@ int dvo_amd_proposals_for_candidates(const dvo_amd_keyframe *keyframes, int keyf
   return DVO_AMD_OK;
 }
 
+extern "C++" {  // (helpers with C++ types inside the extern "C" block of the entry points)
 namespace {
 // worker contexts of the validator, per device, kept for the life of the process
 struct WorkerPool {
@@ -259,6 +260,7 @@ int validator_threads() {
   return n;
 }
 }  // namespace
+}  // extern "C++"
 
 int dvo_amd_validate_proposals(dvo_amd_context *ctx, int n_keyframes, const dvo_amd_keyframe *keyframes, int n_stages,
                                const dvo_amd_validator_stage *stages, int n_proposals,
