@@ -440,6 +440,10 @@ def main():
                         "of 64 pixels per wave",
                 "achieved": ab_i / ms_i / 1e6, "unit": "GB/s", "frac": ab_i / ms_i / 1e6 / HBM_PEAK_GBS,
                 "launch_us": ms_i * 1e3 / nl_i, "alg_bytes_per_launch": ab_i / nl_i}
+            # the timed region against what the kernel body reaches on its best case in this very run (the level-0 pass alone on
+            # the GPU sits on the kernel's practical issue ceiling): how much of that the whole job keeps
+            line["roofline"]["concurrent"]["fraction_of_the_isolated_kernel"] = (
+                line["roofline"]["concurrent"]["frac"] / line["roofline_isolated_kernel"]["frac"])
         except Exception as exc:  # pragma: no cover
             line["roofline_isolated_kernel"] = {"error": str(exc)}
         if tile_shard is not None:
