@@ -1276,6 +1276,10 @@ __device__ __forceinline__ void finalize_block(const FinItem &it, const bool sta
 // waiting for one of them to retire.
 template <int NT, bool EXCHANGE>
 __global__ __launch_bounds__(NT, NT == kFinThreadsBatch ? 5 : 1) void k_finalize(const FinArgs args) {
+  // A reducer block is a few thousand cycles of work on the critical path of its group's tick, started on a CU whose SIMDs are
+  // busy with four k_tick waves each: at the default priority it gets a fifth of the issue slots and takes twice as long as alone
+  // on the GPU.  (DVO_AMD_FIN_PRIORITY=0 turns this off for an A/B.)
+  if (args.pad2 & kFinFlagPriority) __builtin_amdgcn_s_setprio(3);
   finalize_block<NT, EXCHANGE>(args.items[blockIdx.x], args.pad == 0x57A3 && blockIdx.x == 0,
                                EXCHANGE && blockIdx.x == 0 ? args.exchange : nullptr, args.xseq);
 }

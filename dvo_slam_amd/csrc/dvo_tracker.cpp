@@ -489,6 +489,7 @@ struct dvo_amd_context {
                                                          // (DVO_AMD_STEPS_AT="a,b,c,d", read when the context is created)
   int fault_slot_alloc = -1;           // DVO_AMD_FAULT_SLOT_ALLOC: fail the allocation of this slot once (tests of the error path)
   bool fin_stamps = false;             // DVO_AMD_FIN_STAMPS=1: k_finalize records phase stamps (diagnostic)
+  bool fin_priority = true;            // the batch reducer's waves run at raised issue priority (DVO_AMD_FIN_PRIORITY=0: off)
   bool small_args = true;              // ticks of at most kMaxSmallItems pairs use the small argument blocks (DVO_AMD_SMALL_ARGS=0: never)
   bool poll = true;                    // wait for a tick by polling the records' sequence words instead of hipStreamSynchronize
   // optional kernel timing (bench.py roofline section)
@@ -1207,7 +1208,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
     FinArgs fa;
     fa.n_items = n_here;
     fa.pad = ctx->fin_stamps ? 0x57A3 : 0;
-    fa.exchange = nullptr, fa.xseq = 0, fa.pad2 = 0;
+    fa.exchange = nullptr, fa.xseq = 0, fa.pad2 = ctx->fin_priority ? kFinFlagPriority : 0u;
     for (int i = 0; i < n_here; ++i) fa.items[i] = fin_items[first + (size_t)i];
     for (int i = n_here; i < kMaxFinItems; ++i) fa.items[i] = fa.items[0];  // the whole block is copied by the launch: no stale stack bytes
     e = launch_finalize(fa, st);
@@ -1771,6 +1772,8 @@ int dvo_amd_context_create(int device, const dvo_amd_config *cfg, dvo_amd_contex
   ctx->poll = !(pe && pe[0] == '0');
   const char *fs = getenv("DVO_AMD_FIN_STAMPS");
   ctx->fin_stamps = fs && fs[0] == '1';
+  const char *fp = getenv("DVO_AMD_FIN_PRIORITY");
+  ctx->fin_priority = !(fp && fp[0] == '0');
   const char *sa = getenv("DVO_AMD_SMALL_ARGS");
   ctx->small_args = !(sa && sa[0] == '0');
   const char *hp = getenv("DVO_AMD_HOST_PROF");

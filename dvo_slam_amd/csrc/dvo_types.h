@@ -156,13 +156,14 @@ struct FinItem {
   unsigned seq;
   unsigned ll_qmax_off;   // the per-block maxima of the likelihood pass live ll_qmax_off doubles behind ll_partials
 };
+constexpr unsigned kFinFlagPriority = 1;  // the reducer's waves raise their issue priority (s_setprio)
 constexpr int kMaxFinItems = kMaxItemsPerLaunch;  // 64 B each: one reduce launch per tick launch
 struct FinArgs {
   int n_items;
   int pad;
   const struct ExchangeArgs *exchange;  // tile-sharded pair: push item 0's record to the peers, gather theirs (else null)
   unsigned xseq;          // sequence number of this tick's exchange
-  unsigned pad2;
+  unsigned pad2;          // kFinFlag* bits
   FinItem items[kMaxFinItems];
 };
 static_assert(sizeof(FinArgs) <= 2400, "kernel argument block too large");
