@@ -638,6 +638,18 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
 // (computeCompleteDataLogLikelihood, dense_tracking_impl.cpp:406-425, incl. Q6).  Same segment geometry as the residual
 // pass that wrote the residuals; {cut_seg, cut_local} locate global rank 50*floor(V/50).
 // ------------------------------------------------------------------------------------------------------------------
+// 1 + 0.2 q in double, one fused operation: the reference's expression (dense_tracking_impl.cpp:415) is contracted by its own
+// build (-O3 -march=native, GNU contraction default), the oracle's portable build keeps the two roundings apart; the two differ by
+// at most half an ulp of a double per term, far below the float the likelihood is returned as.  One fp64 operation less per pixel
+// in a pass that is issue-bound on them.
+__device__ __forceinline__ double ll_term(float q) { return __builtin_fma(0.2, (double)q, 1.0); }
+// v_max_f32 without the canonicalising self-max the compiler puts in front of fmaxf's accumulator (q is never a signalling NaN)
+__device__ __forceinline__ float max_raw(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 __device__ void loglik_pass(const TickItem &it, const LevelPairDesc &d, const int lb) {
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
@@ -664,16 +676,17 @@ __device__ void loglik_pass(const TickItem &it, const LevelPairDesc &d, const in
   // The largest Mahalanobis distance among the residuals that count: the reference multiplies 50 consecutive terms
   // 1 + 0.2 q in a double before it takes a log (dense_tracking_impl.cpp:413-419), and that product overflows -- likelihood
   // -inf, iteration rejected -- when 50 consecutive q are all above ~7e6 (noise-free synthetic depth; never sensor data).
-  // Here a log is taken per 16 terms, so nothing overflows; the host is told the largest q of the pass and, only if one
+  // Here a log is taken before the running product can leave the double range, so nothing overflows; the host is told the largest q of the pass and, only if one
   // group of 50 COULD have overflowed, asks k_ll_overflow for the exact answer (dvo_tracker.cpp: ll_overflowed).
   float qmax = 0.0f;
   if (steps > 0 && seg_before < cut_rank) {
     const DVO_GLOBAL v2f *src =
         (const DVO_GLOBAL v2f *)((it.flags & kItemLlBuf) ? d.res[1] : d.res[0]) + seg * (kStepPx * item_ll_steps(it)) + lane;
     int run_count = seg_before;
-    // up to four steps (256 pixels) per trip; one log per lane of the product of up to 16 terms (four trips), like the
-    // reference takes one log per 50 residuals (dense_tracking_impl.cpp:415-419): a term is 1 + 0.2 r^T P r >= 1, and
-    // sixteen of them stay far below the double range
+    // up to four steps (256 pixels) per trip; the terms 1 + 0.2 r^T P r >= 1 of a lane are multiplied up in a double and a log
+    // is taken of the product, like the reference takes one log per 50 residuals (dense_tracking_impl.cpp:415-419) -- here
+    // whenever the product has grown past 1e150 (checked once per trip) and at the end of the segment: the fp64 log is ninety
+    // instructions, and one per sixteen terms was two fifths of this pass's issue time
     double prod = 1.0;
     const int per_trip = steps < 4 ? steps : 4;
     const bool all_below_cut = seg_before + steps * kWave <= cut_rank;  // wave uniform: every pixel of the segment counts
@@ -691,8 +704,8 @@ __device__ void loglik_pass(const TickItem &it, const LevelPairDesc &d, const in
             const float t0 = r[k].x * P0 + r[k].y * P1;
             const float t1 = r[k].x * P2 + r[k].y * P3;
             const float q = t0 * r[k].x + t1 * r[k].y;
-            prod *= (1.0 + 0.2 * (double)q);
-            qmax = __builtin_fmaxf(qmax, q);
+            prod *= ll_term(q);
+            qmax = max_raw(qmax, q);
           }
           continue;
         }
@@ -702,13 +715,15 @@ __device__ void loglik_pass(const TickItem &it, const LevelPairDesc &d, const in
           const float t0 = r[k].x * P0 + r[k].y * P1;
           const float t1 = r[k].x * P2 + r[k].y * P3;
           const float q = t0 * r[k].x + t1 * r[k].y;
-          prod *= (1.0 + 0.2 * (double)q);
-          qmax = __builtin_fmaxf(qmax, q);
+          prod *= ll_term(q);
+          qmax = max_raw(qmax, q);
         }
         run_count += __popcll(b);
       }
-      if ((step & 12) == 12) {
-        if (prod != 1.0) total += log(prod);
+      // a log only when the running product gets large: a term is at most 1 + 0.2 * FLT_MAX < 7e37, so four more of them on top of
+      // 1e150 stay below the double range; with ordinary residuals (terms of 1 .. 20) a lane takes one log per wave segment
+      if (prod > 1e150) {
+        total += log(prod);
         prod = 1.0;
       }
     }
