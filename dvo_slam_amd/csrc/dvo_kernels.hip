@@ -653,22 +653,19 @@ __device__ __forceinline__ float max_raw(float a, float b) {
 __device__ void loglik_pass(const TickItem &it, const LevelPairDesc &d, const int lb) {
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
-  const int seg = lb * kWavesPerBlock + wave;
-  // Merged segments (kItemLlMerge): a likelihood wave covers `merge` consecutive wave segments of the residual pass that filled
-  // the buffer (a likelihood step is a tenth of a residual step's work: segments as short as the residual pass's make blocks
-  // that are all prologue and hold a block slot for it).  The prefix table is indexed by residual segments; segments past the
-  // end of that pass were not written in this iteration and are not read.
-  const bool merged = (it.flags & kItemLlMerge) != 0;
-  const int merge = merged ? (int)it.reserved : 1;
-  const int res_segs_left = merged ? (int)it.ll_first * kWavesPerBlock - seg * merge : merge;
-  int steps = item_ll_steps(it);
-  if (merged) {
-    const int sub = steps / merge;  // steps of one residual segment
-    steps = res_segs_left >= merge ? steps : (res_segs_left > 0 ? res_segs_left * sub : 0);
-  }
+  // Merged blocks: likelihood block `lb` covers up to m residual blocks of the pass that filled the buffer, never across a chunk
+  // boundary of the level's summation tree (ll_block_range); its wave w walks the `count` consecutive residual wave segments
+  // from segment 4 first + w count on.  (A likelihood step is a tenth of a residual step's work: blocks as short as the
+  // residual pass's are all prologue and hold a block slot for it.)  The geometry is a function of the level alone, so a lane's
+  // running product -- and with it every log -- is cut at the same pixels whatever else the tick carries.
+  int blk_first, blk_count;
+  ll_block_range((int)it.ll_level_blocks, item_ll_merge_log2(it), lb, &blk_first, &blk_count);
+  const int sub = item_ll_steps(it);                          // steps of one residual wave segment
+  const int seg = blk_first * kWavesPerBlock + wave * blk_count;  // first residual wave segment of this wave
+  const int steps = blk_count * sub;
   // valid pixels of this band that precede the segment (written by k_finalize of the residual pass that filled the buffer)
   const int seg_before =
-      steps > 0 ? ((const DVO_GLOBAL int *)((it.flags & kItemLlBuf) ? d.seg_prefix[1] : d.seg_prefix[0]))[seg * merge] : 0;
+      steps > 0 ? ((const DVO_GLOBAL int *)((it.flags & kItemLlBuf) ? d.seg_prefix[1] : d.seg_prefix[0]))[seg] : 0;
   const int cut_rank = it.ll_cut_rank;
   const float P0 = it.P[0], P1 = it.P[1], P2 = it.P[2], P3 = it.P[3];
   const unsigned long long below = (1ull << lane) - 1ull;
@@ -680,8 +677,7 @@ __device__ void loglik_pass(const TickItem &it, const LevelPairDesc &d, const in
   // group of 50 COULD have overflowed, asks k_ll_overflow for the exact answer (dvo_tracker.cpp: ll_overflowed).
   float qmax = 0.0f;
   if (steps > 0 && seg_before < cut_rank) {
-    const DVO_GLOBAL v2f *src =
-        (const DVO_GLOBAL v2f *)((it.flags & kItemLlBuf) ? d.res[1] : d.res[0]) + seg * (kStepPx * item_ll_steps(it)) + lane;
+    const DVO_GLOBAL v2f *src = (const DVO_GLOBAL v2f *)((it.flags & kItemLlBuf) ? d.res[1] : d.res[0]) + seg * (kStepPx * sub) + lane;
     int run_count = seg_before;
     // up to four steps (256 pixels) per trip; the terms 1 + 0.2 r^T P r >= 1 of a lane are multiplied up in a double and a log
     // is taken of the product, like the reference takes one log per 50 residuals (dense_tracking_impl.cpp:415-419) -- here
@@ -836,7 +832,7 @@ __device__ __forceinline__ void tick_body(const TickItem &it, const int bx) {
   if (bx < rb)
     residual_pass<ACC>(it, d, it.res_first + xcd_contiguous_block(bx, rb));
   else
-    loglik_pass(it, d, ((it.flags & kItemLlMerge) ? 0 : (int)it.ll_first) + (bx - rb));
+    loglik_pass(it, d, (int)it.ll_first + (bx - rb));
 }
 
 // Which item owns this block, and which of the item's blocks is it?  Two-dimensional grid: (block, item).  One-dimensional
@@ -976,13 +972,20 @@ constexpr int kFinThreads = DVO_FIN_THREADS;
 constexpr int kFinSegThreads = 64;    // wave 0: the ordered part of the records (no block barriers inside)
 constexpr int kFinAccFirst = 64;      // threads [64, ...): row-chunks x 24 groups of 4 columns (waves 1.. sum the moments)
 constexpr int kFinCols = 96;
+static_assert(kLevelChunksMax == 16, "finalize_block spells the tree over the 16 moment slices out");
 constexpr int kFinCol4 = kFinCols / 4;
 constexpr int kFinThreadsBatch = 256;  // the launch of a tick of many pairs: half the block runs 2 % more pairs/s next to other
                                        // streams' k_tick blocks (a small tick keeps 512 threads: its level-0 reduce is bandwidth)
+// The reducer follows the level's summation tree (dvo_types.h, kLevelChunks): per chunk a fold in ascending block order, then a
+// perfect binary tree over the 16 slices -- the same additions in the same order whether the 512-thread form (a single match())
+// or the 256-thread form (a tick of many pairs) runs, and whether the item is a whole level or a band of it.  The 512-thread
+// form gives every slice its own threads; in the 256-thread form a thread owns slices 2k and 2k + 1 and adds the two itself
+// (the first level of the tree).
 template <int NT>
 struct FinGeometry {
-  static constexpr int kChunks = (NT - kFinAccFirst) / kFinCol4;
-  static_assert(kFinAccFirst + kNumAcc + 1 <= NT && kChunks >= 2, "the block holds the output threads and at least two row chunks");
+  static constexpr int kChunks = NT == kFinThreadsBatch ? kLevelChunksMax / 2 : kLevelChunksMax;  // leaf slices the block's threads cover
+  static constexpr int kPerThread = kLevelChunksMax / kChunks;                                 // slices per thread
+  static_assert(kFinAccFirst + kChunks * kFinCol4 <= NT && kFinAccFirst + kNumAcc + 1 <= NT, "the block holds the summing and the output threads");
 };
 
 struct SegRec {
@@ -1096,20 +1099,26 @@ __device__ __forceinline__ void finalize_block(const FinItem &it, const bool sta
   __shared__ __attribute__((aligned(16))) FinOut sh_out;
 
   DVO_FIN_STAMP(0);
-  const gcf recs = (gcf)it.records + (size_t)it.block_first * kRecStride;  // the band's first block record
-  const int nb = it.records ? it.n_blocks : 0;
-  const int per = (nb + kFinSegThreads - 1) / kFinSegThreads;
+  const gcf recs = (gcf)it.records;  // indexed by logical block of the level
+  const int nb = it.records ? (int)it.n_blocks : 0;
+  const int band_lo = (int)it.block_first, band_hi = band_lo + nb;  // the blocks this item reduces
+  const int level_nb = (int)it.level_blocks;                        // the blocks the level's chunks partition
   if (t < kFinSegThreads) {
+    // Wave 0: the ordered part.  Lane 4 c + q owns quarter q of chunk c (what of it lies in the band), folds its records in
+    // ascending order, and the 64 lane records are folded by a binary tree -- chunk subtrees first, then the tree over chunks.
     SegRec r;
     r.c = 0, r.first_w = 0.0f, r.l0 = r.l1 = 0.0f;
     for (int i = 0; i < 3; ++i) r.s0[i] = r.s1[i] = 0.0;
-    const int b_end = (t + 1) * per < nb ? (t + 1) * per : nb;
+    int b_lo, b_end;
+    leaf_range(level_nb, 6, t, &b_lo, &b_end);
+    b_lo = b_lo > band_lo ? b_lo : band_lo, b_end = b_end < band_hi ? b_end : band_hi;
+    if (b_end < b_lo) b_end = b_lo;
     // four records' headers (64 bytes each) in flight at a time; the per-wave counts of the first four are kept in registers
     // for the prefix pass below, so a lane with at most four records (every level up to 256 blocks) reads its headers once
     // (the 256-thread batch form keeps two in flight: it is built for 96 registers, see k_finalize)
     constexpr int kHdr = NT == kFinThreadsBatch ? 2 : 4;
     unsigned cw_first[4][4] = {};
-    for (int b0 = t * per; b0 < b_end; b0 += kHdr) {
+    for (int b0 = b_lo; b0 < b_end; b0 += kHdr) {
       v4f h0[kHdr], h1[kHdr], h2[kHdr], h3[kHdr];
 #pragma unroll
       for (int k = 0; k < kHdr; ++k)
@@ -1126,7 +1135,7 @@ __device__ __forceinline__ void finalize_block(const FinItem &it, const bool sta
           q.s0[0] = h1[k].x, q.s0[1] = h1[k].y, q.s0[2] = h1[k].z;
           q.s1[0] = h1[k].w, q.s1[1] = h2[k].x, q.s1[2] = h2[k].y;
           r = seg_combine(r, q);
-          const int j = b0 - t * per + k;  // the lane's j-th record
+          const int j = b0 - b_lo + k;  // the lane's j-th record
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj)
             if (j == jj) cw_first[jj][0] = f2u(h2[k].z), cw_first[jj][1] = f2u(h2[k].w), cw_first[jj][2] = f2u(h3[k].x), cw_first[jj][3] = f2u(h3[k].y);
@@ -1136,9 +1145,9 @@ __device__ __forceinline__ void finalize_block(const FinItem &it, const bool sta
     sh_seg[t] = r;
     sh_cnt[t] = r.c;
     DVO_WAVE_LDS_SYNC();
-    // ordered combine (tree) and inclusive scan of the per-lane valid counts: wave-local steps over the lanes that hold records
-    const int used = per > 0 ? (nb + per - 1) / per : 0;
-    for (int stride = 1; stride < used; stride <<= 1) {
+    // ordered combine (binary tree over the 64 lanes; an empty record is the identity of seg_combine, bit for bit) and inclusive
+    // scan of the per-lane valid counts: wave-local steps
+    for (int stride = 1; stride < kFinSegThreads; stride <<= 1) {
       SegRec merged;
       int add = 0;
       const bool do_merge = (t % (2 * stride)) == 0;
@@ -1159,18 +1168,18 @@ __device__ __forceinline__ void finalize_block(const FinItem &it, const bool sta
       }
       // exclusive scan of the valid counts over the band's wave segments: the log-likelihood pass needs each pixel's
       // rank to honour the V % 50 cut (Q6)
-      int prefix = sh_cnt[t] - own_total;  // valid pixels before this lane's blocks
-      DVO_GLOBAL int *sp = (DVO_GLOBAL int *)it.seg_prefix_out + (size_t)it.block_first * kWavesPerBlock;
+      int prefix = sh_cnt[t] - own_total;  // valid pixels of the band before this lane's blocks
+      DVO_GLOBAL int *sp = (DVO_GLOBAL int *)it.seg_prefix_out;
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if (t * per + k < b_end) {
+        if (b_lo + k < b_end) {
 #pragma unroll
           for (int wv = 0; wv < 4; ++wv) {
-            sp[(t * per + k) * kWavesPerBlock + wv] = prefix;
+            sp[(b_lo + k) * kWavesPerBlock + wv] = prefix;
             prefix += (int)cw_first[k][wv];
           }
         }
-      for (int b0 = t * per + 4; b0 < b_end; b0 += 4) {  // levels with more than 256 blocks: the rest is read again
+      for (int b0 = b_lo + 4; b0 < b_end; b0 += 4) {  // levels with more than 256 blocks: the rest is read again
         v4f h2[4], h3[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -1195,68 +1204,74 @@ __device__ __forceinline__ void finalize_block(const FinItem &it, const bool sta
       sh_out.first_w = sh_out.last_r0 = sh_out.last_r1 = 0.0f;
     }
   } else if (t >= kFinAccFirst && (t - kFinAccFirst) / kFinCol4 < kFinChunks) {
-    // moments: 16-byte loads (4 columns), rows strided by the 32 chunks, four independent loads in flight per thread
-    const int c4 = (t - kFinAccFirst) % kFinCol4, chunk = (t - kFinAccFirst) / kFinCol4;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    if (c4 * 4 < kNumAcc) {
-      const gcf base = recs + kRecAcc + c4 * 4;
-      int b = chunk;
-      for (; NT != kFinThreadsBatch && b + 7 * kFinChunks < nb; b += 8 * kFinChunks) {  // eight independent 16-byte loads in flight per thread (four in the 96-register batch form)
-        v4f r[8];
+    // moments: 16-byte loads (4 columns).  A chunk's rows are added up in ascending order (the loads of several rows are in
+    // flight at a time, the additions stay sequential)
+    constexpr int kPer = FinGeometry<NT>::kPerThread;
+    constexpr int kInFlight = 4;
+    const int c4 = (t - kFinAccFirst) % kFinCol4, tc = (t - kFinAccFirst) / kFinCol4;
+    double s[kPer][4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) r[k] = *reinterpret_cast<gcf4>(base + (size_t)(b + k * kFinChunks) * kRecStride);
+    for (int v = 0; v < kPer; ++v) {
+      s[v][0] = s[v][1] = s[v][2] = s[v][3] = 0.0;
+      const int c = tc * kPer + v;  // the slice
+      if (c4 * 4 < kNumAcc) {
+        int lo, hi;
+        leaf_range(level_nb, 4, c, &lo, &hi);
+        lo = lo > band_lo ? lo : band_lo, hi = hi < band_hi ? hi : band_hi;
+        const gcf base = recs + kRecAcc + c4 * 4;
+        int b = lo;
+        for (; b + kInFlight <= hi; b += kInFlight) {
+          v4f r[kInFlight];
 #pragma unroll
-        for (int k = 0; k < 8; k += 4) {
-          s0 += ((double)r[k].x + (double)r[k + 1].x) + ((double)r[k + 2].x + (double)r[k + 3].x);
-          s1 += ((double)r[k].y + (double)r[k + 1].y) + ((double)r[k + 2].y + (double)r[k + 3].y);
-          s2 += ((double)r[k].z + (double)r[k + 1].z) + ((double)r[k + 2].z + (double)r[k + 3].z);
-          s3 += ((double)r[k].w + (double)r[k + 1].w) + ((double)r[k + 2].w + (double)r[k + 3].w);
+          for (int k = 0; k < kInFlight; ++k) r[k] = *reinterpret_cast<gcf4>(base + (size_t)(b + k) * kRecStride);
+#pragma unroll
+          for (int k = 0; k < kInFlight; ++k)
+            s[v][0] += (double)r[k].x, s[v][1] += (double)r[k].y, s[v][2] += (double)r[k].z, s[v][3] += (double)r[k].w;
         }
+        for (; b < hi; ++b) {
+          const v4f r0 = *reinterpret_cast<gcf4>(base + (size_t)b * kRecStride);
+          s[v][0] += (double)r0.x, s[v][1] += (double)r0.y, s[v][2] += (double)r0.z, s[v][3] += (double)r0.w;
+        }
+      } else if (c4 == (kNumAcc + 3) / 4) {
+        // the first spare column group sums the log-likelihood partials: the first slice of a chunk folds the chunk's merged
+        // blocks in ascending order, the chunk's other slices add exact zeros
+        const int m_log2 = (int)it.ll_merge_log2, ll_nb = (int)it.ll_level_blocks;
+        const int per = 4 - level_chunks_log2(ll_nb);
+        int lo = 0, hi = 0;
+        if ((c & ((1 << per) - 1)) == 0) lo = ll_blocks_before(ll_nb, m_log2, c >> per), hi = ll_blocks_before(ll_nb, m_log2, (c >> per) + 1);
+        const int ll_lo = (int)it.ll_first, ll_hi = ll_lo + (int)it.n_ll_blocks;
+        lo = lo > ll_lo ? lo : ll_lo, hi = hi < ll_hi ? hi : ll_hi;
+        const DVO_GLOBAL double *llp = (const DVO_GLOBAL double *)it.ll_partials;
+        const DVO_GLOBAL float *qp = (const DVO_GLOBAL float *)((const DVO_GLOBAL double *)it.ll_partials + it.ll_qmax_off);
+        float qm = 0.0f;
+        for (int b = lo; b < hi; ++b) s[v][0] += llp[b], qm = __builtin_fmaxf(qm, qp[b]);
+        s[v][1] = (double)qm;  // (rides in the second column of the spare group)
       }
-      for (; b + 3 * kFinChunks < nb; b += 4 * kFinChunks) {
-        const v4f r0 = *reinterpret_cast<gcf4>(base + (size_t)b * kRecStride);
-        const v4f r1 = *reinterpret_cast<gcf4>(base + (size_t)(b + kFinChunks) * kRecStride);
-        const v4f r2 = *reinterpret_cast<gcf4>(base + (size_t)(b + 2 * kFinChunks) * kRecStride);
-        const v4f r3 = *reinterpret_cast<gcf4>(base + (size_t)(b + 3 * kFinChunks) * kRecStride);
-        s0 += ((double)r0.x + (double)r1.x) + ((double)r2.x + (double)r3.x);
-        s1 += ((double)r0.y + (double)r1.y) + ((double)r2.y + (double)r3.y);
-        s2 += ((double)r0.z + (double)r1.z) + ((double)r2.z + (double)r3.z);
-        s3 += ((double)r0.w + (double)r1.w) + ((double)r2.w + (double)r3.w);
-      }
-      for (; b < nb; b += kFinChunks) {
-        const v4f r0 = *reinterpret_cast<gcf4>(base + (size_t)b * kRecStride);
-        s0 += (double)r0.x, s1 += (double)r0.y, s2 += (double)r0.z, s3 += (double)r0.w;
-      }
-    } else {
-      // the two spare column groups x 32 chunks sum the log-likelihood partials
-      const int lane64 = chunk * 2 + (c4 - (kNumAcc + 3) / 4);
-      const DVO_GLOBAL double *llp = (const DVO_GLOBAL double *)it.ll_partials + it.ll_first;
-      const DVO_GLOBAL float *qp = (const DVO_GLOBAL float *)((const DVO_GLOBAL double *)it.ll_partials + it.ll_qmax_off) + it.ll_first;
-      float qm = 0.0f;
-      for (int b = lane64; b < it.n_ll_blocks; b += kFinChunks * 2) s0 += llp[b], qm = __builtin_fmaxf(qm, qp[b]);
-      s1 = (double)qm;  // (rides in the second column of the spare group)
     }
-    sh_acc[chunk][c4 * 4 + 0] = s0, sh_acc[chunk][c4 * 4 + 1] = s1;
-    sh_acc[chunk][c4 * 4 + 2] = s2, sh_acc[chunk][c4 * 4 + 3] = s3;
+    if (kPer == 2) {  // chunks 2k and 2k + 1 meet here: the first level of the tree (the 512-thread form adds them after the barrier)
+      const bool is_ll = c4 * 4 >= kNumAcc;
+      s[0][0] += s[kPer - 1][0], s[0][2] += s[kPer - 1][2], s[0][3] += s[kPer - 1][3];
+      s[0][1] = is_ll ? (s[kPer - 1][1] > s[0][1] ? s[kPer - 1][1] : s[0][1]) : s[0][1] + s[kPer - 1][1];
+    }
+    sh_acc[tc][c4 * 4 + 0] = s[0][0], sh_acc[tc][c4 * 4 + 1] = s[0][1];
+    sh_acc[tc][c4 * 4 + 2] = s[0][2], sh_acc[tc][c4 * 4 + 3] = s[0][3];
   }
   __syncthreads();
   DVO_FIN_STAMP(1);
 
-  if (t >= kFinAccFirst && t < kFinAccFirst + kNumAcc) {
-    const int col = t - kFinAccFirst;
-    double s = 0.0;
-    for (int c = 0; c < kFinChunks; ++c) s += sh_acc[c][col];
-    sh_out.acc[col] = s;
-  }
+  // chunk sums -> totals: the perfect binary tree over the 16 slices
+  constexpr bool kPaired = FinGeometry<NT>::kPerThread == 2;  // the threads added chunks 2k and 2k + 1 already
+  auto tree = [&](const int col) __attribute__((always_inline)) {
+    double p[kLevelChunksMax / 2];
+#pragma unroll
+    for (int k = 0; k < kLevelChunksMax / 2; ++k) p[k] = kPaired ? sh_acc[k][col] : sh_acc[kPaired ? k : 2 * k][col] + sh_acc[kPaired ? k : 2 * k + 1][col];
+    return ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+  };
+  if (t >= kFinAccFirst && t < kFinAccFirst + kNumAcc) sh_out.acc[t - kFinAccFirst] = tree(t - kFinAccFirst);
   if (t == kFinAccFirst + kNumAcc) {
-    double s = 0.0;
     double qm = 0.0;
-    for (int c = 0; c < kFinChunks; ++c) {  // first lanes of the two spare groups
-      s += sh_acc[c][88] + sh_acc[c][92];
-      qm = sh_acc[c][89] > qm ? sh_acc[c][89] : qm;
-      qm = sh_acc[c][93] > qm ? sh_acc[c][93] : qm;
-    }
-    sh_out.ll_sum = s;
+    for (int c = 0; c < kFinChunks; ++c) qm = sh_acc[c][89] > qm ? sh_acc[c][89] : qm;
+    sh_out.ll_sum = tree(88);
     sh_out.ll_qmax = (float)qm;
     sh_out.has_ll = it.n_ll_blocks > 0 ? 1 : 0;
   }

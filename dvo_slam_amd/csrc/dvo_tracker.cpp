@@ -482,11 +482,15 @@ struct dvo_amd_context {
   unsigned tick_seq = 0;
   unsigned *ovf_host = nullptr, *ovf_dev = nullptr;  // pinned word for the verdict of k_ll_overflow (rare path)
   long long ovf_checks = 0, ovf_hits = 0;            // how often the exact overflow check ran / said yes (diagnostic)
-  // wave-step counts from which a tick takes 2 / 4 / 8 / 16 steps per wave.  Tuned on the throughput of several streams at once:
-  // a launch that runs alone on the GPU would like segments half as long (more blocks to fill it), kernels that share the
-  // GPU with three others gain more from fewer prologues and epilogues (+6 % pairs/s against 2048, 8192, 32768, 262144)
-  long long steps_at[4] = {2048, 4096, 12288, 49152};
-                                                         // (DVO_AMD_STEPS_AT="a,b,c,d", read when the context is created)
+  // Wave-step counts OF A LEVEL (its pixels / 64) from which its wave segments take 2 / 4 / 8 / 16 steps: the geometry of a
+  // residual pass -- and with it the order every fp32 sum of the pass is taken in -- is a function of the level alone, never
+  // of what else is resident in the tick (level_steps below).  DVO_AMD_LEVEL_STEPS_AT="a,b,c,d", read when the context is
+  // created (a tuning knob: it changes results in the last bits like any other summation order would).
+  // Default: 640x480 levels 3..0 (75 / 300 / 1 200 / 4 800 wave steps) take 2 / 4 / 8 / 8 steps per wave, a 1280x960 level 0
+  // (19 200) takes 16.  Interleaved runs of the streaming bench (gpurun_out/r4b, r4c; pairs/s | single-pair latency):
+  // 4/8/8/8 46.6 k | 0.83 ms; 8/8/8/8 45.9 k | 0.84; 2/4/8/8 46.2 k | 0.76; 2/4/4/8 45.2 k | 0.72; 1/2/4/8 44.5 k | 0.70;
+  // 8/8/8/16 46.1 k | 0.84; 1/1/1/4 (what a single pair got until round 3) 35.8 k | 0.71.
+  long long level_steps_at[4] = {70, 250, 1000, 9600};
   int fault_slot_alloc = -1;           // DVO_AMD_FAULT_SLOT_ALLOC: fail the allocation of this slot once (tests of the error path)
   bool fin_stamps = false;             // DVO_AMD_FIN_STAMPS=1: k_finalize records phase stamps (diagnostic)
   bool fin_priority = true;            // the batch reducer's waves run at raised issue priority (DVO_AMD_FIN_PRIORITY=0: off)
@@ -900,15 +904,29 @@ int ensure_slots(dvo_amd_context *ctx, int n_jobs, int n_pad) {
   return rc;
 }
 
-int pick_steps(const dvo_amd_context *ctx, long long total_px) {
-  // Steps per wave segment for a tick whose residual passes cover total_px pixels.  A step is a dependent chain (reference
-  // scalars -> projection -> gathers -> arithmetic -> staging), ~1.5 us when nothing else hides it, so a launch that does
-  // not fill the GPU's 4096 wave slots anyway runs one or two steps per wave: a 4 800-pixel level is 75 waves instead of 19
-  // and its chain a quarter as long.  Saturating launches take 8 or 16 steps per wave: the per-wave epilogue (seven wave
-  // reductions, the Gram tile) is amortised and k_finalize reads fewer per-block records.
-  const long long waves = total_px / kStepPx;
-  const long long *t = ctx->steps_at;
-  return waves >= t[3] ? 16 : waves >= t[2] ? 8 : waves >= t[1] ? 4 : waves >= t[0] ? 2 : 1;
+// Steps per wave segment of a residual pass over a level of n_px pixels.  A pair's result must depend on its inputs only
+// (the reference runs independent match() calls under tbb::parallel_reduce / parallel_invoke, keyframe_graph.cpp:587-590,
+// local_tracker.cpp:184: whatever runs beside a pair cannot change it), and the segment length decides where the fp32 sums of
+// a pass are cut.  So it is a function of the level's size alone: the same for a single match(), a pair in a batch of any
+// residency, the submit queue, every validator worker and every band count.  Until round 3 it was picked per tick from the
+// pixels of everything resident (short segments for small ticks, long ones for saturating launches), and a batched result
+// moved by up to 5.8e-5 from the same pair's single match().
+// The trade-off the table settles: a step is a dependent chain (reference scalars -> projection -> gathers -> arithmetic ->
+// staging, ~1.5 us when nothing else hides it), so short segments make a single pair's tick shorter; a block's prologue and
+// epilogue (descriptors, seven wave reductions, the Gram tile, the block record) are amortised over long ones.
+int level_steps(const dvo_amd_context *ctx, int n_px) {
+  const long long waves = n_px / kStepPx;
+  const long long *t = ctx->level_steps_at;
+  int steps = waves >= t[3] ? 16 : waves >= t[2] ? 8 : waves >= t[1] ? 4 : waves >= t[0] ? 2 : 1;
+  while (steps < kMaxSteps && (n_px + kStepPx * kWavesPerBlock * steps - 1) / (kStepPx * kWavesPerBlock * steps) > 2048) steps *= 2;
+  return steps;
+}
+// residual wave segments one likelihood wave walks (a likelihood step is a tenth of a residual step's work): a function of the
+// pass's segment length alone, like level_steps -- a lane's running product, and so its logs, are cut at the ends of ITS segment
+int level_ll_merge(const dvo_amd_context *ctx, int res_steps) {
+  int merge = 1;
+  while (merge < ctx->ll_merge && res_steps * merge * 2 <= kMaxSteps) merge *= 2;
+  return merge;
 }
 
 // a pair of events for the next timed launch; the launch itself stamps them (begin / end of that dispatch)
@@ -1038,20 +1056,12 @@ inline double now_ns() {
 int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
   const double t_begin = ctx->host_prof ? now_ns() : 0.0;
   grp.in_flight = false;
-  long long total_px = 0;
   int active_pairs = 0;
   for (size_t ji = grp.lo; ji < grp.hi; ++ji) active_pairs += jobs[ji].done ? 0 : 1;
   const bool speculate_levels = ctx->spec_levels == 1 || (ctx->spec_levels < 0 && active_pairs <= kSpecLevelsMaxPairs);
   auto wants_spec = [&](const Job &j) {
     return speculate_levels && j.have_a && !j.have_b && !j.a.cont && j.level > j.cfg->last_level;
   };
-  for (size_t ji = grp.lo; ji < grp.hi; ++ji) {
-    const Job &j = jobs[ji];
-    if (j.done) continue;
-    if (j.have_b) total_px += j.ref->lv[j.level].n;
-    if (wants_spec(j)) total_px += j.ref->lv[j.level - 1].n;
-  }
-  const int steps_now = pick_steps(ctx, total_px);
   const unsigned seq = ctx->tick_seq = next_seq(ctx->tick_seq);
   grp.seq = seq;
 
@@ -1072,28 +1082,27 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
     w.cur = j.cur->cur_desc + j.level;
     w.slot = ctx->slot_desc + slot_index;
     FinItem f;
-    f.records = nullptr, f.n_blocks = 0, f.block_first = 0, f.n_ll_blocks = 0, f.ll_first = 0;
+    std::memset(&f, 0, sizeof(f));
     f.ll_partials = j.slot->ll_partials;
     f.seg_prefix_out = j.slot->seg_prefix[0], f.out = j.slot->out, f.out_dev = nullptr, f.seq = seq;
     f.ll_qmax_off = j.slot->ll_qmax_off;
     if (j.have_b) {
-      j.b.steps = steps_now;
-      while (j.b.steps < kMaxSteps && blocks_for(j.ref->lv[j.level].n, j.b.steps) > 2048) j.b.steps *= 2;
+      j.b.steps = level_steps(ctx, j.ref->lv[j.level].n);  // the level's own geometry, whatever else this tick carries
       j.b.n_blocks = blocks_for(j.ref->lv[j.level].n, j.b.steps);
     }
     if (j.have_a) {
       if (j.a.buf) w.flags |= kItemLlBuf;
       w.ll_cut_rank = j.a.cut_rank;
-      // the likelihood blocks walk the residuals in merged wave segments: up to ll_merge residual segments per wave (not for
-      // small ticks: a single pair wants many short blocks).  Measured: 45.8k -> 48.1k pairs/s at 4; folding the likelihood
+      // the likelihood blocks walk the residuals in merged blocks: up to ll_merge residual blocks per likelihood block, a
+      // function of the pass's geometry alone (level_ll_merge).  Measured: 45.8k -> 48.1k pairs/s at 4; folding the likelihood
       // into the residual-pass waves of the next iteration instead (no likelihood blocks at all) gave nothing on top of it and
       // cost 22 registers and 5 % single-pair latency
-      int merge = 1;
-      while (active_pairs > kSpecLevelsMaxPairs && merge < ctx->ll_merge && j.a.steps * merge * 2 <= kMaxSteps) merge *= 2;
-      w.ll_blocks = (uint16_t)((j.a.n_blocks + merge - 1) / merge);
-      ll_steps = j.a.steps * merge;
-      if (merge > 1) w.flags |= kItemLlMerge, w.ll_first = (uint16_t)j.a.n_blocks, w.reserved = (uint16_t)merge;
-      f.n_ll_blocks = w.ll_blocks;
+      item_set_ll_merge(w, level_ll_merge(ctx, j.a.steps));
+      w.ll_level_blocks = (uint16_t)j.a.n_blocks;
+      w.ll_first = 0;
+      w.ll_blocks = (uint16_t)ll_blocks_total(j.a.n_blocks, item_ll_merge_log2(w));
+      ll_steps = j.a.steps;
+      f.n_ll_blocks = w.ll_blocks, f.ll_first = 0, f.ll_level_blocks = w.ll_level_blocks, f.ll_merge_log2 = (uint16_t)item_ll_merge_log2(w);
       j.sub_ll = true;
     }
     if (j.have_b) {
@@ -1103,7 +1112,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
       if (j.b.k == 0) w.flags |= kItemUnitWeights;  // dense_tracking.cpp:286-293
       make_kt(j.cur->lv[j.level], j.b.estimate_after, w.kt);
       f.records = j.slot->records;
-      f.n_blocks = w.res_blocks;
+      f.n_blocks = w.res_blocks, f.level_blocks = w.res_blocks;
       f.seg_prefix_out = j.slot->seg_prefix[j.b.buf];
       j.sub_res = true;
       j.sub_px = (double)j.sel->count[j.level];
@@ -1113,8 +1122,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
       // iteration a ends its level whatever its likelihood says: start the next level in this tick, assuming acceptance
       const int nl = j.level - 1;
       speculate_next_level(j, j.spec_b);
-      j.spec_b.steps = steps_now;
-      while (j.spec_b.steps < kMaxSteps && blocks_for(j.ref->lv[nl].n, j.spec_b.steps) > 2048) j.spec_b.steps *= 2;
+      j.spec_b.steps = level_steps(ctx, j.ref->lv[nl].n);
       j.spec_b.n_blocks = blocks_for(j.ref->lv[nl].n, j.spec_b.steps);
       w.ref = j.sel->ref_desc + nl;  // the likelihood pass only uses the slot's buffers
       w.cur = j.cur->cur_desc + nl;
@@ -1124,7 +1132,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
       w.flags |= kItemUnitWeights;
       make_kt(j.cur->lv[nl], j.spec_b.estimate_after, w.kt);
       f.records = j.slot->records;
-      f.n_blocks = w.res_blocks;
+      f.n_blocks = w.res_blocks, f.level_blocks = w.res_blocks;
       f.seg_prefix_out = j.slot->seg_prefix[j.spec_b.buf];
       j.have_spec = true;
       j.sub_res = true;
@@ -1171,7 +1179,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
       for (int i = 0; i < n_here; ++i) {
         rb += ta.items[i].res_blocks, lb += ta.items[i].ll_blocks;
         res_steps += (double)ta.items[i].res_blocks * kWavesPerBlock * item_res_steps(ta.items[i]);
-        ll_steps += (double)ta.items[i].ll_blocks * kWavesPerBlock * item_ll_steps(ta.items[i]);
+        if (ta.items[i].ll_blocks) ll_steps += (double)ta.items[i].ll_level_blocks * kWavesPerBlock * item_ll_steps(ta.items[i]);
       }
       for (size_t ji = grp.lo, k = 0; ji < grp.hi; ++ji) {
         const Job &j = jobs[ji];
@@ -1475,55 +1483,91 @@ int check_config(const dvo_amd_config *c) {
 
 
 // ---- one pair tile-sharded into bands of scan-order blocks (BASELINE config 4) ---------------------------------------
-// Band i of n covers blocks [nb*i/n, nb*(i+1)/n) of the level.  Per-pixel work is independent given the pose; what
-// couples the bands is exactly what couples blocks inside one GPU: the ordered fold of (count, pair-quirk scale sums under
-// both start parities, boundary weight / residual) and the plain sums of the 87 moments and of the likelihood.  So the
-// exchange per tick is one record (FinOut, 784 B) per band, combined left to right in band order on every rank.
-void band_range(int nb, int n_bands, int b, int *first, int *count) {
-  const int lo = (int)((long long)nb * b / n_bands), hi = (int)((long long)nb * (b + 1) / n_bands);
-  *first = lo, *count = hi - lo;
+// Band b of n covers whole chunks of the level's summation tree (band_blocks, dvo_types.h).  Per-pixel work is independent
+// given the pose; what couples the bands is exactly what couples blocks inside one GPU: the ordered fold of (count, pair-quirk
+// scale sums under both start parities, boundary weight / residual) and the plain sums of the 87 moments and of the
+// likelihood.  So the exchange per tick is one record (FinOut, 784 B) per band, combined on every rank along the same tree.
+
+// the ordered part of a record (count, pair-quirk scale sums under both start parities, boundary weight / residual) and the
+// rule that joins two neighbouring runs of pixels: the host's copy of seg_combine in dvo_kernels.hip, operation for operation
+struct HostSeg {
+  int c;
+  float first_w, l0, l1;
+  double s0[3], s1[3];
+};
+HostSeg host_seg_combine(const HostSeg &a, const HostSeg &b) {
+  if (b.c == 0) return a;
+  if (a.c == 0) return b;
+  HostSeg o;
+  const bool flip = (a.c & 1) != 0;  // b starts on the opposite parity of everything before it
+  const double rxx = (double)a.l0 * a.l0, rxy = (double)a.l0 * a.l1, ryy = (double)a.l1 * a.l1;
+  for (int i = 0; i < 3; ++i) {
+    o.s0[i] = a.s0[i] + (flip ? b.s1[i] : b.s0[i]);
+    o.s1[i] = a.s1[i] + (flip ? b.s0[i] : b.s1[i]);
+  }
+  // b's first pixel is a pair-second under exactly one hypothesis: there it weights a's last residual
+  double *tgt = flip ? o.s0 : o.s1;
+  tgt[0] += (double)b.first_w * rxx, tgt[1] += (double)b.first_w * rxy, tgt[2] += (double)b.first_w * ryy;
+  o.c = a.c + b.c;
+  o.first_w = a.first_w;
+  o.l0 = b.l0, o.l1 = b.l1;
+  return o;
 }
 
+// Band records -> the record of the level.  When the band count divides 16 every band is a subtree of the level's summation
+// tree (dvo_types.h, level_chunks_log2) and its reducer has produced that subtree's value: folding the bands with the rest of the
+// SAME tree -- a perfect binary tree over the bands -- gives, bit for bit, the record one reducer would have produced from the
+// whole level.  Other band counts (3, 5, ...) are folded left to right: deterministic, and equal to the unsharded record up to
+// the rounding of the fp64 sums.
 void combine_bands(const FinOut *const *recs, int n, FinOut &out) {
   std::memset(&out, 0, sizeof(out));
-  int c = 0;
-  double s0[3] = {0, 0, 0}, s1[3] = {0, 0, 0};
-  float fw = 0.0f, l0 = 0.0f, l1 = 0.0f;
+  HostSeg seg_small[kMaxBands];
+  double acc_small[kMaxBands][kNumAcc], ll_small[kMaxBands];
+  std::vector<HostSeg> seg_big;
+  std::vector<double> acc_big, ll_big;
+  HostSeg *seg = seg_small;
+  double(*acc)[kNumAcc] = acc_small, *ll = ll_small;
+  if (n > kMaxBands) {  // (only the debug entry folds more bands than a node has GPUs)
+    seg_big.resize((size_t)n), acc_big.resize((size_t)n * kNumAcc), ll_big.resize((size_t)n);
+    seg = seg_big.data(), acc = reinterpret_cast<double(*)[kNumAcc]>(acc_big.data()), ll = ll_big.data();
+  }
   for (int b = 0; b < n; ++b) {
     const FinOut &r = *recs[b];
     out.has_res |= r.has_res, out.has_ll |= r.has_ll;
-    for (int i = 0; i < kNumAcc; ++i) out.acc[i] += r.acc[i];
-    out.ll_sum += r.ll_sum;
     out.ll_qmax = r.ll_qmax > out.ll_qmax ? r.ll_qmax : out.ll_qmax;
-    if (!r.has_res || r.valid == 0) continue;
-    if (c == 0) {
-      for (int i = 0; i < 3; ++i) s0[i] = r.S[i], s1[i] = r.S_odd[i];
-      fw = r.first_w;
-    } else {
-      const bool flip = (c & 1) != 0;  // the band starts on the opposite parity of everything before it
-      const double R[3] = {(double)l0 * l0, (double)l0 * l1, (double)l1 * l1};
-      for (int i = 0; i < 3; ++i) {
-        double n0 = s0[i] + (flip ? r.S_odd[i] : r.S[i]);
-        double n1 = s1[i] + (flip ? r.S[i] : r.S_odd[i]);
-        // the band's first pixel is a pair-second under exactly one hypothesis: there it weights the previous last residual
-        (flip ? n0 : n1) += (double)r.first_w * R[i];
-        s0[i] = n0, s1[i] = n1;
-      }
-    }
-    l0 = r.last_r0, l1 = r.last_r1;
-    c += r.valid;
+    HostSeg &g = seg[b];
+    g.c = r.has_res ? r.valid : 0;
+    g.first_w = r.first_w, g.l0 = r.last_r0, g.l1 = r.last_r1;
+    for (int i = 0; i < 3; ++i) g.s0[i] = r.S[i], g.s1[i] = r.S_odd[i];
+    for (int i = 0; i < kNumAcc; ++i) acc[b][i] = r.acc[i];
+    ll[b] = r.ll_sum;
   }
-  out.valid = c;
-  for (int i = 0; i < 3; ++i) out.S[i] = s0[i], out.S_odd[i] = s1[i];
-  out.first_w = fw, out.last_r0 = l0, out.last_r1 = l1;
+  if (kLevelChunksMax % n == 0) {
+    for (int m = n; m > 1; m >>= 1)  // one level of the tree per round
+      for (int b = 0; b < m / 2; ++b) {
+        seg[b] = host_seg_combine(seg[2 * b], seg[2 * b + 1]);
+        for (int i = 0; i < kNumAcc; ++i) acc[b][i] = acc[2 * b][i] + acc[2 * b + 1][i];
+        ll[b] = ll[2 * b] + ll[2 * b + 1];
+      }
+  } else {
+    for (int b = 1; b < n; ++b) {
+      seg[0] = host_seg_combine(seg[0], seg[b]);
+      for (int i = 0; i < kNumAcc; ++i) acc[0][i] += acc[b][i];
+      ll[0] += ll[b];
+    }
+  }
+  out.valid = seg[0].c;
+  for (int i = 0; i < 3; ++i) out.S[i] = seg[0].s0[i], out.S_odd[i] = seg[0].s1[i];
+  out.first_w = seg[0].first_w, out.last_r0 = seg[0].l0, out.last_r1 = seg[0].l1;
+  for (int i = 0; i < kNumAcc; ++i) out.acc[i] = acc[0][i];
+  out.ll_sum = ll[0];
 }
 
 int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, int n_local, bool exchange) {
   const unsigned seq = ctx->tick_seq = next_seq(ctx->tick_seq);
   if (!j.have_a && !j.have_b) return DVO_AMD_OK;
-  // segment length as the unsharded driver picks it for one pair of this level: the same for every band count and rank
-  int steps_level = pick_steps(ctx, j.ref->lv[j.level].n);
-  while (steps_level < kMaxSteps && blocks_for(j.ref->lv[j.level].n, steps_level) > 2048) steps_level *= 2;
+  // the level's own segment length (level_steps): the same for every band count and rank, and the unsharded driver's
+  const int steps_level = level_steps(ctx, j.ref->lv[j.level].n);
   const int nb_level = blocks_for(j.ref->lv[j.level].n, steps_level);
   TickArgs ta;
   FinArgs fa;
@@ -1551,24 +1595,29 @@ int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, i
     f.out_dev = exchange ? ctx->slots[(size_t)li].out_dev : nullptr;  // device copy: source of the all-gather / peer exchange
     f.seq = seq;
     if (j.have_a) {
-      int first = 0, count = 0;
-      band_range(j.a.n_blocks, n_bands, band, &first, &count);
-      w.ll_first = (uint16_t)first, w.ll_blocks = (uint16_t)count;
+      // the merged likelihood blocks of the band's chunks (a band is a run of whole chunks: none straddles its edge) -- the
+      // very blocks the unsharded pass runs
+      item_set_ll_merge(w, level_ll_merge(ctx, j.a.steps));
+      const int C = 1 << level_chunks_log2(j.a.n_blocks);
+      const int first = ll_blocks_before(j.a.n_blocks, item_ll_merge_log2(w), C * band / n_bands);
+      const int count = ll_blocks_before(j.a.n_blocks, item_ll_merge_log2(w), C * (band + 1) / n_bands) - first;
+      w.ll_first = (uint16_t)first, w.ll_blocks = (uint16_t)count, w.ll_level_blocks = (uint16_t)j.a.n_blocks;
       if (j.a.buf) w.flags |= kItemLlBuf;
       int before = 0;
       for (int b = 0; b < band; ++b) before += j.a.band_valid[b];
       w.ll_cut_rank = j.a.cut_rank - before;  // rank inside the band below which residuals enter the likelihood
-      f.n_ll_blocks = w.ll_blocks, f.ll_first = w.ll_first;
+      f.n_ll_blocks = w.ll_blocks, f.ll_first = w.ll_first, f.ll_level_blocks = w.ll_level_blocks;
+      f.ll_merge_log2 = (uint16_t)item_ll_merge_log2(w);
     }
     if (j.have_b) {
       int first = 0, count = 0;
-      band_range(nb_level, n_bands, band, &first, &count);
+      band_blocks(nb_level, n_bands, band, &first, &count);
       w.res_first = (uint16_t)first, w.res_blocks = (uint16_t)count;
       if (j.b.buf) w.flags |= kItemResBuf;
       if (j.b.k == 0) w.flags |= kItemUnitWeights;
       make_kt(j.cur->lv[j.level], j.b.estimate_after, w.kt);
       f.records = ctx->slots[0].records;
-      f.n_blocks = w.res_blocks, f.block_first = w.res_first;
+      f.n_blocks = w.res_blocks, f.block_first = w.res_first, f.level_blocks = (uint16_t)nb_level;
       f.seg_prefix_out = ctx->slots[0].seg_prefix[j.b.buf];
     }
     std::memcpy(w.P, j.have_a ? j.a.P : j.precision, sizeof(w.P));
@@ -1638,9 +1687,9 @@ int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, i
       //  sharded over several GPUs holds only its own band here: the overflow artefact is not emulated on that path.)
       OvfBand ob[kMaxBands];
       int before = 0;
-      for (int b = 0; b < n_bands; ++b) {  // the prefix table is relative to each band (band_range of the pass's blocks)
+      for (int b = 0; b < n_bands; ++b) {  // the prefix table is relative to each band (band_blocks of the pass's blocks)
         int first = 0, count = 0;
-        band_range(j.a.n_blocks, n_bands, b, &first, &count);
+        band_blocks(j.a.n_blocks, n_bands, b, &first, &count);
         ob[b].seg_first = first * kWavesPerBlock, ob[b].n_segs = count * kWavesPerBlock, ob[b].rank_offset = before;
         before += j.a.band_valid[b];
       }
@@ -1780,8 +1829,9 @@ int dvo_amd_context_create(int device, const dvo_amd_config *cfg, dvo_amd_contex
   ctx->host_prof = hp && hp[0] == '1';
   if (const char *sl = getenv("DVO_AMD_SPEC_LEVELS")) ctx->spec_levels = sl[0] == '1' ? 1 : 0;
   if (const char *fs2 = getenv("DVO_AMD_FAULT_SLOT_ALLOC")) ctx->fault_slot_alloc = atoi(fs2);
-  if (const char *sa = getenv("DVO_AMD_STEPS_AT"))
-    (void)sscanf(sa, "%lld,%lld,%lld,%lld", &ctx->steps_at[0], &ctx->steps_at[1], &ctx->steps_at[2], &ctx->steps_at[3]);
+  if (const char *sa = getenv("DVO_AMD_LEVEL_STEPS_AT"))
+    (void)sscanf(sa, "%lld,%lld,%lld,%lld", &ctx->level_steps_at[0], &ctx->level_steps_at[1], &ctx->level_steps_at[2],
+                 &ctx->level_steps_at[3]);
   if (const char *lm = getenv("DVO_AMD_LL_MERGE")) {
     const int v = atoi(lm);
     if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ctx->ll_merge = v;
@@ -2311,8 +2361,7 @@ int single_tick(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyrami
   w.ref = sel->ref_desc + level;
   w.cur = current->cur_desc + level;
   w.slot = ctx->slot_desc;
-  int steps = pick_steps(ctx, R.n);
-  while (steps < kMaxSteps && blocks_for(R.n, steps) > 2048) steps *= 2;
+  const int steps = level_steps(ctx, R.n);
   item_set_steps(w, steps, steps);
   const int nb = blocks_for(R.n, steps);
   if (unit_weights) w.flags |= kItemUnitWeights;
@@ -2334,12 +2383,14 @@ int single_tick(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyrami
       for (int c = 0; c < 4; ++c)
         w.kt[i * 4 + c] = (K[i * 3 + 0] * T[c * 4 + 0] + K[i * 3 + 1] * T[c * 4 + 1]) + K[i * 3 + 2] * T[c * 4 + 2];
     f.records = s.records;
-    f.n_blocks = nb;
+    f.n_blocks = (uint16_t)nb, f.level_blocks = (uint16_t)nb;
   }
-  if (loglik_pass) {
-    w.ll_blocks = (uint16_t)nb;
+  if (loglik_pass) {  // the merged blocks match() runs for this level (level_ll_merge)
+    item_set_ll_merge(w, level_ll_merge(ctx, steps));
+    w.ll_level_blocks = (uint16_t)nb;
+    w.ll_blocks = (uint16_t)ll_blocks_total(nb, item_ll_merge_log2(w));
     w.ll_cut_rank = ll_cut_rank;
-    f.n_ll_blocks = nb;
+    f.n_ll_blocks = w.ll_blocks, f.ll_level_blocks = (uint16_t)nb, f.ll_merge_log2 = (uint16_t)item_ll_merge_log2(w);
   }
   hipError_t e = launch_tick(ta, (int)w.res_blocks + (int)w.ll_blocks, ctx->stream);
   if (e != hipSuccess) return fail_hip("launch_tick", e);
@@ -2423,8 +2474,7 @@ int dvo_amd_debug_iteration(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dv
   out->loglik_sum = ctx->out_host[0].ll_sum;
   bool overflowed = false;
   if (ctx->out_host[0].ll_qmax >= kLlOverflowScreen) {
-    int st = pick_steps(ctx, R.n);  // (the geometry single_tick used)
-    while (st < kMaxSteps && blocks_for(R.n, st) > 2048) st *= 2;
+    const int st = level_steps(ctx, R.n);  // (the geometry single_tick used)
     rc = ll_overflowed(ctx, ctx->slots[0].res[0], ctx->slots[0].seg_prefix[0], blocks_for(R.n, st), st, 50 * (o.valid / 50), P, nullptr, 0,
                        &overflowed);
     if (rc) return rc;
@@ -2472,7 +2522,7 @@ int dvo_amd_bench_residual_pass_pairs(dvo_amd_context *ctx, int n_items, dvo_amd
   if (rc) return rc;
   // `rounds` of the public interface = 256-pixel rounds per wave segment (four steps each); 0 = the driver's choice
   if (rounds != 0 && rounds != 1 && rounds != 2 && rounds != 4 && rounds != 8 && rounds != 16) return DVO_AMD_ERR_INVALID_ARGUMENT;
-  int steps = rounds <= 0 ? pick_steps(ctx, (long long)R.n * n_items) : rounds * 4;
+  int steps = rounds <= 0 ? level_steps(ctx, R.n) : rounds * 4;
   while (steps < kMaxSteps && blocks_for(R.n, steps) > 2048) steps *= 2;
   TickItem proto;
   std::memset(&proto, 0, sizeof(proto));

@@ -31,6 +31,65 @@ constexpr int kRecStride = 104;
 //   [63..68] sum w Ja_i r0   [69..74] sum w Ja_i r1   [75..80] sum w Jb_i r0   [81..86] sum w Jb_i r1
 constexpr int kAccAA = 0, kAccAB = 21, kAccBB = 42, kAccAR0 = 63, kAccAR1 = 69, kAccBR0 = 75, kAccBR1 = 81;
 
+// ---- the summation tree of a level ----------------------------------------------------------------------------------------
+// A pair's result is a function of its inputs alone: not of what else is resident in the tick, not of which form of the
+// reduce kernel ran, and not of how many bands (GPUs) a level was cut into.  Everything that is summed across blocks is
+// therefore summed along ONE tree that depends on the level's geometry only:
+//   - the nb block records of a level's residual pass are cut into C = level_chunks(nb) contiguous chunks (a power of two up to
+//     16; fewer for levels of few blocks), chunk c = blocks [nb c / C, nb (c + 1) / C);
+//   - a chunk is cut into 64 / C (ordered part) or 16 / C (moments) leaf ranges the same way; inside a leaf range records are
+//     folded in ascending order (fp64);
+//   - the leaves are folded by a perfect binary tree ((l0 + l1) + (l2 + l3)) + ...
+// A band of a tile-sharded level is a run of whole chunks -- band b of n owns chunks [C b / n, C (b + 1) / n) --, its reducer
+// produces the value of its subtree (the leaves it does not own contribute exact zeros / empty records), and the host folds
+// the band records with the rest of the same tree: 1, 2, 4, 8 and 16 bands, on one GPU or on as many, give bit-identical sums.
+// The likelihood pass walks merged blocks of about m residual blocks that never straddle a chunk.
+constexpr int kLevelChunksMax = 16;
+__host__ __device__ inline int level_chunks_log2(int nb) { return nb >= 128 ? 4 : nb >= 64 ? 3 : nb >= 32 ? 2 : nb >= 16 ? 1 : 0; }
+__host__ __device__ inline int chunk_lo(int nb, int c) { return (nb * c) >> level_chunks_log2(nb); }  // nb <= 2048: no overflow
+// leaf range i of 1 << g_log2 (g_log2 = 6: the lanes of the ordered fold, 4: the slices of the moment sums)
+__host__ __device__ inline void leaf_range(int nb, int g_log2, int i, int *lo, int *hi) {
+  const int per = g_log2 - level_chunks_log2(nb);  // leaves per chunk, log2
+  const int c = i >> per, q = i & ((1 << per) - 1);
+  const int c_lo = chunk_lo(nb, c), len = chunk_lo(nb, c + 1) - c_lo;
+  *lo = c_lo + ((len * q) >> per), *hi = c_lo + ((len * (q + 1)) >> per);
+}
+// the blocks of band b of n: whole chunks
+__host__ __device__ inline void band_blocks(int nb, int n_bands, int b, int *first, int *count) {
+  const int C = 1 << level_chunks_log2(nb);
+  const int lo = chunk_lo(nb, C * b / n_bands), hi = chunk_lo(nb, C * (b + 1) / n_bands);
+  *first = lo, *count = hi - lo;
+}
+// merged likelihood blocks of a chunk of `len` residual blocks: about 1 << m_log2 residual blocks each, dealt evenly
+__host__ __device__ inline int ll_chunk_blocks(int len, int m_log2) {
+  const int k = (len + ((1 << m_log2) >> 1)) >> m_log2;
+  return len <= 0 ? 0 : (k < 1 ? 1 : k);
+}
+// merged likelihood blocks in chunks [0, c)
+__host__ __device__ inline int ll_blocks_before(int nb, int m_log2, int c) {
+  int n = 0;
+  for (int i = 0; i < c; ++i) n += ll_chunk_blocks(chunk_lo(nb, i + 1) - chunk_lo(nb, i), m_log2);
+  return n;
+}
+__host__ __device__ inline int ll_blocks_total(int nb, int m_log2) { return ll_blocks_before(nb, m_log2, 1 << level_chunks_log2(nb)); }
+// merged likelihood block `lb` of a pass with nb residual blocks -> its residual blocks [first, first + count)
+__host__ __device__ inline void ll_block_range(int nb, int m_log2, int lb, int *first, int *count) {
+  int before = 0;
+  *first = 0, *count = 0;
+  const int C = 1 << level_chunks_log2(nb);
+  for (int c = 0; c < C; ++c) {
+    const int lo = chunk_lo(nb, c), len = chunk_lo(nb, c + 1) - lo;
+    const int here = ll_chunk_blocks(len, m_log2);
+    if (lb < before + here) {
+      const int j = lb - before;
+      *first = lo + len * j / here;
+      *count = lo + len * (j + 1) / here - *first;
+      return;
+    }
+    before += here;
+  }
+}
+
 // Static descriptors, resident in device memory next to what they describe and read by every block through scalar loads.
 // They are written once (pyramid build / point selection / scratch allocation); nothing is uploaded per match or per tick.
 struct RefLevelDesc {  // one per (pyramid, selection thresholds, level): the reference side of a pair
@@ -62,11 +121,12 @@ struct TickItem {
   const CurLevelDesc *cur;
   const SlotDesc *slot;
   uint16_t res_blocks, ll_blocks;  // blocks this item runs (a band of the level when the pair is sharded), <= 2048 each
-  uint16_t res_first, ll_first;    // first logical block of the band (0 for the whole level); with kItemLlMerge ll_first is
-                                   // instead the number of blocks of the residual pass that filled the buffer
-  uint8_t steps_log2;              // 64-pixel steps per wave, log2: low nibble residual pass, high nibble log-likelihood pass
-  uint8_t flags;                   // kItem* bits
-  uint16_t reserved;               // kItemLlMerge: residual wave segments per likelihood wave segment (a power of two)
+  uint16_t res_first, ll_first;    // first logical block of the band (0 for the whole level): a residual block / a merged
+                                   // likelihood block (ll_block_range)
+  uint8_t steps_log2;              // 64-pixel steps per wave segment, log2: low nibble = this item's residual pass, high nibble
+                                   // = the residual pass that filled the buffer the likelihood pass reads
+  uint8_t flags;                   // kItem* bits; bits 4..6: log2 of the residual blocks per merged likelihood block
+  uint16_t ll_level_blocks;        // residual blocks of the WHOLE level in the pass that filled the likelihood pass's buffer
   int ll_cut_rank;                 // log-likelihood pass: keep valid pixels whose rank within the band is below this (Q6)
   float kt[12];                    // K * T[0:3,0:4], row-major, float (dense_tracking_impl.cpp:142-152)
   float P[4];                      // column-major 2x2 precision: of the iteration whose likelihood is evaluated, which is
@@ -74,16 +134,21 @@ struct TickItem {
 };
 __host__ __device__ inline int item_res_steps(const TickItem &it) { return 1 << (it.steps_log2 & 15); }
 __host__ __device__ inline int item_ll_steps(const TickItem &it) { return 1 << (it.steps_log2 >> 4); }
+__host__ __device__ inline int item_ll_merge_log2(const TickItem &it) { return (it.flags >> 4) & 7; }
 inline void item_set_steps(TickItem &it, int res_steps, int ll_steps) {
   int a = 0, b = 0;
   while ((1 << a) < res_steps) ++a;
   while ((1 << b) < ll_steps) ++b;
   it.steps_log2 = (uint8_t)(a | (b << 4));
 }
+inline void item_set_ll_merge(TickItem &it, int merge) {
+  int m = 0;
+  while ((1 << m) < merge) ++m;
+  it.flags = (uint8_t)((it.flags & 0x8F) | (m << 4));
+}
 constexpr unsigned kItemResBuf = 1;       // which residual buffer the residual pass writes
 constexpr unsigned kItemLlBuf = 2;        // which residual buffer the log-likelihood pass reads
 constexpr unsigned kItemUnitWeights = 4;  // first iteration on a level: weights = 1 (dense_tracking.cpp:286-289)
-constexpr unsigned kItemLlMerge = 8;      // the likelihood pass runs merged wave segments (see loglik_pass)
 static_assert(sizeof(TickItem) == 104, "TickItem is packed to fit many items into one kernel-argument block");
 
 constexpr int kMaxItemsPerLaunch = 36;
@@ -147,8 +212,12 @@ struct ExchangeArgs {                 // constant per context once the peers are
 
 struct FinItem {
   const float *records;   // residual-pass block records (or null), indexed by logical block of the level
-  int n_blocks, block_first;      // the band this item reduces
-  int n_ll_blocks, ll_first;
+  uint16_t n_blocks, block_first;      // the band this item reduces (the whole level: 0, level_blocks)
+  uint16_t n_ll_blocks, ll_first;      // ... and its merged likelihood blocks
+  uint16_t level_blocks;               // residual blocks of the whole level in this tick's residual pass (the chunk structure)
+  uint16_t ll_level_blocks;            // ... in the pass whose likelihood is summed
+  uint16_t ll_merge_log2;              // log2 of the residual blocks per merged likelihood block
+  uint16_t pad;
   const double *ll_partials;
   int *seg_prefix_out;    // per wave segment of the band: valid pixels before it (exclusive scan from the band start)
   FinWire *out;           // host (pinned, device-visible): where the record is published, as tagged pieces
@@ -156,6 +225,7 @@ struct FinItem {
   unsigned seq;
   unsigned ll_qmax_off;   // the per-block maxima of the likelihood pass live ll_qmax_off doubles behind ll_partials
 };
+static_assert(sizeof(FinItem) == 64, "FinItem is packed: one per resident pair in the reducer's argument block");
 constexpr unsigned kFinFlagPriority = 1;  // the reducer's waves raise their issue priority (s_setprio)
 constexpr int kMaxFinItems = kMaxItemsPerLaunch;  // 64 B each: one reduce launch per tick launch
 struct FinArgs {

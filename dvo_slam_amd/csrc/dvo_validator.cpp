@@ -249,15 +249,13 @@ void worker_release(int device, dvo_amd_context *c, bool healthy) {
   }
   dvo_amd_context_destroy(c);
 }
+// read at every call (a getenv is nothing next to a validation): a test or a host application may change it between calls.
+// The number of workers changes which context aligns a proposal and what shares its ticks -- never its result
+// (tests/test_validator.py::test_validator_output_does_not_depend_on_the_worker_count)
 int validator_threads() {
-  static std::once_flag once;
-  static int n = 3;
-  std::call_once(once, [] {
-    const char *e = getenv("DVO_AMD_VALIDATOR_THREADS");
-    n = e ? atoi(e) : 3;
-    n = n < 1 ? 1 : (n > 8 ? 8 : n);
-  });
-  return n;
+  const char *e = getenv("DVO_AMD_VALIDATOR_THREADS");
+  int n = e ? atoi(e) : 3;
+  return n < 1 ? 1 : (n > 8 ? 8 : n);
 }
 }  // namespace
 }  // extern "C++"
