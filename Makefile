@@ -2,13 +2,14 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 SRC   := dvo_slam_amd/csrc
 LIB   := dvo_slam_amd/libdvo_amd.so
-FLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wall -Wno-unused-function
+FLAGS := $(shell python3 dvo_slam_amd/_build.py --print-flags)
+BUILD_ID := $(shell python3 dvo_slam_amd/_build.py --print-id)
 
 all: $(LIB)
 
 $(LIB): $(SRC)/dvo_kernels.hip $(SRC)/dvo_tracker.cpp $(SRC)/dvo_validator.cpp $(SRC)/dvo_frontend.cpp $(SRC)/dvo_tum.cpp \
         $(SRC)/dvo_types.h $(SRC)/se3.h include/dvo_amd.h
-	$(HIPCC) $(FLAGS) -x hip $(SRC)/dvo_kernels.hip $(SRC)/dvo_tracker.cpp $(SRC)/dvo_validator.cpp $(SRC)/dvo_frontend.cpp \
+	$(HIPCC) $(FLAGS) '-DDVO_AMD_BUILD_ID="$(BUILD_ID)"' -x hip $(SRC)/dvo_kernels.hip $(SRC)/dvo_tracker.cpp $(SRC)/dvo_validator.cpp $(SRC)/dvo_frontend.cpp \
 	    $(SRC)/dvo_tum.cpp -lz -o $@
 
 oracle:

@@ -236,7 +236,7 @@ def main():
     result_bufs = [[trackers[t].alloc_results(len(shares[t])) for _ in range(2)] if with_stats else None for t in range(T)]
     streaming = not args.drain_between_steps
 
-    def run_steps(n_steps, collect, r_list=None, c_list=None, stats=with_stats):
+    def run_steps(n_steps, collect, r_list=None, c_list=None, stats=with_stats, keep=None):
         """n_steps batches of B pairs on this GPU; with T > 1 every thread drives its own tracker"""
         r_list, c_list = r_list or refs, c_list or curb
 
@@ -249,6 +249,8 @@ def main():
                                 sum(o.is_nan for o in out), sum(o.n_iterations for o in out),
                                 sum(o.alg_bytes_discarded for o in out)))
             prev = None
+            if keep is not None:
+                keep[t] = None
             for s_ in range(n_steps):
                 ts = time.perf_counter()
                 bufs = result_bufs[t][s_ % 2] if stats else None
@@ -259,11 +261,17 @@ def main():
                         tally(trackers[t].wait(prev, raw=True))
                     prev = sub
                 else:
-                    tally(trackers[t].match_batch(r, c, stats=False, in_flight=args.in_flight, raw=True, results=bufs))
+                    out_ = trackers[t].match_batch(r, c, stats=False, in_flight=args.in_flight, raw=True, results=bufs)
+                    tally(out_)
+                    if keep is not None:
+                        keep[t] = (ix, out_)
                 if os.environ.get("DVO_BENCH_DEBUG"):
                     print(f"thread {t} step {s_}: {(time.perf_counter() - ts) * 1e3:.2f} ms", file=sys.stderr, flush=True)
             if prev is not None:
-                tally(trackers[t].wait(prev, raw=True))
+                last = trackers[t].wait(prev, raw=True)
+                tally(last)
+                if keep is not None:
+                    keep[t] = (ix, last)  # the raw result structs of this thread's share of the LAST step
         if T == 1:
             worker(0)
         else:
@@ -301,9 +309,11 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     col = []
-    run_steps(args.steps, col)
+    kept = [None] * T
+    run_steps(args.steps, col, keep=kept)
     sync_all()
     elapsed = time.perf_counter() - t0
+    region_check = check_timed_region(capi, synth, cfg, device, kept, refs, curb)
     alg_bytes = sum(c[0] for c in col)
     discarded_bytes = sum(c[4] for c in col)
     passes = sum(c[1] for c in col)
@@ -402,7 +412,10 @@ def main():
                 "iteration_statistics": "delivered" if with_stats else "dropped",
                 "sharding": "independent pairs per rank, no collective on the data path",
             },
+            "build_id": capi.build_id(),
             "iterations_per_pair": iterations_delivered / max(1, B * args.steps),
+            "timed_region_check": region_check,
+            "max_deviation_from_single_match": region_check["max_deviation_from_single_match"],
             "single_pair_latency_ms": single_ms,
             "prep_ms_per_frame": prep_ms,
             "prep_ms_per_frame_first_use": prep_first_ms,
@@ -488,6 +501,39 @@ def main():
         os._exit(0)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def check_timed_region(capi, synth, cfg, device, kept, refs, curb, n_samples=48):
+    """Results of the LAST step of the timed region (as its host threads collected them) against a single match() of the same
+    pair on a fresh tracker: a pair's result is a function of its inputs alone (tests/test_determinism.py), so every sampled
+    pair must come back bit for bit -- whatever it shared its ticks with in the timed region.  A deviation fails the bench."""
+    import numpy as np
+
+    single = capi.DenseTracker(cfg, device=device)
+    per_thread = max(1, -(-n_samples // max(1, len(kept))))
+    n = identical = 0
+    worst = 0.0
+    for entry in kept:
+        if entry is None:
+            continue
+        ix, raw = entry
+        for k in np.linspace(0, len(ix) - 1, num=min(per_thread, len(ix)), dtype=int):
+            i = ix[int(k)]
+            want = single.match(refs[i], curb[i])
+            got_T = np.array(raw[int(k)].transformation[:]).reshape(4, 4).T
+            got_I = np.array(raw[int(k)].information[:]).reshape(6, 6).T
+            same = np.array_equal(got_T, want.Transformation) and np.array_equal(got_I, want.Information) \
+                and raw[int(k)].n_iterations == sum(len(L["Iterations"]) for L in want.Levels)
+            n += 1
+            identical += 1 if same else 0
+            if not np.array_equal(got_T, want.Transformation):  # (identical matrices are at distance 0, not at the rounding of log())
+                worst = max(worst, synth.pose_error(want.Transformation, got_T))
+    out = {"sampled_pairs": n, "bit_identical_to_single_match": identical, "max_deviation_from_single_match": worst,
+           "what": "pairs of the last step of the timed region, re-aligned one at a time by dvo_amd_match() on a fresh tracker: "
+                   "transformation, information and iteration count compared bit for bit; deviation = |log(T_single^-1 T_batch)|"}
+    if n == 0 or identical != n:
+        raise SystemExit("bench.py: a result of the timed region differs from the same pair's single match(): " + json.dumps(out))
+    return out
 
 
 def stats_variant(run_steps, B, args, with_stats):

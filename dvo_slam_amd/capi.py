@@ -20,7 +20,7 @@ TERMINATION = {0: "IterationsExceeded", 1: "IncrementTooSmall", 2: "LogLikelihoo
                -1: "Unset"}
 
 EXPORTS = [
-    "dvo_amd_abi_version", "dvo_amd_status_string", "dvo_amd_last_error", "dvo_amd_device_count",
+    "dvo_amd_abi_version", "dvo_amd_build_id", "dvo_amd_status_string", "dvo_amd_last_error", "dvo_amd_device_count",
     "dvo_amd_default_config", "dvo_amd_context_create", "dvo_amd_context_destroy", "dvo_amd_configure",
     "dvo_amd_get_config", "dvo_amd_pyramid_create", "dvo_amd_pyramid_create_from_device", "dvo_amd_pyramid_retain",
     "dvo_amd_pyramid_release", "dvo_amd_pyramid_levels", "dvo_amd_pyramid_timestamp", "dvo_amd_pyramid_level_info",
@@ -104,10 +104,19 @@ def lib():
             pass
     path = _build.LIB_PATH
     if _build.needs_build():
-        path = _build.build()
+        # missing, or not built from exactly the sources next to it (dvo_amd_build_id() != the hash of csrc/* + flags)
+        try:
+            path = _build.build()
+        except RuntimeError as exc:
+            raise RuntimeError(f"{path} is missing or stale (build id {_build.library_id()!r}, sources {_build.source_id()!r}) "
+                               f"and cannot be rebuilt here: {exc}") from exc
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: build it with `python -m dvo_slam_amd._build` (no CPU fallback exists)")
     L = C.CDLL(path)
+    L.dvo_amd_build_id.restype = C.c_char_p
+    if not os.environ.get("DVO_AMD_LIB") and L.dvo_amd_build_id().decode() != _build.source_id():
+        raise RuntimeError(f"{path} carries build id {L.dvo_amd_build_id().decode()!r} but the sources next to it hash to "
+                           f"{_build.source_id()!r}: refusing to run an edited tree against a stale binary")
     fp = C.POINTER(C.c_float)
     dp = C.POINTER(C.c_double)
     vp = C.c_void_p
@@ -180,6 +189,11 @@ def lib():
     L.dvo_amd_solve6.restype = None
     _lib = L
     return L
+
+
+def build_id() -> str:
+    """the hash of the sources and flags the loaded library was built from (dvo_amd_build_id)"""
+    return lib().dvo_amd_build_id().decode()
 
 
 def _check(status: int, where: str):
@@ -378,6 +392,9 @@ class DenseTracker:
         c = self._cfg._c()
         _check(lib().dvo_amd_context_create(device, C.byref(c), C.byref(self._h)), "dvo_amd_context_create")
         self.device = device
+        # the library writes the results of a submission until it is complete: the tracker keeps every open Submission (its
+        # result structs and iteration arrays) alive, whether or not the caller holds on to it
+        self._open = {}
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -465,19 +482,36 @@ class DenseTracker:
             T0 = T0a.ctypes.data_as(C.POINTER(C.c_double))
         ticket = C.c_ulonglong()
         _check(lib().dvo_amd_match_submit(self._h, n, refs, curs, T0, res, in_flight, C.byref(ticket)), "dvo_amd_match_submit")
-        return Submission(ticket.value, res, its, n)
+        sub = Submission(ticket.value, res, its, n)
+        self._open[sub.ticket] = sub
+        return sub
 
     def wait(self, submission=None, raw: bool = False):
         """dvo_amd_match_wait: drive the queue until the submission (None: everything submitted) is complete; returns its
         results (raw=True: the C result structs as the library filled them)."""
-        _check(lib().dvo_amd_match_wait(self._h, 0 if submission is None else submission.ticket), "dvo_amd_match_wait")
+        try:
+            _check(lib().dvo_amd_match_wait(self._h, 0 if submission is None else submission.ticket), "dvo_amd_match_wait")
+        finally:  # complete, or dropped by a failed tick: either way the library is done with the result storage
+            if submission is None:
+                self._open.clear()
+            else:
+                self._open.pop(submission.ticket, None)
         return None if submission is None else submission.results(raw)
 
     def poll(self, submission=None) -> bool:
         """dvo_amd_match_poll: advance whatever has landed, never waiting for the GPU; True when the submission is complete"""
         done = C.c_int()
-        _check(lib().dvo_amd_match_poll(self._h, 0 if submission is None else submission.ticket, C.byref(done)),
-               "dvo_amd_match_poll")
+        try:
+            _check(lib().dvo_amd_match_poll(self._h, 0 if submission is None else submission.ticket, C.byref(done)),
+                   "dvo_amd_match_poll")
+        except DvoAmdError:
+            self._open.clear()  # a failed tick drops everything queued
+            raise
+        if done.value:
+            if submission is None:
+                self._open.clear()
+            else:
+                self._open.pop(submission.ticket, None)
         return bool(done.value)
 
     def track_frame(self, keyframe: RgbdImagePyramid, last_frame: RgbdImagePyramid, frame: RgbdImagePyramid,

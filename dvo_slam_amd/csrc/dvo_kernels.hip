@@ -81,21 +81,24 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int n_blocks) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
 }
 
-// trunc(1/z): the quotient rounded toward zero, independent of the current rounding mode.
-// v_rcp_f32 is accurate to 1 ulp; the exact sign of 1 - |z| c (one fma, never rounds across zero) picks the largest
-// candidate c with c <= 1/|z| among r-2ulp .. r+2ulp.
+// trunc(1/z): the quotient rounded toward zero.  MUST run with MODE.FP_ROUND = toward zero (project_pixel_rtz does).
+// r = v_rcp_f32(|z|) is within 1 ulp of rho = 1/|z|: r = rho (1 + d), |d| <= 2^-22.  One Newton step r' = r + r (1 - |z| r),
+// its residual e = 1 - |z| r exact in one fma (|z| r is within 2^-22 of 1) and the step itself one fma ROUNDED TOWARD ZERO,
+// evaluates V = rho (1 - d^2): below rho by at most rho 2^-44, far less than the spacing of floats there.  So r' = floor(V) is
+// the truncated quotient T or its lower neighbour, and the sign of the exact residual 1 - |z| nextup(r') (again one fma: a
+// non-zero value never rounds across zero) tells which.  NaN goes through as NaN (every compare is false, every candidate a
+// NaN): an unselected reference pixel -- depth NaN by construction, i.e. most lanes of most steps -- costs nothing extra.
+// Zero, denormal, huge and infinite |z| (never a pixel that ends up in bounds with a sane pose, but the result must still be
+// the division's) take the IEEE division; until round 3 NaN lanes took it too, on three of four wave steps.
 __device__ __forceinline__ float rcp_toward_zero(float z) {
   const float az = __builtin_fabsf(z);
-  if (!(az >= 1.1754944e-38f && az <= 8.5070592e+37f)) return 1.0f / z;  // 0, denormal, huge, inf, NaN: never in bounds
-  // v_rcp_f32 is within 1 ulp, so the truncated quotient is one of r-2 .. r+1.  The sign of the exact residual
-  // 1 - az*c (one fma: exact, since az*c is within 2^-23 of 1) says on which side of 1/az a candidate c lies:
-  // first r itself, then its neighbour on the side the quotient must be.
-  const unsigned r = f2u(__builtin_amdgcn_rcpf(az));
-  const bool r_below = __builtin_fmaf(-az, u2f(r), 1.0f) >= 0.0f;  // r <= 1/az
-  const unsigned n = r_below ? r + 1 : r - 1;
-  const bool n_below = __builtin_fmaf(-az, u2f(n), 1.0f) >= 0.0f;
-  const unsigned pick = r_below ? (n_below ? r + 1 : r) : (n_below ? r - 1 : r - 2);
-  return __builtin_copysignf(u2f(pick), z);
+  if (__builtin_expect(az < 1.1754944e-38f || az > 8.5070592e+37f, 0)) return 1.0f / z;  // (ordered compares: false for NaN)
+  const float r = __builtin_amdgcn_rcpf(az);
+  const float e = __builtin_fmaf(-az, r, 1.0f);
+  const unsigned lo = f2u(__builtin_fmaf(e, r, r));  // T or T - 1 ulp (toward-zero rounding)
+  const unsigned up = lo + 1u;
+  const bool up_fits = __builtin_fmaf(-az, u2f(up), 1.0f) >= 0.0f;  // nextup(r') <= 1/|z|
+  return __builtin_copysignf(u2f(up_fits ? up : lo), z);
 }
 
 // Pointers read from a descriptor in memory are generic ("flat") to the compiler; flat loads are slower and cannot be
@@ -153,18 +156,18 @@ __device__ __forceinline__ Proj project_pixel_rtz(const float *kt, const LevelPa
   p.sz = (kt[8] * x + kt[9] * y) + (kt[10] * z + kt[11]);
   const float rz = rcp_toward_zero(p.sz);
   p.u = sx * rz, p.v = sy * rz;
-  // 0 <= u <= w-2 and 0 <= v <= h-2 (:160-161,203); NaN compares false
-  p.inb = (p.u >= 0.0f) && (p.u <= d.ub_x) && (p.v >= 0.0f) && (p.v <= d.ub_y);
+  // 0 <= u <= w-2 and 0 <= v <= h-2 (:160-161,203); NaN compares false.  (Bitwise and: four compares and three scalar ands;
+  // the short-circuit form compiles to an exec-masked region.)
+  p.inb = (bool)((int)(p.u >= 0.0f) & (int)(p.u <= d.ub_x) & (int)(p.v >= 0.0f) & (int)(p.v <= d.ub_y));
   const int iu = (int)p.u, iv = (int)p.v;  // truncation == _mm_cvtps_epi32 under RTZ (:195)
-  p.base = p.inb ? iv * d.w + iu : 0;
+  p.base = p.inb ? __mul24(iv, d.w) + iu : 0;  // both factors are below 2^24 for a pixel in bounds: one full-rate v_mad_i32_i24
   return p;
 }
 
 __device__ __forceinline__ Gathered gather_pixel(const LevelPairDesc &d, int base) {
   const DVO_GLOBAL void *ca = (const DVO_GLOBAL void *)d.c_a, *cb = (const DVO_GLOBAL void *)d.c_b;
-  const unsigned ub = (unsigned)base, row = (unsigned)d.w;
-  const unsigned oa0 = ub * 16u, oa1 = (ub + row) * 16u;  // {I, Z, Ix, Iy}: 16 bytes per pixel
-  const unsigned ob0 = ub * 8u, ob1 = (ub + row) * 8u;    // {Zx, Zy}: 8 bytes per pixel
+  const unsigned oa0 = (unsigned)base * 16u, oa1 = oa0 + (unsigned)d.w * 16u;  // {I, Z, Ix, Iy}: 16 bytes per pixel
+  const unsigned ob0 = (unsigned)base * 8u, ob1 = ob0 + (unsigned)d.w * 8u;    // {Zx, Zy}: 8 bytes per pixel
   Gathered g;
   g.a00 = ld_off<v4f>(ca, oa0), g.a10 = ld_off<v4f, 16>(ca, oa0);
   g.a01 = ld_off<v4f>(ca, oa1), g.a11 = ld_off<v4f, 16>(ca, oa1);
@@ -179,8 +182,8 @@ template <bool ZERO_E>
 __device__ __forceinline__ void finish_pixel_rtz(const LevelPairDesc &d, const Proj &p, const Gathered &g, float z, float ri,
                                                  float rix, float riy, float &r0, float &r1, float &e2, float &e3, float &e4,
                                                  float &e5, bool &valid) {
-  const float fu = (float)(int)p.u, fv = (float)(int)p.v;
-  const float w1u = p.u - fu, w1v = p.v - fv;
+  // u - (float)(int)u (:211-216): for a point in bounds (u >= 0) that is u - floor(u), an exact difference: v_fract_f32
+  const float w1u = __builtin_amdgcn_fractf(p.u), w1v = __builtin_amdgcn_fractf(p.v);
   const float w0u = 1.0f - w1u, w0v = 1.0f - w1v;
   // bilinear blend, per channel: w0v*(w0u*c00 + w1u*c10) + w1v*(w0u*c01 + w1u*c11)  (:227-258)
 #define DVO_BLEND(c00, c10, c01, c11) ((w0v * (w0u * (c00) + w1u * (c10))) + (w1v * (w0u * (c01) + w1u * (c11))))
@@ -288,7 +291,9 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
   // (a two-step lead with two alternating register sets was measured: +10 VGPRs, +9 VALU per step, no gain in or out of cache)
   float n_z = ld_off<float>(p_z, 4u * idx), n_i = ld_off<float>(p_i, 4u * idx), n_ix = ld_off<float>(p_ix, 4u * idx),
         n_iy = ld_off<float>(p_iy, 4u * idx);
-  float n_tx = ld_off<float>(p_tx, 4u * pcol), n_ty = ld_off<float>(p_ty, 4u * (prow < d.h ? prow : d.h - 1));
+  const unsigned last_row = (unsigned)d.h - 1u;   // rows past the image (the padding of the planes) read the last ray: their depth is NaN
+  const bool wide = w >= kWave;                   // block uniform
+  float n_tx = ld_off<float>(p_tx, 4u * pcol), n_ty = ld_off<float>(p_ty, 4u * (prow < last_row ? prow : last_row));
 
   // Operand fetch of the Gram-matrix accumulation: lane l supplies component l & 15 of points 4 m + (l >> 4), m = 0..15, of
   // the 64 points a step staged.  With the write swizzle below, chunk (comp >> 2) of point p sits at chunk position
@@ -318,11 +323,17 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
     // prefetch the next step's reference scalars; they are consumed a whole step later
     idx += kWave;
     pcol += kWave;
-    while (pcol >= (unsigned)w) pcol -= (unsigned)w, ++prow;
+    {  // one wrap, branch free (unsigned: pcol - w wraps around when pcol < w) ...
+      const unsigned wrapped = pcol - (unsigned)w;
+      prow += wrapped < pcol ? 1u : 0u;
+      pcol = wrapped < pcol ? wrapped : pcol;
+    }
+    if (!wide)  // ... and only a level narrower than a step (block uniform) can need more
+      while (pcol >= (unsigned)w) pcol -= (unsigned)w, ++prow;
     auto prefetch_next = [&]() __attribute__((always_inline)) {
       n_z = ld_off<float>(p_z, 4u * idx), n_i = ld_off<float>(p_i, 4u * idx), n_ix = ld_off<float>(p_ix, 4u * idx),
       n_iy = ld_off<float>(p_iy, 4u * idx);
-      n_tx = ld_off<float>(p_tx, 4u * pcol), n_ty = ld_off<float>(p_ty, 4u * (prow < d.h ? prow : d.h - 1));
+      n_tx = ld_off<float>(p_tx, 4u * pcol), n_ty = ld_off<float>(p_ty, 4u * (prow < last_row ? prow : last_row));
     };
     if (prefetch) prefetch_next();
 
@@ -385,6 +396,8 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
     wgt = ok ? wgt : 0.0f;
 
     // Jacobians at the untransformed reference point (dense_tracking.cpp:333-339,448-476)
+    // (Formed from the pixel's ray instead -- x / z is tx, y / z is ty: five instructions fewer, same Jacobian to an ulp -- the
+    //  batch ran at the same 47.0 k pairs/s, three interleaved runs, gpurun_out/r4f: not kept, the arithmetic stays as it was.)
     x = ok ? x : 0.0f, y = ok ? y : 0.0f, z = ok ? z : 1.0f;
     const float iz = __builtin_amdgcn_rcpf(z);
     const float iz2 = iz * iz;
@@ -466,7 +479,7 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
       return;
     }
     // ---- rank of every valid pixel in scan order within this wave's segment (needed by the pair quirk Q5)
-    const unsigned long long bk = __ballot(ok);
+    const unsigned long long bk = __builtin_amdgcn_ballot_w64(ok);  // (__ballot() takes the flag through a vector register and back)
     const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bk, 0u));
     const int rank = run_count + pos;
     const int n_here = __popcll(bk);

@@ -1327,6 +1327,7 @@ struct Pending {
   unsigned long long batch = 0;
   bool has_init = false;
   double T_init[16];
+  float ti = 0.0f, td = 0.0f;  // the point-selection thresholds of the configuration the pair was submitted under
 };
 struct Batch {
   unsigned long long id = 0;
@@ -1343,8 +1344,14 @@ struct Runner {
   int in_flight = 0;
   bool timing = false;                      // the layout was made for kernel timing (one group)
   int resident = 0;
-  int failed_status = DVO_AMD_OK;           // a tick failed: every batch up to failed_upto ended with this status
-  unsigned long long failed_upto = 0;
+  // a tick failed: the submissions that were still open then ended with its status (a submission that had completed before
+  // keeps its OK); wait / poll of ticket 0 ("everything") reports a failure nobody has been told about yet
+  struct Failure {
+    unsigned long long batch;
+    int status;
+  };
+  std::vector<Failure> failures;
+  int unreported_failure = DVO_AMD_OK;
 };
 
 namespace {
@@ -1379,12 +1386,43 @@ int runner_fail(dvo_amd_context *ctx, int code) {
     dvo_amd_pyramid_release(q.cur);
   }
   R.pending.clear();
-  for (Batch &b : R.batches) b.remaining = 0;
+  for (Batch &b : R.batches) {
+    if (b.remaining > 0) R.failures.push_back({b.id, code});  // open when the tick failed: dropped with this status
+    b.remaining = 0;
+  }
+  if (R.failures.size() > 4096) R.failures.erase(R.failures.begin(), R.failures.end() - 2048);
   for (GroupTick &g : R.groups) g.in_flight = false;
-  R.failed_status = code;
-  R.failed_upto = R.next_batch - 1;
+  R.unreported_failure = code;
   R.batches.clear();
   return code;
+}
+
+// what wait / poll of `ticket` returns once the ticket is no longer open: the status its submission was dropped with, if it
+// was; ticket 0 ("everything submitted so far") reports a failure that no wait / poll has returned yet
+int runner_reported_status(Runner &R, unsigned long long ticket) {
+  if (ticket == 0) {
+    const int st = R.unreported_failure;
+    R.unreported_failure = DVO_AMD_OK;
+    return st;
+  }
+  for (const Runner::Failure &f : R.failures)
+    if (f.batch == ticket) {
+      R.unreported_failure = DVO_AMD_OK;
+      return f.status;
+    }
+  return DVO_AMD_OK;
+}
+
+// Entry points that work in slot 0 outside the queue (the band pipeline, the residual / error-image / stage probes, the
+// kernel bench) or change what the queue reads (match_selection) must find the queue empty: they would overwrite resident pair
+// 0's buffers and record tags, and re-allocating the slots for larger frames would leave the queue's jobs pointing at freed
+// memory.  (dvo_amd_configure refuses the same way.)
+int queue_must_be_idle(dvo_amd_context *ctx, const char *what) {
+  if (ctx->runner && (ctx->runner->resident > 0 || !ctx->runner->pending.empty())) {
+    g_last_error = std::string(what) + " while submitted pairs are still in flight (dvo_amd_match_wait first)";
+    return DVO_AMD_ERR_INVALID_ARGUMENT;
+  }
+  return DVO_AMD_OK;
 }
 
 // complete the group's tick in flight (waits for it), hand free slots to pending pairs, submit the next tick
@@ -1408,7 +1446,7 @@ int runner_step(dvo_amd_context *ctx, size_t g) {
     j.cfg = &ctx->cfg;
     R.batch_of_slot[sidx] = q.batch;
     R.resident++;
-    rc = pyramid_selection(j.ref, cfg.intensity_derivative_threshold, cfg.depth_derivative_threshold, &j.sel);
+    rc = pyramid_selection(j.ref, q.ti, q.td, &j.sel);
     if (rc) return rc;
     dvo_amd_result *r = j.result;
     r->n_levels = 0, r->n_iterations = 0, r->n_ticks = 0, r->n_residual_passes = 0, r->alg_bytes = 0.0, r->alg_bytes_discarded = 0.0, r->is_nan = 0;
@@ -1713,6 +1751,8 @@ int match_one_banded(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_p
   const dvo_amd_config &cfg = ctx->cfg;
   int rc = check_config(&cfg);
   if (rc) return rc;
+  rc = queue_must_be_idle(ctx, "dvo_amd_match_banded / _sharded");
+  if (rc) return rc;
   HIP_TRY(hipSetDevice(ctx->device));
   if (reference->device != ctx->device || current->device != ctx->device) return DVO_AMD_ERR_DEVICE_MISMATCH;
   if (reference->n_levels < cfg.first_level + 1 || current->n_levels < cfg.first_level + 1) return DVO_AMD_ERR_TOO_FEW_LEVELS;
@@ -1757,6 +1797,16 @@ int match_one_banded(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_p
 extern "C" {
 
 int dvo_amd_abi_version(void) { return DVO_AMD_ABI_VERSION; }
+
+#ifndef DVO_AMD_BUILD_ID
+#define DVO_AMD_BUILD_ID "unknown"
+#endif
+// (behind a marker, so that the id can also be read from the file without loading it: dvo_slam_amd/_build.py library_id)
+static const char kBuildIdString[] = "DVO_AMD_BUILD_ID=" DVO_AMD_BUILD_ID ";";
+const char *dvo_amd_build_id(void) {
+  static const std::string id(kBuildIdString + sizeof("DVO_AMD_BUILD_ID=") - 1, sizeof(kBuildIdString) - sizeof("DVO_AMD_BUILD_ID=") - 1);
+  return id.c_str();
+}
 
 const char *dvo_amd_status_string(int s) {
   switch (s) {
@@ -2041,6 +2091,7 @@ int dvo_amd_match_submit(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *re
     Pending q;
     q.ref = references[i], q.cur = currents[i], q.result = &results[i], q.batch = b.id;
     q.has_init = cfg.use_initial_estimate != 0;
+    q.ti = cfg.intensity_derivative_threshold, q.td = cfg.depth_derivative_threshold;
     if (q.has_init) std::memcpy(q.T_init, T_inits + 16 * (size_t)i, sizeof(q.T_init));
     // the queue holds its own references: the caller may release a pyramid right after submitting
     dvo_amd_pyramid_retain(q.ref);
@@ -2076,8 +2127,7 @@ int dvo_amd_match_wait(dvo_amd_context *ctx, unsigned long long ticket) {
     if (rc) return runner_fail(ctx, rc);
   }
   while (!R.batches.empty() && R.batches.front().remaining == 0) R.batches.pop_front();
-  if (R.failed_status != DVO_AMD_OK && ticket != 0 && ticket <= R.failed_upto) return R.failed_status;
-  return DVO_AMD_OK;
+  return runner_reported_status(R, ticket);
 }
 
 int dvo_amd_match_poll(dvo_amd_context *ctx, unsigned long long ticket, int *done) {
@@ -2097,8 +2147,7 @@ int dvo_amd_match_poll(dvo_amd_context *ctx, unsigned long long ticket, int *don
     if ((ticket == 0 || b.id == ticket) && b.remaining > 0) *done = 0;
   if (*done)
     while (!R.batches.empty() && R.batches.front().remaining == 0) R.batches.pop_front();
-  if (R.failed_status != DVO_AMD_OK && ticket != 0 && ticket <= R.failed_upto) return R.failed_status;
-  return DVO_AMD_OK;
+  return runner_reported_status(R, ticket);
 }
 
 int dvo_amd_match_many(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *references, dvo_amd_pyramid *const *currents,
@@ -2335,6 +2384,10 @@ int dvo_amd_match(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyra
 int dvo_amd_match_selection(dvo_amd_context *ctx, dvo_amd_pyramid *reference, float intensity_threshold, float depth_threshold,
                             dvo_amd_pyramid *current, const double *T_init, dvo_amd_result *result) {
   if (!ctx) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  {
+    int rc = queue_must_be_idle(ctx, "dvo_amd_match_selection");
+    if (rc) return rc;
+  }
   // the PointSelection's predicate decides which reference pixels take part, not the tracker's configuration
   // (dense_tracking.cpp:131,226: reference.select(level)); a context is single-threaded by contract
   const float keep_i = ctx->cfg.intensity_derivative_threshold, keep_d = ctx->cfg.depth_derivative_threshold;
@@ -2413,6 +2466,8 @@ int dvo_amd_residuals(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_
   if (!ctx || !reference || !current || !T || level < 0) return DVO_AMD_ERR_INVALID_ARGUMENT;
   int rc = check_level_pair(ctx, reference, current, level);
   if (rc) return rc;
+  rc = queue_must_be_idle(ctx, "dvo_amd_residuals / dvo_amd_error_image");
+  if (rc) return rc;
   const LevelData &R = reference->lv[level];
   HIP_TRY(hipSetDevice(ctx->device));
   const Selection *sel = nullptr;
@@ -2436,6 +2491,8 @@ int dvo_amd_debug_iteration(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dv
                             dvo_amd_iteration_probe *out) {
   if (!ctx || !reference || !current || !T || !out || level < 0) return DVO_AMD_ERR_INVALID_ARGUMENT;
   int rc = check_level_pair(ctx, reference, current, level);
+  if (rc) return rc;
+  rc = queue_must_be_idle(ctx, "dvo_amd_debug_iteration");
   if (rc) return rc;
   const LevelData &R = reference->lv[level];
   HIP_TRY(hipSetDevice(ctx->device));
@@ -2505,6 +2562,10 @@ int dvo_amd_bench_residual_pass_pairs(dvo_amd_context *ctx, int n_items, dvo_amd
                                       double *avg_ms, double *alg_bytes, int *n_launches) {
   if (!ctx || !references || !currents || !T || level < 0 || n_items < 1 || n_items > 1024 || reps < 1)
     return DVO_AMD_ERR_INVALID_ARGUMENT;
+  {
+    int rc = queue_must_be_idle(ctx, "dvo_amd_bench_residual_pass");
+    if (rc) return rc;
+  }
   HIP_TRY(hipSetDevice(ctx->device));
   std::vector<const Selection *> sels((size_t)n_items);
   double px = 0.0;

@@ -118,6 +118,10 @@ typedef struct dvo_amd_context dvo_amd_context; /* one DenseTracker instance: on
 typedef struct dvo_amd_pyramid dvo_amd_pyramid; /* one RgbdImagePyramid: refcounted, immutable after create, shareable */
 
 int dvo_amd_abi_version(void);
+/* The build this binary is: the first 16 hex digits of the sha256 over the compiler flags and every source file and header of
+ * the library (dvo_slam_amd/_build.py: source_id; the Makefile passes the same string).  The Python binding refuses a library
+ * whose id is not the hash of the sources next to it, and rebuilds it where hipcc exists.  "unknown" for a hand-made build. */
+const char *dvo_amd_build_id(void);
 const char *dvo_amd_status_string(int status);
 /* text of the most recent HIP failure on the calling thread ("" if none) */
 const char *dvo_amd_last_error(void);
@@ -186,7 +190,12 @@ int dvo_amd_match_selection(dvo_amd_context *ctx, dvo_amd_pyramid *reference, fl
 
 /* n independent match() calls advanced in lock step on one GPU (the shape of LocalTracker::update's tbb::parallel_invoke,
  * local_tracker.cpp:184, and of the loop-closure validator's parallel_reduce, keyframe_graph.cpp:576-593).
- * T_inits: n x 16 doubles or NULL.  Results are identical to n dvo_amd_match() calls. */
+ * T_inits: n x 16 doubles or NULL.  Results are identical to n dvo_amd_match() calls BIT FOR BIT: a pair's result is a function
+ * of its inputs and the configuration alone -- the reference's guarantee for match() calls that run side by side under TBB
+ * (keyframe_graph.cpp:587-590, local_tracker.cpp:184).  The same holds for dvo_amd_match_many at any max_in_flight, for the
+ * submit / wait / poll queue whatever else is queued, for dvo_amd_validate_proposals at any number of workers, and for
+ * dvo_amd_match_banded / dvo_amd_match_sharded at 1, 2, 4, 8 and 16 bands (tests/test_determinism.py): the geometry of a residual
+ * pass is the pyramid level's own and every sum across blocks follows one tree per level (csrc/dvo_types.h). */
 int dvo_amd_match_batch(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *references, dvo_amd_pyramid *const *currents,
                         const double *T_inits, dvo_amd_result *results);
 
@@ -207,8 +216,12 @@ int dvo_amd_match_many(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *refe
  * stay valid and untouched until the submission is complete; the queue retains the pyramids itself; the tracker's
  * configuration must not change while pairs are queued (dvo_amd_configure refuses); a different max_in_flight or larger
  * frames than the queue was laid out for let the queued pairs run to completion first.  Results are those of n dvo_amd_match()
- * calls.  If a tick fails, every queued pair is dropped, nothing of the context is running any more when the error is
- * returned, and the wait / poll of each dropped submission returns that status.
+ * calls, bit for bit.  While pairs are queued every entry point that works outside the queue in the context's scratch
+ * (dvo_amd_match_banded / _sharded, dvo_amd_match_selection, dvo_amd_residuals, dvo_amd_error_image, the debug and bench
+ * entries) returns DVO_AMD_ERR_INVALID_ARGUMENT, like dvo_amd_configure.  If a tick fails, every queued pair is dropped,
+ * nothing of the context is running any more when the error is returned, and the wait / poll of each submission that was still
+ * open then returns that status (a submission that had completed before keeps its OK; ticket 0 returns a failure that no
+ * wait / poll has reported yet, once).
  */
 int dvo_amd_match_submit(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *references, dvo_amd_pyramid *const *currents,
                          const double *T_inits, dvo_amd_result *results, int max_in_flight, unsigned long long *ticket);
@@ -217,8 +230,10 @@ int dvo_amd_match_poll(dvo_amd_context *ctx, unsigned long long ticket, int *don
 
 /*
  * One pair tile-sharded over several GPUs (BASELINE config 4).  Every rank holds both pyramids and processes one band of
- * scan-order blocks of every level; per Gauss-Newton tick the ranks all-gather one 784-byte record per band over RCCL and
- * combine them left to right, so every rank runs the identical state machine and returns the identical result.
+ * scan-order blocks of every level (whole chunks of the level's summation tree); per Gauss-Newton tick the ranks all-gather
+ * one 784-byte record per band over RCCL and fold them along that tree, so every rank runs the identical state machine and
+ * returns the identical result -- for 1, 2, 4, 8 and 16 ranks the result of dvo_amd_match() on one GPU, bit for bit (other
+ * rank counts: to the rounding of the fp64 sums).
  *   id = dvo_amd_comm_unique_id() on rank 0, broadcast by the caller (torch.distributed, MPI, a file ...);
  *   dvo_amd_comm_create(ctx, id, nranks, rank) on every rank;  dvo_amd_match_sharded(...) on every rank, same arguments.
  * dvo_amd_match_banded runs the same band pipeline with all n_bands bands on ONE GPU (no communicator): it is how the band

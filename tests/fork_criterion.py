@@ -144,6 +144,9 @@ def without_overflow(orc, ocfg, o_ref, o_cur, T_init):
     return orc.match(orc.default_config(**kw), o_ref, o_cur, T_init)
 
 
+DIVERGED_PATH_CEILING = 3e-4  # no forked path may be further from the oracle than this, whatever the oracle's own spread
+
+
 def pose_bar(orc, synth, ocfg, o_ref, o_cur, T_init, ro, err, pose_tol=1e-5):
     """The pose tolerance for callers that hold no per-iteration statistics of the GPU side (the batched validator, the
     front-end step): pose_tol when the GPU is within it; otherwise the GPU may be as far from the oracle as the oracle lands
@@ -156,7 +159,9 @@ def pose_bar(orc, synth, ocfg, o_ref, o_cur, T_init, ro, err, pose_tol=1e-5):
         sd = self_distance(orc, synth, ocfg, o_ref, o_cur, T_init, ro, thorough=True)
     d_self = max(d for d, _ in sd.values())
     worst = max(sd, key=lambda k: sd[k][0])
-    return max(pose_tol, SELF_DISTANCE_SLACK * d_self), \
+    # an absolute ceiling on top: on a chaotic pair the oracle's own spread can grow to the size of a whole
+    # Gauss-Newton step, and a bar that grows with it would let a real regression through
+    return min(DIVERGED_PATH_CEILING, max(pose_tol, SELF_DISTANCE_SLACK * d_self)), \
         f"pose error {err:.2e}; the oracle lands up to {d_self:.2e} from itself ({worst}; {len(sd)} perturbations below the " \
         f"GPU's arithmetic differences tried)"
 

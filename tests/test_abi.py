@@ -94,3 +94,31 @@ def test_product_package_does_not_touch_the_oracle():
         p = os.path.join(ROOT, "include", f)
         if os.path.isfile(p):
             assert "oracle" not in open(p).read().lower().replace("no oracle", "")
+
+
+def test_build_id_ties_the_binary_to_the_sources(tmp_path):
+    """dvo_amd_build_id() is the hash of csrc/*, include/dvo_amd.h and the compiler flags the library was built from; a library
+    whose id is not the hash of the sources next to it is rebuilt (where hipcc exists) or refused -- never silently used
+    (staleness used to be mtime-only)."""
+    import subprocess
+    import sys
+
+    from dvo_slam_amd import _build, capi
+
+    assert capi.build_id() == _build.source_id() == _build.library_id()
+    assert len(capi.build_id()) == 16 and int(capi.build_id(), 16) >= 0
+    # a copy whose embedded id was tampered with reads as stale ...
+    blob = open(_build.LIB_PATH, "rb").read()
+    at = blob.find(b"DVO_AMD_BUILD_ID=") + len(b"DVO_AMD_BUILD_ID=")
+    stale = tmp_path / "libdvo_amd.so"
+    stale.write_bytes(blob[:at] + b"0" * 16 + blob[at + 16:])
+    assert _build.library_id(str(stale)) == "0" * 16 != _build.source_id()
+    # ... and where it cannot be rebuilt the binding refuses it instead of running it
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from dvo_slam_amd import _build, capi\n"
+            "_build.LIB_PATH = %r\n"
+            "def no_compiler(*a, **k): raise RuntimeError('no hipcc on this box')\n"
+            "_build.build = no_compiler\n"
+            "try:\n    capi.lib()\nexcept RuntimeError as e:\n    print('REFUSED', e)\n" % (ROOT, str(stale)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "REFUSED" in out.stdout and "stale" in out.stdout, out.stdout + out.stderr

@@ -890,6 +890,41 @@ def test_queue_keeps_pairs_resident_across_submissions(capi, synth, pair640):
     assert len(trk.match(pair640["gr"], pair640["gc"]).Levels) == 3
 
 
+def test_entries_outside_the_queue_are_refused_while_pairs_are_queued(capi, synth, pair640):
+    """the band pipeline, the residual / stage probes, the kernel bench and match_selection work in slot 0 of the
+    context's scratch (or change what the queue reads): with a submission in flight they are refused like dvo_amd_configure,
+    and the submission still completes with the single match()'s bits.  A Submission the caller dropped stays alive inside the
+    tracker until the library is done with its result storage."""
+    import gc
+
+    cfg = capi.Config(FirstLevel=3, LastLevel=0)
+    trk, plain = capi.DenseTracker(cfg), capi.DenseTracker(cfg)
+    want = plain.match(pair640["gr"], pair640["gc"])
+    sub = trk.submit([pair640["gr"]] * 60, [pair640["gc"]] * 60, in_flight=20)
+    T = np.eye(4)
+    for call in (lambda: trk.match_banded(pair640["gr"], pair640["gc"], 2),
+                 lambda: trk.residuals(pair640["gr"], pair640["gc"], 0, T),
+                 lambda: trk.computeIntensityErrorImage(pair640["gr"], pair640["gc"], T, 1),
+                 lambda: trk.iteration_probe(pair640["gr"], pair640["gc"], 2, T),
+                 lambda: trk.bench_residual_pass(pair640["gr"], pair640["gc"], 0, T, 4),
+                 lambda: capi._check(capi.lib().dvo_amd_match_selection(trk._h, pair640["gr"]._h, 2.5, 0.01, pair640["gc"]._h, None,
+                                                                        capi.C.byref(capi.CResult())), "dvo_amd_match_selection")):
+        with pytest.raises(capi.DvoAmdError):
+            call()
+    for r in trk.wait(sub):
+        assert np.array_equal(want.Transformation, r.Transformation)
+    # idle again: the same entries work
+    assert trk.residuals(pair640["gr"], pair640["gc"], 0, T)[1] > 0
+    assert np.array_equal(trk.match_banded(pair640["gr"], pair640["gc"], 2).Transformation, want.Transformation)
+    # fire and forget: the caller drops the Submission, the tracker keeps its result storage alive until wait() returns
+    trk.submit([pair640["gr"]] * 40, [pair640["gc"]] * 40, in_flight=10)
+    gc.collect()
+    junk = [np.zeros(100_000) for _ in range(20)]  # churn the allocator: freed result structs would be overwritten
+    assert trk.wait() is None and not trk._open
+    del junk
+    assert np.array_equal(trk.match(pair640["gr"], pair640["gc"]).Transformation, want.Transformation)
+
+
 def test_queue_holds_its_own_pyramid_references(capi, synth):
     """The queue retains the pyramids of a submission: the caller may drop its handles right after submitting (the reference's
     callers hand boost::shared_ptr copies to their TBB tasks the same way, keyframe_graph.cpp:576-593)."""
