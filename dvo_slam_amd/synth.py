@@ -9,6 +9,10 @@ are NaN (invalid), as a structured-light sensor would produce.
 Inputs follow the reference's contract (dvo_benchmark/src/benchmark_slam.cpp:46-93): intensity is
 float32 in 0..255, depth is float32 metres with NaN = invalid, TUM fr1 intrinsics by default
 (benchmark_slam.cpp:384).
+
+Two regimes: render() / make_pair() are noise-free (exact depth); sensor_frame() / sensor_pair() deliver the same
+views the way the reference's inputs arrive -- 8-bit grey, uint16 depth at 1/5000 m, depth noise of the sigma the
+reference models itself (depth_std_dev) -- see the block above sensor_frame().
 """
 from __future__ import annotations
 
@@ -158,6 +162,76 @@ def to_raw(intensity, depth, depth_factor: float = 5000.0, seed: int = SEED + 3)
     return bgr, raw_z
 
 
+# ---- the regime the reference actually runs in: what a structured-light RGB-D sensor / a TUM PNG pair delivers ------------
+# dvo_benchmark/src/benchmark_slam.cpp:56-80 feeds 8-bit grey (cv::cvtColor + convertTo(CV_32F), :60-68) and uint16 depth in
+# 1/5000 m with 0 = no measurement (:77) from a sensor whose depth noise the reference models itself: depthStdDevZ(z) =
+# 0.0012 + 0.0019 (z - 0.4)^2 (dvo_core/src/dense_tracking_impl.cpp:122-128, the occlusion test's sigma).  The analytic frames
+# above are noise-free: their depth precision comes out as 1e9, the reference's 50-term likelihood product overflows and one
+# valid pixel more or less flips an iteration -- artefacts that never occur on sensor data.  sensor_frame() adds what the
+# sensor adds, deterministically (hashed, seeded): Gaussian depth noise of exactly that sigma, quantisation to 1/5000 m,
+# Gaussian intensity noise and rounding to 8 bits.
+DEPTH_FACTOR = 5000.0
+
+
+def depth_std_dev(z):
+    """depthStdDevZ, dense_tracking_impl.cpp:122-128"""
+    z = np.asarray(z, dtype=np.float64)
+    return 0.0012 + 0.0019 * (z - 0.4) ** 2
+
+
+def _hash_normal(width: int, height: int, seed: int):
+    """one N(0, 1) sample per pixel from two hashed uniforms (Box-Muller): deterministic, independent of numpy's generators"""
+    u, v = np.meshgrid(np.arange(width, dtype=np.int64), np.arange(height, dtype=np.int64))
+    u1 = (_hash_u32(u, v, seed).astype(np.float64) + 1.0) / 4294967297.0  # (0, 1)
+    u2 = _hash_u32(u, v, seed ^ 0x5BD1E995).astype(np.float64) / 4294967296.0
+    return np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+
+
+def sensor_from_analytic(intensity, depth, seed: int = SEED, frame_id: int = 0, intensity_sigma: float = 1.5,
+                         depth_noise: float = 1.0, channels: int = 1):
+    """A noise-free frame (render()) as the sensor would deliver it: depth = true depth + depth_noise * depthStdDevZ(depth) *
+    N(0, 1), rounded to the 0.2 mm grid (0 = no measurement); grey = texture + intensity_sigma * N(0, 1), rounded and clipped
+    to 0..255.  Noise is hashed from (pixel, seed, frame_id)."""
+    height, width = intensity.shape
+    nz = _hash_normal(width, height, seed + 1009 + 7919 * frame_id)
+    ni = _hash_normal(width, height, seed + 2003 + 104729 * frame_id)
+    z = depth.astype(np.float64)
+    with np.errstate(invalid="ignore"):
+        z_noisy = z + depth_noise * depth_std_dev(z) * nz
+        raw = np.rint(np.where(np.isnan(z_noisy), 0.0, z_noisy) * DEPTH_FACTOR)
+    raw_z = np.clip(raw, 0, 65535).astype(np.uint16)
+    gray = np.clip(np.rint(intensity.astype(np.float64) + intensity_sigma * ni), 0, 255).astype(np.uint8)
+    if channels == 3:
+        gray = np.repeat(gray[..., None], 3, axis=2)  # a grey scene seen by a colour camera: B = G = R
+    return gray, raw_z
+
+
+def sensor_frame(width: int, height: int, T_cam=None, seed: int = SEED, frame_id: int = 0, intensity_sigma: float = 1.5,
+                 depth_noise: float = 1.0, channels: int = 1, K=None, nan_fraction: float = 0.02, hole: bool = True):
+    """The analytic view from T_cam as a sensor would deliver it: (uint8 grey HxW -- or BGR HxWx3 with channels=3 --, uint16
+    depth in 1/5000 m, 0 = no measurement); see sensor_from_analytic()."""
+    I, Z = render(width, height, T_cam, seed, frame_id, nan_fraction, hole, K)
+    return sensor_from_analytic(I, Z, seed, frame_id, intensity_sigma, depth_noise, channels)
+
+
+def raw_to_float(image, raw_z, depth_factor: float = DEPTH_FACTOR):
+    """What frame ingest makes of a raw frame (benchmark_slam.cpp:60-80; the oracle's orc_ingest_* and the device's k_ingest do
+    the same bit for bit, tests/test_gpu_parity.py::test_ingest_raw_frame_bit_exact): float32 grey 0..255 and float32 metres,
+    (float) raw * (float)(1 / factor), with NaN where raw is 0.  Grey input only (BGR goes through the luma rule of ingest)."""
+    assert image.ndim == 2
+    scale = np.float32(1.0 / depth_factor)
+    Z = raw_z.astype(np.float32) * scale
+    Z[raw_z == 0] = np.nan
+    return image.astype(np.float32), Z
+
+
+def sensor_pair(width: int = 640, height: int = 480, xi_gt=XI_GT_PAIR, seed: int = SEED, frame_id: int = 0, **kw):
+    """make_pair() in the sensor regime: ((grey_ref, raw_z_ref), (grey_cur, raw_z_cur), T_gt)"""
+    T_gt = se3_exp(xi_gt)
+    return (sensor_frame(width, height, None, seed, 2 * frame_id, **kw),
+            sensor_frame(width, height, T_gt, seed, 2 * frame_id + 1, **kw), T_gt)
+
+
 def make_pair(width: int = 640, height: int = 480, xi_gt=XI_GT_PAIR, seed: int = SEED, frame_id: int = 0):
     """Reference frame at the scene origin, current frame at exp(xi_gt).  The expected DenseTracker result
     (cur <- ref convention, dense_tracking.cpp:371) is T = exp(xi_gt)."""
@@ -186,23 +260,25 @@ def loop_closure_poses(n_candidates: int = 32, seed: int = SEED + 2, max_trans: 
 
 
 def loop_closure_scenario(width: int = 640, height: int = 480, n_candidates: int = 6, seed: int = SEED, decoys: bool = True,
-                          pose_error: float = 0.1):
+                          pose_error: float = 0.1, sensor: bool = False):
     """Config 5 as a validator workload: one keyframe (id 100, pose = identity) and candidate keyframes at the hashed poses of
     loop_closure_poses().  Every entry: dict(id, frame=(I, Z), pose_true, pose) where `pose` is the pose the pose graph
     believes (the true one with `pose_error` of its twist removed, mirroring the 10 % perturbation of SURVEY.md config 5).
     With decoys, three candidates that validation must throw out are appended: a neighbour in id (odometry constraint),
     a frame of a different scene (seed + 77), and a frame without any depth (NaN result)."""
-    key = dict(id=100, frame=render(width, height, None, seed, 0), pose_true=np.eye(4), pose=np.eye(4))
+    def frame(T, sd, fid):  # sensor=True: the frame as the sensor delivers it, ingested to float planes (raw_to_float)
+        return raw_to_float(*sensor_frame(width, height, T, sd, fid)) if sensor else render(width, height, T, sd, fid)
+
+    key = dict(id=100, frame=frame(None, seed, 0), pose_true=np.eye(4), pose=np.eye(4))
     cands = []
     for i, T in enumerate(loop_closure_poses(n_candidates)):
         xi = se3_log(T)
-        cands.append(dict(id=2 * i, frame=render(width, height, T, seed, 1 + i), pose_true=T,
-                          pose=se3_exp(xi * (1.0 - pose_error))))
+        cands.append(dict(id=2 * i, frame=frame(T, seed, 1 + i), pose_true=T, pose=se3_exp(xi * (1.0 - pose_error))))
     if decoys:
         T = se3_exp(XI_STEP_STREAM)
-        cands.append(dict(id=101, frame=render(width, height, T, seed, 50), pose_true=T, pose=T))
+        cands.append(dict(id=101, frame=frame(T, seed, 50), pose_true=T, pose=T))
         T = se3_exp(XI_GT_PAIR)
-        cands.append(dict(id=60, frame=render(width, height, T, seed + 77, 51), pose_true=T, pose=T))
-        I, Z = render(width, height, T, seed, 52)
+        cands.append(dict(id=60, frame=frame(T, seed + 77, 51), pose_true=T, pose=T))
+        I, Z = frame(T, seed, 52)
         cands.append(dict(id=70, frame=(I, np.full_like(Z, np.nan)), pose_true=T, pose=T))
     return key, cands

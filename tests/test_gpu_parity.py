@@ -193,6 +193,11 @@ def test_every_iteration_of_a_match_teacher_forced(capi, orc, synth, pair640, ca
         gr, gc = capi.RgbdImagePyramid(Ir, Zr, K, 3), capi.RgbdImagePyramid(Ic, Zc, K, 3)
         orr, occ = orc.Pyramid(Ir, Zr, K, 3), orc.Pyramid(Ic, Zc, K, 3)
         first = 2
+    _teacher_forced(capi, orc, synth, gr, gc, orr, occ, first, case, capsys)
+
+
+def _teacher_forced(capi, orc, synth, gr, gc, orr, occ, first, case, capsys):
+    """every iteration of the oracle's match of (orr, occ), replayed on the GPU from the oracle's pose and previous precision"""
     # The reference's sequential fp32 sums drift with the number of terms (840 000 at level 0 of 1280x960): against the float64
     # restatement the oracle itself is off by 6.1e-4 (scale), 2.1e-3 (A), 1.2e-4 (b) there, the GPU by 1e-7 as everywhere.
     REF_SCALE_RTOL, REF_A_RTOL, REF_B_CS = ((2e-3, 6e-3, 4e-4) if case.startswith("1280x960") else
@@ -230,6 +235,7 @@ def test_every_iteration_of_a_match_teacher_forced(capi, orc, synth, pair640, ca
         print(f"\n[teacher-forced {case}] {n_checked} iterations ({n_weighted} weighted): worst deviations "
               + ", ".join(f"{k} {v:.1e}" for k, v in worst.items()))
     assert n_checked >= 10 and n_weighted >= 6
+    return worst
 
 
 @pytest.mark.parametrize("n_drop", [0, 1, 2, 3, 49])
@@ -277,7 +283,7 @@ ITER_INCREMENT_RTOL, ITER_INCREMENT_ATOL = 2e-2, 3e-6
 ITER_COUNT_SLACK = 3  # constraints (or 1e-5 of them, whichever is more) by which V of a later iteration may differ on a same-path run
 
 
-def _compare_iterations(levels_gpu, levels_orc, label, first_is_identical=True):
+def _compare_iterations(levels_gpu, levels_orc, label, first_is_identical=True, count_slack=None):
     """levels_orc: [(V, -ll, P 2x2, has_increment, increment)] per level.  Asserts the per-iteration quantities and returns
     (iterations compared, iterations with identical V)."""
     n_it = n_same_v = 0
@@ -290,7 +296,7 @@ def _compare_iterations(levels_gpu, levels_orc, label, first_is_identical=True):
             identical = first_is_identical and k == 0 and li == 0
             if identical:
                 assert ig["ValidConstraints"] == V, where  # identical inputs
-            assert abs(ig["ValidConstraints"] - V) <= max(ITER_COUNT_SLACK, 1e-5 * V), where + (ig["ValidConstraints"], V)
+            assert abs(ig["ValidConstraints"] - V) <= max(count_slack or ITER_COUNT_SLACK, 1e-5 * V), where + (ig["ValidConstraints"], V)
             if ig["ValidConstraints"] != V:
                 continue
             n_same_v += 1
@@ -301,7 +307,10 @@ def _compare_iterations(levels_gpu, levels_orc, label, first_is_identical=True):
             assert np.allclose(ig["TDistributionPrecision"], P, rtol=p_rtol, atol=p_rtol * np.abs(P).max()), where
             assert abs(ig["TDistributionLogLikelihood"] - nll) <= l_rtol * abs(nll), where
             if has_inc:
-                assert np.allclose(ig["EstimateIncrement"], inc, rtol=ITER_INCREMENT_RTOL, atol=ITER_INCREMENT_ATOL), where
+                # (a drift band, not a precision claim: the two sides reach the iteration at poses ~1e-6 apart; on sensor-noise
+                #  input that moves an increment by a few per cent of its largest component)
+                assert np.allclose(ig["EstimateIncrement"], inc, rtol=ITER_INCREMENT_RTOL,
+                                   atol=max(ITER_INCREMENT_ATOL, 0.05 * np.abs(inc).max())), where
     return n_it, n_same_v
 
 
@@ -310,10 +319,12 @@ def _oracle_levels(ro):
              for it in L["iterations"]] for L in ro["levels"]]
 
 
-def _check_match(capi, orc, synth, g_ref, g_cur, o_ref, o_cur, cfg_kw, T_init=None, tol=POSE_TOL):
+def _check_match(capi, orc, synth, g_ref, g_cur, o_ref, o_cur, cfg_kw, T_init=None, tol=POSE_TOL, paths=None, label=None,
+                 count_slack=None):
     import inspect
 
-    label = inspect.stack()[1].function + repr(sorted(cfg_kw.items()))
+    _PATHS = paths if paths is not None else globals()["_PATHS"]  # (the sensor-regime suite keeps its own book)
+    label = label or (inspect.stack()[1].function + repr(sorted(cfg_kw.items())))
     gcfg = capi.Config(**cfg_kw)
     trk = capi.DenseTracker(gcfg)
     rg = trk.match(g_ref, g_cur, T_init)
@@ -327,12 +338,13 @@ def _check_match(capi, orc, synth, g_ref, g_cur, o_ref, o_cur, cfg_kw, T_init=No
     same_path = all(Lg["TerminationCriterion"] == Lo["termination"] and len(Lg["Iterations"]) == len(Lo["iterations"])
                     for Lg, Lo in zip(rg.Levels, ro["levels"]))
     _PATHS["same" if same_path else "forked"].append(label)
+    _PATHS.setdefault("errs", []).append(err)
     if not same_path:
         _PATHS.setdefault("fork_err", []).append(err)
     if same_path:
         assert err <= tol, err
         # every Gauss-Newton iteration, not only the final pose
-        n_it, n_same_v = _compare_iterations(rg.Levels, _oracle_levels(ro), label)
+        n_it, n_same_v = _compare_iterations(rg.Levels, _oracle_levels(ro), label, count_slack=count_slack)
         print(f"[iterations] {label}: {n_it} compared, {n_same_v} with identical ValidConstraints, pose err {err:.2e}")
     else:
         # no blanket tolerance: the fork must be legitimate on its own evidence (tests/fork_criterion.py)
@@ -343,7 +355,8 @@ def _check_match(capi, orc, synth, g_ref, g_cur, o_ref, o_cur, cfg_kw, T_init=No
         for Lg, Lo in zip(rg.Levels, ro["levels"]):
             if len(Lg["Iterations"]) != len(Lo["iterations"]) or Lg["TerminationCriterion"] != Lo["termination"]:
                 break
-            _compare_iterations([Lg], _oracle_levels({"levels": [Lo]}), label + " (prefix)", first_is_identical=Lg is rg.Levels[0])
+            _compare_iterations([Lg], _oracle_levels({"levels": [Lo]}), label + " (prefix)", first_is_identical=Lg is rg.Levels[0],
+                                count_slack=count_slack)
     assert rg.isNaN() == ro["is_nan"]
     assert [L["Id"] for L in rg.Levels] == [L["id"] for L in ro["levels"]]
     for Lg, Lo in zip(rg.Levels, ro["levels"]):
@@ -1050,11 +1063,17 @@ def test_ingest_argument_errors(capi, synth, pair640):
 # dual-match front-end step
 # ---------------------------------------------------------------------------------------------------------------------
 def test_track_frame_equals_oracle_and_two_single_matches(capi, orc, synth):
+    _track_frame_case(capi, orc, synth, synth.render, _PATHS)
+
+
+def _track_frame_case(capi, orc, synth, render, _PATHS, gt_tol=1e-3):
+    """render(width, height, T_cam, frame_id=...) -> (intensity, depth) float planes: the noise-free frames here, the sensor
+    regime's in tests/test_sensor_regime.py"""
     from oracle import frontend
 
     K = synth.intrinsics_for(640, 480)
     poses = synth.stream_poses(7)
-    frames = [synth.render(640, 480, poses[t], frame_id=t) for t in (0, 5, 6)]  # keyframe, last frame, new frame
+    frames = [render(640, 480, poses[t], frame_id=t) for t in (0, 5, 6)]  # keyframe, last frame, new frame
     g = [capi.RgbdImagePyramid(I, Z, K, 4) for I, Z in frames]
     o = [orc.Pyramid(I, Z, K, 4) for I, Z in frames]
     for cfg_kw in (dict(FirstLevel=3, LastLevel=1, UseInitialEstimate=True), dict(FirstLevel=3, LastLevel=0, UseInitialEstimate=False)):
@@ -1078,7 +1097,7 @@ def test_track_frame_equals_oracle_and_two_single_matches(capi, orc, synth):
                 _PATHS["fork_err"].append(err)
                 _PATHS["reports"].append((_PATHS["forked"][-1], fork_criterion.adjudicate(
                     orc, synth, ocfg, o_ref, o[2], T0, got, want, err, POSE_TOL)))
-        assert synth.pose_error(rk.Transformation, poses[6]) < 1e-3 and synth.pose_error(ro.Transformation, poses[6] @ np.linalg.inv(poses[5])) < 1e-3
+        assert synth.pose_error(rk.Transformation, poses[6]) < gt_tol and synth.pose_error(ro.Transformation, poses[6] @ np.linalg.inv(poses[5])) < gt_tol
         # the likelihood is discontinuous in the valid-constraint count (Q5 re-pairing, Q6 tail): +-1 constraint moves it by
         # ~1e4 of ~4e6 even on the same iteration path, so it is only comparable to a few percent (chaos caveat above)
         for name, want in ocrit.items():
@@ -1154,8 +1173,10 @@ def test_zz_every_fork_was_adjudicated(capsys):
     adjudicated where it happened -- an illegitimate fork failed its test there -- and the verdicts are printed here.  There is
     no budget of allowed forks: how many configurations fork, and which, changes with any change of summation order."""
     with capsys.disabled():
-        print(f"\n[paths] same: {len(_PATHS['same'])}, forked: {len(_PATHS['forked'])} (accumulator: "
-              f"{os.environ.get('DVO_AMD_ACCUM', 'mfma')}); pose errors of the forked configurations: "
+        print(f"\n[paths] analytic (noise-free) regime: same path: {len(_PATHS['same'])}, forked: {len(_PATHS['forked'])} "
+              f"(accumulator: {os.environ.get('DVO_AMD_ACCUM', 'mfma')}); configurations beyond 1e-5 of the oracle: "
+              f"{sum(e > 1e-5 for e in _PATHS.get('errs', []))} of {len(_PATHS.get('errs', []))}, worst "
+              f"{max(_PATHS.get('errs', [0.0])):.2e}; pose errors of the forked configurations: "
               f"{['%.1e' % e for e in _PATHS['fork_err']]}")
         for label, report in _PATHS["reports"]:
             print(f"[fork] {label}")

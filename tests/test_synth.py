@@ -49,3 +49,21 @@ def test_workload_generators(synth):
     for T in lc:
         xi = synth.se3_log(T)
         assert np.linalg.norm(xi[3:]) <= np.deg2rad(5.0) + 1e-9
+
+
+def test_the_sensor_model_is_what_it_says(synth):
+    """8-bit grey, uint16 depth on the 0.2 mm grid with 0 = no measurement, depth noise of the reference's own sigma"""
+    (gray, raw_z), _, _ = synth.sensor_pair(640, 480)
+    I, Z = synth.render(640, 480)
+    assert gray.dtype == np.uint8 and raw_z.dtype == np.uint16 and gray.shape == raw_z.shape == (480, 640)
+    assert np.array_equal(raw_z == 0, np.isnan(Z))
+    If, Zf = synth.raw_to_float(gray, raw_z)
+    m = ~np.isnan(Z)
+    ratio = (Zf[m].astype(np.float64) - Z[m]) / synth.depth_std_dev(Z[m])
+    assert abs(ratio.std() - 1.0) < 0.02 and abs(ratio.mean()) < 0.01          # N(0, sigma_z(z)), on top of +-0.1 mm rounding
+    assert abs(synth.depth_std_dev(0.4) - 0.0012) < 1e-15 and abs(synth.depth_std_dev(2.4) - 0.0088) < 1e-15
+    assert 1.3 < (If - I).std() < 1.7
+    again = synth.sensor_frame(640, 480)  # deterministic
+    assert np.array_equal(again[0], gray) and np.array_equal(again[1], raw_z)
+    other = synth.sensor_frame(640, 480, frame_id=1)
+    assert not np.array_equal(other[1], raw_z)

@@ -188,7 +188,7 @@ def _summary_gpu(props):
              p.TrackingResult.Transformation, p.TotalScore(), p.origin) for p in props]
 
 
-def _like_with_like(orc, synth, ov, stage, g_props, notes):
+def _like_with_like(orc, synth, ov, stage, g_props, notes, ceiling=None):
     """Every GPU survivor of `stage` against the oracle's alignment of the SAME proposal -- same (reference, current) and same
     initialisation lineage (`origin`), whether or not the oracle's own keepBest / cross-validation kept it -- under the fork
     rule of tests/fork_criterion.py: 1e-5, or as far as the oracle lands from itself under re-associated sums.
@@ -203,7 +203,8 @@ def _like_with_like(orc, synth, ov, stage, g_props, notes):
         if artefact:
             notes.append(f"{rid}->{cid} origin {p.origin}: {artefact}")
         err = synth.pose_error(ro["T"], p.TrackingResult.Transformation)
-        bar, note = fork_criterion.pose_bar(orc, synth, stage.TrackingConfig, ov.images[rid], ov.images[cid], init, ro, err, POSE_TOL)
+        bar, note = fork_criterion.pose_bar(orc, synth, stage.TrackingConfig, ov.images[rid], ov.images[cid], init, ro, err, POSE_TOL,
+                                            ceiling)
         if note:
             notes.append(f"{rid}->{cid} origin {p.origin}: {note}")
         assert err <= bar, (rid, cid, p.origin, err, bar, note)
@@ -211,7 +212,7 @@ def _like_with_like(orc, synth, ov, stage, g_props, notes):
     return worst
 
 
-def _compare(orc, synth, ov, got_props, want_props, notes):
+def _compare(orc, synth, ov, got_props, want_props, notes, ceiling=None):
     """Survivors, their order, every vote decision; vote values within the heuristic band of a likelihood ratio.  Poses are
     compared like with like for a single stage only: in a free-running two-stage run each side starts stage 2 from its OWN
     stage-1 estimate (validator.cpp:95-100), so the two sides align different proposals there -- the second stage is compared
@@ -225,11 +226,11 @@ def _compare(orc, synth, ov, got_props, want_props, notes):
         assert np.allclose(g[3], w[3], rtol=1e-2, atol=6e-4), (g[3], w[3])
         assert abs(g[5] - w[5]) <= 1e-2 * max(1.0, abs(w[5]))
     if len(ov.stages) == 1:
-        return _like_with_like(orc, synth, ov, ov.stages[0], got_props, notes)
+        return _like_with_like(orc, synth, ov, ov.stages[0], got_props, notes, ceiling)
     return 0.0
 
 
-def _teacher_forced_second_stage(orc, synth, Cn, V, make_validators, o_stage1, gkf, okf, notes):
+def _teacher_forced_second_stage(orc, synth, Cn, V, make_validators, o_stage1, gkf, okf, notes, ceiling=None):
     """Stage 2 alone on both sides, both starting from the ORACLE's stage-1 survivors (reference, current, initial transformation
     = inverse of the oracle's stage-1 estimate): every GPU survivor against the oracle's alignment of the same proposal.
     make_validators() -> (GPU validator, oracle validator) holding the second stage only."""
@@ -239,23 +240,35 @@ def _teacher_forced_second_stage(orc, synth, Cn, V, make_validators, o_stage1, g
     g2, o2 = gv2.validate(gp2), ov2.validate(op2)
     assert len(ov2.history) == len(o_stage1)
     assert {frozenset((p.Reference.id, p.Current.id)) for p in g2} == {frozenset((p.Reference.id, p.Current.id)) for p in o2}
-    return g2, o2, _like_with_like(orc, synth, ov2, ov2.stages[0], g2, notes)
+    return g2, o2, _like_with_like(orc, synth, ov2, ov2.stages[0], g2, notes, ceiling)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["LogLikelihood", "NormalizedLogLikelihood", "EntropyRatio"])
 def test_gpu_validator_equals_oracle(orc, V, synth, kind):
+    _validator_against_oracle(orc, V, synth, kind, sensor=False)
+
+
+@pytest.mark.gpu
+def test_gpu_validator_equals_oracle_on_sensor_frames(orc, V, synth):
+    """the same scenario as the sensor delivers it: 8-bit grey, uint16 depth at 1/5000 m with the depth noise the reference models
+    (synth.sensor_frame) -- the regime the reference's validator actually runs in"""
+    _validator_against_oracle(orc, V, synth, "LogLikelihood", sensor=True)
+
+
+def _validator_against_oracle(orc, V, synth, kind, sensor):
     from dvo_slam_amd import capi, constraints as Cn
 
     if capi.lib().dvo_amd_device_count() < 1:
         pytest.fail("no HIP device visible: the gpu tests must run on the MI355X box")
     n_cand = 6
-    okey, ocands = S.oracle_keyframes(orc, V, synth, 640, 480, n_cand, getattr(V, kind + "TrackingResultEvaluation"))
-    gkey, gcands = S.gpu_keyframes(capi, Cn, synth, 640, 480, n_cand, getattr(Cn, kind + "TrackingResultEvaluation"))
+    okey, ocands = S.oracle_keyframes(orc, V, synth, 640, 480, n_cand, getattr(V, kind + "TrackingResultEvaluation"), sensor=sensor)
+    gkey, gcands = S.gpu_keyframes(capi, Cn, synth, 640, 480, n_cand, getattr(Cn, kind + "TrackingResultEvaluation"), sensor=sensor)
     assert abs(gkey.evaluation.average - okey.evaluation.average) <= 1e-4 * abs(okey.evaluation.average)
 
     notes = []
     images = {k.id: k.image for k in [okey] + ocands}
+    ceiling = fork_criterion.SENSOR_REGIME_CEILING if sensor else None
 
     def run(thresholds, stages=2):
         ov = V.create_constraint_proposal_validator(**thresholds)
@@ -264,7 +277,7 @@ def test_gpu_validator_equals_oracle(orc, V, synth, kind):
         ov.images = images
         o = ov.validate(V.proposals_for_candidates(okey, ocands))
         g = gv.validate(Cn.proposalsForCandidates(gkey, gcands))
-        worst = _compare(orc, synth, ov, g, o, notes)
+        worst = _compare(orc, synth, ov, g, o, notes, ceiling)
         return o, worst
 
     # (1) stage 1 alone, nothing rejected by a ratio: the observed coarse ratios give a threshold that splits the proposals
@@ -292,10 +305,12 @@ def test_gpu_validator_equals_oracle(orc, V, synth, kind):
         ov.stages, gv.stages = ov.stages[1:], gv.stages[1:]
         ov.images = images
         return gv, ov
-    _, _, worst2 = _teacher_forced_second_stage(orc, synth, Cn, V, second_stage_only, o1, gkf, okf, notes)
-    print(f"[validator {kind}] second stage, teacher-forced: worst pose error vs the oracle's alignment of the same proposal {worst2:.2e}")
+    _, _, worst2 = _teacher_forced_second_stage(orc, synth, Cn, V, second_stage_only, o1, gkf, okf, notes, ceiling)
+    regime = "sensor regime" if sensor else "analytic regime"
+    print(f"[validator {kind}, {regime}] second stage, teacher-forced: worst pose error vs the oracle's alignment of the same proposal "
+          f"{worst2:.2e}; {len(notes)} alignments beyond 1e-5 (each within the oracle's own re-association distance)")
     for n in notes:
-        print("[validator fork]", n)
+        print(f"[validator fork, {regime}]", n)
 
 
 @pytest.mark.gpu
