@@ -519,7 +519,29 @@ def main():
                         "what": "the timed region's pair list on sensor-realistic input: the same views as 8-bit grey + uint16 "
                                 "depth at 1/5000 m with hashed Gaussian depth noise sigma_z(z) = 0.0012 + 0.0019 (z - 0.4)^2 and "
                                 "1.5 grey levels of intensity noise, ingested on the device; same trackers, same residency"}
+            def host_rcpps():
+                # the opt-in reciprocal mode that reproduces the host's _mm_rcp_ps bit for bit (dense_tracking_impl.cpp:192,700)
+                # from a table: the timed region's workload once more with it switched on, and what it costs
+                for t_ in trackers:
+                    t_.set_reciprocal_mode("host_sse")
+                try:
+                    run_steps(1, [])
+                    n = max(2, args.steps // 2)
+                    tally = []
+                    t0 = time.perf_counter()
+                    run_steps(n, tally)
+                    dt = time.perf_counter() - t0
+                    return {"value": B * n / dt, "unit": "frame-pairs/s", "steps": n,
+                            "relative_to_the_default_mode": (B * n / dt) / value,
+                            "iterations_per_pair": sum(c[3] for c in tally) / (B * n),
+                            "table_mantissa_bits": trackers[0].reciprocal_mode()[1],
+                            "what": "dvo_amd_set_reciprocal_mode(DVO_AMD_RCP_HOST_SSE): 1 / z of the projection and the reciprocal of "
+                                    "the t-distribution weights are this host's _mm_rcp_ps from a device-resident table"}
+                finally:
+                    for t_ in trackers:
+                        t_.set_reciprocal_mode("exact")
             for name, fn in (("sensor_noise_workload", sensor_noise),
+                             ("host_rcpps_mode", host_rcpps),
                              ("cache_resident_workload", cache_resident),
                              ("no_stats_variant", lambda: stats_variant(run_steps, B, args, with_stats)),
                              ("stream_copy", lambda: stream_copy(device)),

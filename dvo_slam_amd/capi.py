@@ -34,6 +34,7 @@ EXPORTS = [
     "dvo_amd_format_trajectory_line", "dvo_amd_debug_tick_log", "dvo_amd_debug_iteration", "dvo_amd_match_selection", "dvo_amd_bench_residual_pass_pairs",
     "dvo_amd_exchange_create", "dvo_amd_exchange_attach", "dvo_amd_exchange_destroy",
     "dvo_amd_match_submit", "dvo_amd_match_wait", "dvo_amd_match_poll", "dvo_amd_debug_next_seq",
+    "dvo_amd_set_reciprocal_mode", "dvo_amd_get_reciprocal_mode", "dvo_amd_debug_rcp",
 ]
 
 
@@ -131,6 +132,9 @@ def lib():
     L.dvo_amd_context_destroy.restype = None
     L.dvo_amd_configure.argtypes = [vp, C.POINTER(CConfig)]
     L.dvo_amd_get_config.argtypes = [vp, C.POINTER(CConfig)]
+    L.dvo_amd_set_reciprocal_mode.argtypes = [vp, C.c_int]
+    L.dvo_amd_get_reciprocal_mode.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.dvo_amd_debug_rcp.argtypes = [vp, C.c_int, fp, fp]
     L.dvo_amd_pyramid_create.argtypes = [C.c_int, fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
                                          C.c_float, C.c_int, C.c_double, C.POINTER(vp)]
     L.dvo_amd_pyramid_create_from_device.argtypes = [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
@@ -404,6 +408,24 @@ class DenseTracker:
 
     def configuration(self) -> Config:
         return self._cfg
+
+    def set_reciprocal_mode(self, mode: str):
+        """"exact" (default): 1 / z of the projection is the exactly truncated quotient; "host_sse": the warp stage and the
+        t-distribution weights use THIS HOST's _mm_rcp_ps bit for bit, from a table probed on the host (dvo_amd_set_reciprocal_mode)"""
+        _check(lib().dvo_amd_set_reciprocal_mode(self._h, {"exact": 0, "host_sse": 1}[mode]), "dvo_amd_set_reciprocal_mode")
+
+    def reciprocal_mode(self):
+        """(mode name, mantissa bits the host's rcpps table is indexed by -- 0 in the exact mode)"""
+        m, k = C.c_int(), C.c_int()
+        _check(lib().dvo_amd_get_reciprocal_mode(self._h, C.byref(m), C.byref(k)), "dvo_amd_get_reciprocal_mode")
+        return ("host_sse" if m.value else "exact"), k.value
+
+    def table_rcp(self, x) -> np.ndarray:
+        """the table reciprocal of every element as the kernels compute it (test entry; needs the host_sse mode)"""
+        a = np.ascontiguousarray(x, dtype=np.float32).ravel()
+        out = np.empty_like(a)
+        _check(lib().dvo_amd_debug_rcp(self._h, a.size, _fp(a), _fp(out)), "dvo_amd_debug_rcp")
+        return out.reshape(np.shape(x))
 
     def configure(self, config: Config):
         c = config._c()

@@ -101,6 +101,19 @@ __device__ __forceinline__ float rcp_toward_zero(float z) {
   return __builtin_copysignf(u2f(up_fits ? up : lo), z);
 }
 
+// The host's _mm_rcp_ps (opt-in, dvo_amd_set_reciprocal_mode): rcpps(x) = rcpps(1.m) 2^-e exactly, rcpps(1.m) a function of the
+// top mantissa bits only -- both probed on the host when the mode is switched on, together with the special cases: zero and
+// denormal input give infinity, a result below the normal range is flushed to zero, infinity gives zero, NaN stays NaN (quiet).
+__device__ __forceinline__ float rcp_host_table(float z, const RcpTable &rcp) {
+  const unsigned u = f2u(z), au = u & 0x7fffffffu, e = au >> 23, m = au & 0x7fffffu;
+  const unsigned t = ((const __attribute__((address_space(1))) unsigned *)rcp.table)[m >> rcp.shift];
+  const int re = (int)(t >> 23) - ((int)e - 127);  // exponent field of the result
+  unsigned r = re >= 1 ? (((unsigned)re << 23) | (t & 0x7fffffu)) : 0u;
+  r = e == 0u ? 0x7f800000u : r;
+  r = e == 255u ? (m ? (au | 0x00400000u) : 0u) : r;
+  return u2f(r | (u & 0x80000000u));
+}
+
 // Pointers read from a descriptor in memory are generic ("flat") to the compiler; flat loads are slower and cannot be
 // counted separately from LDS traffic.  Everything the kernels touch lives in device global memory: say so.
 #define DVO_GLOBAL __attribute__((address_space(1)))
@@ -129,6 +142,7 @@ struct LevelPairDesc {
   int *seg_prefix[2];
   int w, h;
   float wc[6], wr[4], ub_x, ub_y;
+  RcpTable rcp;  // (only read by the RCP = 1 kernels)
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -148,13 +162,14 @@ struct Gathered {
   v4f_a8 b0, b1;           // {Zx, Zy} pairs of the upper and lower row
 };
 
+template <int RCP>
 __device__ __forceinline__ Proj project_pixel_rtz(const float *kt, const LevelPairDesc &d, float x, float y, float z) {
   // hadd(hadd()) adds lanes (0,1) and (2,3) first (:178-188); the point's w is 1
   const float sx = (kt[0] * x + kt[1] * y) + (kt[2] * z + kt[3]);
   const float sy = (kt[4] * x + kt[5] * y) + (kt[6] * z + kt[7]);
   Proj p;
   p.sz = (kt[8] * x + kt[9] * y) + (kt[10] * z + kt[11]);
-  const float rz = rcp_toward_zero(p.sz);
+  const float rz = RCP ? rcp_host_table(p.sz, d.rcp) : rcp_toward_zero(p.sz);  // :192 (_mm_rcp_ps) / the exact quotient
   p.u = sx * rz, p.v = sy * rz;
   // 0 <= u <= w-2 and 0 <= v <= h-2 (:160-161,203); NaN compares false.  (Bitwise and: four compares and three scalar ands;
   // the short-circuit form compiles to an exec-masked region.)
@@ -243,7 +258,9 @@ typedef float v4acc __attribute__((ext_vector_type(4)));
 //        4 waves per SIMD (the 87-register form is capped at 2).
 // (Measured and removed in round 3, DESIGN.md section 10: the Gram matrix from 4x4-block MFMAs, a five-waves-per-SIMD build,
 // physical blocks walking several logical ones, item tables in device memory.)
-template <int ACC>
+// RCP 0 (default): 1 / z of the projection is the exactly truncated quotient, the t-distribution weight 7 v_rcp_f32(5 + d).
+// RCP 1 (dvo_amd_set_reciprocal_mode): both reciprocals are the host's _mm_rcp_ps, bit for bit (dense_tracking_impl.cpp:192,700).
+template <int ACC, int RCP>
 __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const int lb) {
   constexpr int kBufs = 2;
   const int lane = threadIdx.x & (kWave - 1);
@@ -344,7 +361,7 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
     float r0, r1, e2, e3, e4, e5;
     bool ok;
     {
-      const Proj p = project_pixel_rtz(kt, d, x, y, z);
+      const Proj p = project_pixel_rtz<RCP>(kt, d, x, y, z);
       Gathered g;
       if (DVO_ABLATE & 2) {
         const v4f c = {p.u, 1.5f, p.v, 0.25f};
@@ -391,7 +408,7 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
       const float t0 = __builtin_fmaf(r0, P0, r1 * P1);
       const float t1 = __builtin_fmaf(r0, P2, r1 * P3);
       const float dd = __builtin_fmaf(t0, r0, t1 * r1);
-      wgt = 7.0f * __builtin_amdgcn_rcpf(5.0f + dd);
+      wgt = 7.0f * (RCP ? rcp_host_table(5.0f + dd, d.rcp) : __builtin_amdgcn_rcpf(5.0f + dd));
     }
     wgt = ok ? wgt : 0.0f;
 
@@ -837,13 +854,14 @@ __device__ __forceinline__ LevelPairDesc load_desc(const TickItem &it) {
   return d;
 }
 
-template <int ACC>
-__device__ __forceinline__ void tick_body(const TickItem &it, const int bx) {
+template <int ACC, int RCP>
+__device__ __forceinline__ void tick_body(const TickItem &it, const RcpTable &rcp, const int bx) {
   const int rb = it.res_blocks;
   if (bx >= rb + it.ll_blocks) return;
-  const LevelPairDesc d = load_desc(it);
+  LevelPairDesc d = load_desc(it);
+  d.rcp = rcp;
   if (bx < rb)
-    residual_pass<ACC>(it, d, it.res_first + xcd_contiguous_block(bx, rb));
+    residual_pass<ACC, RCP>(it, d, it.res_first + xcd_contiguous_block(bx, rb));
   else
     loglik_pass(it, d, (int)it.ll_first + (bx - rb));
 }
@@ -868,18 +886,24 @@ __device__ __forceinline__ int tick_locate(const Args &args, int &bx) {
 
 // ACC 1 (default): Gram matrix on the matrix pipe, 4 waves per SIMD.  ACC 0 (DVO_AMD_ACCUM=valu): 87 fp32 registers per lane,
 // 2 waves per SIMD -- kept as the cross-check of the summation (tests/test_gpu_parity.py runs the parity suite's criterion under it).
-template <int ACC>
+template <int ACC, int RCP>
 __global__ __launch_bounds__(kBlockThreads, ACC == 0 ? 2 : 4) void k_tick(const TickArgs args) {
   int bx;
   const int idx = tick_locate(args, bx);
-  tick_body<ACC>(args.items[idx], bx);
+  tick_body<ACC, RCP>(args.items[idx], args.rcp, bx);
 }
 
 // the same kernel behind the small argument block of a tick of at most kMaxSmallItems pairs
+template <int RCP>
 __global__ __launch_bounds__(kBlockThreads, 4) void k_tick_small(const TickArgsSmall args) {
   int bx;
   const int idx = tick_locate(args, bx);
-  tick_body<1>(args.items[idx], bx);
+  tick_body<1, RCP>(args.items[idx], args.rcp, bx);
+}
+
+__global__ void k_rcp_table_probe(const RcpTable rcp, const float *__restrict__ in, float *__restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = rcp_host_table(in[i], rcp);
 }
 
 // DVO_AMD_LAUNCH_LOCK=1: a process-wide mutex around every kernel launch.  Only for profiled multi-thread runs: rocprofv3's
@@ -914,7 +938,8 @@ static int acc_mode() {
 }
 
 typedef void (*TickKernel)(const TickArgs);
-static TickKernel pick_tick_kernel() { return acc_mode() == 0 ? k_tick<0> : k_tick<1>; }
+// (the host-rcpps mode exists for the default accumulator only)
+static TickKernel pick_tick_kernel(bool rcp_table) { return rcp_table ? k_tick<1, 1> : acc_mode() == 0 ? k_tick<0, 0> : k_tick<1, 0>; }
 
 // A tick's items are at different pyramid levels: the two-dimensional grid (blocks of the largest item x items) launches
 // mostly blocks that return at once, and the dispatcher starts only ~4 of them per nanosecond.  When more than half of the
@@ -940,24 +965,26 @@ int tick_args_layout(TickArgs &args, int max_blocks) { return tick_args_layout_i
 int tick_args_layout(TickArgsSmall &args, int max_blocks) { return tick_args_layout_impl(args, max_blocks); }
 
 hipError_t launch_tick_small(const TickArgsSmall &args, int max_blocks, hipStream_t stream, hipEvent_t t_start, hipEvent_t t_stop) {
-  if (acc_mode() != 1) return hipErrorNotSupported;
+  if (acc_mode() != 1 && !args.rcp.table) return hipErrorNotSupported;
   if (args.n_items <= 0 || max_blocks <= 0) return hipSuccess;
   LaunchGuard guard;
   dim3 grid((unsigned)((max_blocks + 7) & ~7), (unsigned)args.n_items, 1);
   if (args.compact) grid = dim3((unsigned)args.group_first[args.n_items] * 8u, 1, 1);
   if (t_start && t_stop) {
     void *kargs[] = {const_cast<TickArgsSmall *>(&args)};
-    const hipError_t e = hipExtLaunchKernel(reinterpret_cast<const void *>(&k_tick_small), grid, dim3(kBlockThreads), kargs, 0, stream,
-                                            t_start, t_stop, 0);
+    const void *kernel = args.rcp.table ? reinterpret_cast<const void *>(&k_tick_small<1>) : reinterpret_cast<const void *>(&k_tick_small<0>);
+    const hipError_t e = hipExtLaunchKernel(kernel, grid, dim3(kBlockThreads), kargs, 0, stream, t_start, t_stop, 0);
     if (e != hipSuccess) return e;
+  } else if (args.rcp.table) {
+    hipLaunchKernelGGL(k_tick_small<1>, grid, dim3(kBlockThreads), 0, stream, args);
   } else {
-    hipLaunchKernelGGL(k_tick_small, grid, dim3(kBlockThreads), 0, stream, args);
+    hipLaunchKernelGGL(k_tick_small<0>, grid, dim3(kBlockThreads), 0, stream, args);
   }
   return hipGetLastError();
 }
 
 hipError_t launch_tick(const TickArgs &args, int max_blocks, hipStream_t stream, hipEvent_t t_start, hipEvent_t t_stop) {
-  TickKernel kernel = pick_tick_kernel();
+  TickKernel kernel = pick_tick_kernel(args.rcp.table != nullptr);
   if (args.n_items <= 0 || max_blocks <= 0) return hipSuccess;
   LaunchGuard guard;
   dim3 grid((unsigned)((max_blocks + 7) & ~7), (unsigned)args.n_items, 1);
@@ -1330,6 +1357,13 @@ __global__ __launch_bounds__(NT, NT == kFinThreadsBatch ? 5 : 1) void k_finalize
 // the same behind the small argument block of a tick of at most kMaxSmallItems pairs
 __global__ __launch_bounds__(kFinThreads) void k_finalize_small(const FinArgsSmall args) {
   finalize_block<kFinThreads, false>(args.items[blockIdx.x], args.pad == 0x57A3 && blockIdx.x == 0, nullptr, 0u);
+}
+
+hipError_t launch_rcp_table_probe(const RcpTable &rcp, const float *in, float *out, int n, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  LaunchGuard guard;
+  hipLaunchKernelGGL(k_rcp_table_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rcp, in, out, n);
+  return hipGetLastError();
 }
 
 hipError_t read_finalize_stamps(unsigned long long out[8]) {

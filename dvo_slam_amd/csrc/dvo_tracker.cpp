@@ -480,6 +480,8 @@ struct dvo_amd_context {
   ncclResult_t (*p_allgather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*p_comm_destroy)(ncclComm_t) = nullptr;
   unsigned tick_seq = 0;
+  RcpTable rcp = {nullptr, 0, 0};     // opt-in: the host's _mm_rcp_ps from a table (dvo_amd_set_reciprocal_mode); null = exact
+  unsigned *rcp_table_dev = nullptr;  // the device copy of the table (kept once built)
   unsigned *ovf_host = nullptr, *ovf_dev = nullptr;  // pinned word for the verdict of k_ll_overflow (rare path)
   long long ovf_checks = 0, ovf_hits = 0;            // how often the exact overflow check ran / said yes (diagnostic)
   // Wave-step counts OF A LEVEL (its pixels / 64) from which its wave segments take 2 / 4 / 8 / 16 steps: the geometry of a
@@ -1166,6 +1168,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
     const int n_here = (int)std::min(per, items.size() - first);
     ta.n_items = n_here;
     ta.compact = 0;
+    ta.rcp = ctx->rcp;
     int max_blocks = 0;
     for (int i = 0; i < n_here; ++i) {
       ta.items[i] = items[first + i];
@@ -1194,7 +1197,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
     if (ctx->small_args && n_launch == 1 && n_here <= kMaxSmallItems) {
       // a single match() or the two-pair front-end step: the same two kernels behind argument blocks a tenth the size
       TickArgsSmall ts;
-      ts.n_items = n_here, ts.compact = 0;
+      ts.n_items = n_here, ts.compact = 0, ts.rcp = ctx->rcp;
       for (int i = 0; i < kMaxSmallItems; ++i) ts.items[i] = ta.items[i < n_here ? i : 0];
       (void)tick_args_layout(ts, max_blocks);
       const hipError_t es = launch_tick_small(ts, max_blocks, st, t0, t1);
@@ -1611,6 +1614,7 @@ int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, i
   FinArgs fa;
   std::memset(&ta, 0, sizeof(ta));
   std::memset(&fa, 0, sizeof(fa));
+  ta.rcp = ctx->rcp;
   j.sub_ll = j.have_a, j.sub_res = j.have_b;
   if (j.have_b) {
     j.b.steps = steps_level, j.b.n_blocks = nb_level;
@@ -1791,6 +1795,83 @@ int match_one_banded(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_p
 
 }  // namespace
 
+// ---- the host's _mm_rcp_ps as a table (opt-in reciprocal mode) --------------------------------------------------------------
+// The reference forms 1 / z of the projection and the t-distribution weights with rcpps (dense_tracking_impl.cpp:192,700), a
+// ~12-bit approximation whose bits differ between CPU vendors.  What the instruction is ON THIS HOST is probed once: all 2^23
+// mantissas of [1, 2) give the smallest k such that rcpps(1.m) depends on the top k mantissa bits only (11 on the Xeons and
+// EPYCs probed so far: 2^11 entries; in the worst case k = 23 and the table is the function itself, 32 MB); a sample of
+// exponents confirms rcpps(x 2^e) = rcpps(x) 2^-e and the special cases the device code models (rcp_host_table in
+// dvo_kernels.hip).  If the host's instruction does not have that structure the mode is refused, with the reason.
+namespace {
+struct HostRcp {
+  int k = 0;
+  std::vector<uint32_t> table;
+  std::string problem;
+};
+inline uint32_t f32_bits(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  return u;
+}
+inline float f32_from(uint32_t u) {
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+inline uint32_t host_rcpps_bits(uint32_t x) { return f32_bits(_mm_cvtss_f32(_mm_rcp_ss(_mm_set_ss(f32_from(x))))); }
+// what rcp_host_table (device) computes, on the host: the model the probe checks the instruction against
+uint32_t rcp_model(const HostRcp &h, uint32_t u) {
+  const uint32_t au = u & 0x7fffffffu, e = au >> 23, m = au & 0x7fffffu;
+  const uint32_t t = h.table[m >> (23 - h.k)];
+  const int re = (int)(t >> 23) - ((int)e - 127);
+  uint32_t r = re >= 1 ? (((uint32_t)re << 23) | (t & 0x7fffffu)) : 0u;
+  r = e == 0u ? 0x7f800000u : r;
+  r = e == 255u ? (m ? (au | 0x00400000u) : 0u) : r;
+  return r | (u & 0x80000000u);
+}
+const HostRcp &host_rcp_table() {
+  static HostRcp h;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    std::vector<uint32_t> all((size_t)1 << 23);
+    for (uint32_t m = 0; m < (1u << 23); ++m) all[m] = host_rcpps_bits(0x3f800000u | m);
+    int k = 0;
+    for (k = 0; k <= 23; ++k) {  // smallest k such that the result is constant over every run of 2^(23-k) mantissas
+      bool ok = true;
+      const uint32_t span = 1u << (23 - k);
+      for (uint32_t base = 0; base < (1u << 23) && ok; base += span)
+        for (uint32_t lo = 1; lo < span; ++lo)
+          if (all[base + lo] != all[base]) {
+            ok = false;
+            break;
+          }
+      if (ok) break;
+    }
+    h.k = k;
+    h.table.resize((size_t)1 << k);
+    for (uint32_t i = 0; i < (1u << k); ++i) h.table[i] = all[(size_t)i << (23 - k)];
+    for (uint32_t t : h.table)
+      if ((t >> 23) != 126u && (t >> 23) != 127u) h.problem = "rcpps(1.m) left (0.5, 1]";
+    // the model against the instruction: every exponent x a stride of mantissas, both signs, and the special inputs
+    for (uint32_t e = 0; e <= 255 && h.problem.empty(); ++e)
+      for (uint32_t m = 0; m < (1u << 23); m += 9973u) {
+        const uint32_t x = (e << 23) | m;
+        for (int neg = 0; neg < 2; ++neg) {
+          const uint32_t sgn = neg ? 0x80000000u : 0u;
+          const uint32_t want = host_rcpps_bits(x | sgn), got = rcp_model(h, x | sgn);
+          const bool both_nan = (want & 0x7fffffffu) > 0x7f800000u && (got & 0x7fffffffu) > 0x7f800000u;
+          if (want != got && !both_nan) {
+            char buf[160];
+            std::snprintf(buf, sizeof(buf), "_mm_rcp_ps(0x%08x) = 0x%08x on this host, the table model gives 0x%08x", x | sgn, want, got);
+            h.problem = buf;
+          }
+        }
+      }
+  });
+  return h;
+}
+}  // namespace
+
 // ------------------------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------------------------
@@ -1886,6 +1967,14 @@ int dvo_amd_context_create(int device, const dvo_amd_config *cfg, dvo_amd_contex
     const int v = atoi(lm);
     if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ctx->ll_merge = v;
   }
+  if (const char *rm = getenv("DVO_AMD_RCP"))  // DVO_AMD_RCP=host: every new tracker starts in the host-rcpps mode
+    if (rm[0] == 'h' || rm[0] == 'H' || rm[0] == 's' || rm[0] == 'S') {
+      const int rrc = dvo_amd_set_reciprocal_mode(ctx, DVO_AMD_RCP_HOST_SSE);
+      if (rrc) {
+        dvo_amd_context_destroy(ctx);
+        return rrc;
+      }
+    }
   if (const char *ipl = getenv("DVO_AMD_ITEMS_PER_LAUNCH")) {
     const int v = atoi(ipl);
     if (v >= 1 && v <= kMaxItemsPerLaunch) ctx->items_per_launch = v;
@@ -1923,6 +2012,7 @@ void dvo_amd_context_destroy(dvo_amd_context *ctx) {
   release_slots(ctx);
   if (ctx->out_wire) (void)hipHostFree(ctx->out_wire);
   if (ctx->ovf_host) (void)hipHostFree(ctx->ovf_host);
+  if (ctx->rcp_table_dev) (void)hipFree(ctx->rcp_table_dev);
   for (auto &ev : ctx->events) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
@@ -1940,6 +2030,56 @@ int dvo_amd_configure(dvo_amd_context *ctx, const dvo_amd_config *cfg) {
     return DVO_AMD_ERR_INVALID_ARGUMENT;
   }
   ctx->cfg = *cfg;
+  return DVO_AMD_OK;
+}
+
+int dvo_amd_set_reciprocal_mode(dvo_amd_context *ctx, int mode) {
+  if (!ctx || (mode != DVO_AMD_RCP_EXACT && mode != DVO_AMD_RCP_HOST_SSE)) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  int rc = queue_must_be_idle(ctx, "dvo_amd_set_reciprocal_mode");
+  if (rc) return rc;
+  if (mode == DVO_AMD_RCP_EXACT) {
+    ctx->rcp = RcpTable{nullptr, 0, 0};
+    return DVO_AMD_OK;
+  }
+  const HostRcp &h = host_rcp_table();
+  if (!h.problem.empty()) {
+    g_last_error = "the host's _mm_rcp_ps cannot be reproduced from a table: " + h.problem;
+    return DVO_AMD_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (!ctx->rcp_table_dev) {
+    HIP_TRY(hipMalloc((void **)&ctx->rcp_table_dev, sizeof(uint32_t) * h.table.size()));
+    HIP_TRY(hipMemcpy(ctx->rcp_table_dev, h.table.data(), sizeof(uint32_t) * h.table.size(), hipMemcpyHostToDevice));
+  }
+  ctx->rcp = RcpTable{ctx->rcp_table_dev, 23 - h.k, 0};
+  return DVO_AMD_OK;
+}
+
+int dvo_amd_get_reciprocal_mode(const dvo_amd_context *ctx, int *mode, int *table_mantissa_bits) {
+  if (!ctx) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  if (mode) *mode = ctx->rcp.table ? DVO_AMD_RCP_HOST_SSE : DVO_AMD_RCP_EXACT;
+  if (table_mantissa_bits) *table_mantissa_bits = ctx->rcp.table ? 23 - ctx->rcp.shift : 0;
+  return DVO_AMD_OK;
+}
+
+int dvo_amd_debug_rcp(dvo_amd_context *ctx, int n, const float *in, float *out) {
+  if (!ctx || n < 0 || (n > 0 && (!in || !out))) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  if (!ctx->rcp.table) {
+    g_last_error = "dvo_amd_debug_rcp: the host-rcpps mode is not on (dvo_amd_set_reciprocal_mode)";
+    return DVO_AMD_ERR_INVALID_ARGUMENT;
+  }
+  if (n == 0) return DVO_AMD_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  float *d_in = nullptr, *d_out = nullptr;
+  HIP_TRY(hipMalloc((void **)&d_in, sizeof(float) * (size_t)n));
+  hipError_t e = hipMalloc((void **)&d_out, sizeof(float) * (size_t)n);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_in, in, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = launch_rcp_table_probe(ctx->rcp, d_in, d_out, n, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  if (e != hipSuccess) return fail_hip("dvo_amd_debug_rcp", e);
   return DVO_AMD_OK;
 }
 
@@ -2410,6 +2550,7 @@ int single_tick(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyrami
   TickArgs ta;
   std::memset(&ta, 0, sizeof(ta));
   ta.n_items = 1;
+  ta.rcp = ctx->rcp;
   TickItem &w = ta.items[0];
   w.ref = sel->ref_desc + level;
   w.cur = current->cur_desc + level;
@@ -2602,6 +2743,7 @@ int dvo_amd_bench_residual_pass_pairs(dvo_amd_context *ctx, int n_items, dvo_amd
       TickArgs ta;
       ta.n_items = std::min(per, n_items - first);
       ta.compact = 0;
+      ta.rcp = ctx->rcp;
       for (int i = 0; i < ta.n_items; ++i) {
         TickItem &w = ta.items[i];
         w = proto;

@@ -152,15 +152,24 @@ constexpr unsigned kItemUnitWeights = 4;  // first iteration on a level: weights
 static_assert(sizeof(TickItem) == 104, "TickItem is packed to fit many items into one kernel-argument block");
 
 constexpr int kMaxItemsPerLaunch = 36;
+// Opt-in reciprocal mode (dvo_amd_set_reciprocal_mode): the HOST's _mm_rcp_ps, reproduced bit for bit from a table of
+// rcpps(1.m) indexed by the top mantissa bits that instruction looks at on this machine (probed when the mode is switched on,
+// csrc/dvo_tracker.cpp host_rcp_table).  table == nullptr: the default, exactly truncated quotient / v_rcp_f32.
+struct RcpTable {
+  const unsigned *table;  // device memory: bits of rcpps(1.m) for m = index << shift
+  int shift;              // 23 - (mantissa bits rcpps depends on)
+  int pad;
+};
 struct TickArgs {
   int n_items;
   int compact;  // 0: grid (blocks of the largest item, n_items); 1: one-dimensional grid without the blocks no item owns
+  RcpTable rcp;
   // compact grid: item i owns block groups [group_first[i], group_first[i + 1]) of 8 blocks each (its blocks start on a
   // multiple of 8, so that "blocks b and b + 8 share an XCD" holds inside every item)
   uint16_t group_first[kMaxItemsPerLaunch + 4];
   TickItem items[kMaxItemsPerLaunch];
 };
-static_assert(sizeof(TickArgs) <= 3900, "kernel argument block too large");
+static_assert(sizeof(TickArgs) <= 3950, "kernel argument block too large");
 
 // what the finalize kernel hands to the host for one job (lives in pinned host memory)
 struct FinOut {
@@ -245,6 +254,7 @@ constexpr int kMaxSmallItems = 8;
 struct TickArgsSmall {
   int n_items;
   int compact;
+  RcpTable rcp;
   uint16_t group_first[kMaxSmallItems + 4];
   TickItem items[kMaxSmallItems];
 };
@@ -280,6 +290,8 @@ hipError_t launch_ll_overflow(const float2 *res, const int *seg_prefix, int seg_
 // a Mahalanobis distance below this cannot make a group of fifty terms 1 + 0.2 q overflow a double (50 log2(1 + 0.2 q) < 1024)
 constexpr float kLlOverflowScreen = 7.0e6f;
 hipError_t read_finalize_stamps(unsigned long long out[8]);
+// out[i] = the table reciprocal of in[i] (device pointers): the unit test of the opt-in host-rcpps mode
+hipError_t launch_rcp_table_probe(const RcpTable &rcp, const float *in, float *out, int n, hipStream_t stream);
 
 // prep (pyramid construction) kernels
 hipError_t launch_pyr_down(const float *i_prev, const float *z_prev, int w_prev, float *i_out, float *z_out, int w, int h,

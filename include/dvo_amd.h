@@ -135,6 +135,23 @@ int dvo_amd_context_create(int device, const dvo_amd_config *cfg, dvo_amd_contex
 void dvo_amd_context_destroy(dvo_amd_context *ctx);
 /* the HIP device the context was created on */
 int dvo_amd_context_device(const dvo_amd_context *ctx, int *device);
+
+/* The reciprocal the warp stage and the t-distribution weights use (dense_tracking_impl.cpp:192,700: _mm_rcp_ps, a ~12-bit
+ * approximation whose bits differ between CPU vendors).
+ *   DVO_AMD_RCP_EXACT (default): 1 / z of the projection is the exactly truncated quotient, the weight's reciprocal is within
+ *     1 ulp: the same on every machine.
+ *   DVO_AMD_RCP_HOST_SSE: both are THIS HOST's _mm_rcp_ps, bit for bit, from a table probed on the host when the mode is
+ *     switched on (2^11 entries on the Xeons / EPYCs seen so far): residuals and validity decisions are then bit-identical to
+ *     the reference's SSE path as this host runs it.  (The reference uses an exact division for the last V mod 4 weights,
+ *     :702-706; here every weight uses the table.)  Returns DVO_AMD_ERR_INVALID_ARGUMENT with a reason in dvo_amd_last_error()
+ *     if the host's instruction does not have the structure the table assumes; refused while pairs are queued.
+ * DVO_AMD_RCP=host in the environment makes it the default of every new context. */
+#define DVO_AMD_RCP_EXACT 0
+#define DVO_AMD_RCP_HOST_SSE 1
+int dvo_amd_set_reciprocal_mode(dvo_amd_context *ctx, int mode);
+int dvo_amd_get_reciprocal_mode(const dvo_amd_context *ctx, int *mode, int *table_mantissa_bits);
+/* (test entry) out[i] = the table reciprocal of in[i] as the kernels compute it; needs DVO_AMD_RCP_HOST_SSE */
+int dvo_amd_debug_rcp(dvo_amd_context *ctx, int n, const float *in, float *out);
 int dvo_amd_configure(dvo_amd_context *ctx, const dvo_amd_config *cfg);
 int dvo_amd_get_config(const dvo_amd_context *ctx, dvo_amd_config *cfg);
 

@@ -260,6 +260,10 @@ const int *orc_select_index(orc_pyramid *p, int level, float ti, float td) {
 /* ------------------------------------------------------------------------------------------ */
 
 float orc_host_rcp(float x) { return _mm_cvtss_f32(_mm_rcp_ps(_mm_set1_ps(x))); }
+/* the same over an array: what _mm_rcp_ps (dense_tracking_impl.cpp:192,700) is on THIS host, for the tests of the GPU's table mode */
+void orc_host_rcp_many(const float *in, float *out, int n) {
+  for (int i = 0; i < n; ++i) out[i] = _mm_cvtss_f32(_mm_rcp_ss(_mm_set_ss(in[i])));
+}
 
 /* depthStdDevZ, dense_tracking_impl.cpp:122-128 */
 static inline float depth_sigma(float depth) {

@@ -172,6 +172,7 @@ int orc_iteration(orc_pyramid *ref, orc_pyramid *cur, int level, float ti, float
                   int unit_weights, int rcp_mode, float scale_out[4], float prec_out[4], float *ll_out, float A36[36],
                   float b6[6]);
 float orc_host_rcp(float x); /* _mm_rcp_ps lane 0 on this host */
+void orc_host_rcp_many(const float *in, float *out, int n);
 
 #ifdef __cplusplus
 }

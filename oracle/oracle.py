@@ -128,6 +128,8 @@ def lib():
         L.orc_iteration.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, fp, fp, C.c_int, C.c_int, fp, fp, fp, fp, fp]
         L.orc_host_rcp.restype = C.c_float
         L.orc_host_rcp.argtypes = [C.c_float]
+        L.orc_host_rcp_many.restype = None
+        L.orc_host_rcp_many.argtypes = [fp, fp, C.c_int]
         _lib = L
     return _lib
 
@@ -287,3 +289,11 @@ def ingest_gray(image):
     else:
         lib().orc_ingest_gray_from_gray8(ptr, w, h, w, _fp(out))
     return out
+
+
+def host_rcp(x) -> np.ndarray:
+    """_mm_rcp_ps of every element on THIS host (float32 in, float32 out)"""
+    a = np.ascontiguousarray(x, dtype=np.float32).ravel()
+    out = np.empty_like(a)
+    lib().orc_host_rcp_many(_fp(a), _fp(out), a.size)
+    return out.reshape(np.shape(x))

@@ -1,0 +1,158 @@
+"""The opt-in reciprocal mode that reproduces the HOST's _mm_rcp_ps (SURVEY Q8 and the body of Q7).
+
+The reference forms 1 / z of the projection (dvo_core/src/dense_tracking_impl.cpp:192) and the t-distribution weights (:700)
+with rcpps, a ~12-bit approximation whose bits differ between CPU vendors.  By default the HIP path uses the exactly truncated
+quotient (the same on every machine); with dvo_amd_set_reciprocal_mode(DVO_AMD_RCP_HOST_SSE) it uses a table of rcpps(1.m)
+probed on the host it runs on.  Checked here against the oracle's RCP_SSE mode, which executes the real instruction:
+
+  * the table reciprocal == _mm_rcp_ps on this host, bit for bit, for every class of input;
+  * residuals and validity decisions bit-exact at every level;
+  * match(): same-path poses <= 1e-5, forks under the self-distance rule; the three flavours of "the reference SSE path"
+    (portable oracle with rcpps, natively built FMA-contracting oracle with rcpps, exact-reciprocal oracle) on one line.
+"""
+import numpy as np
+import pytest
+
+import fork_criterion
+import test_gpu_parity as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from dvo_slam_amd import capi as c
+
+    if c.lib().dvo_amd_device_count() < 1:
+        pytest.fail("no HIP device visible: the gpu tests must run on the MI355X box")
+    return c
+
+
+@pytest.fixture(scope="module")
+def pair(capi, orc, synth):
+    (Ir, Zr), (Ic, Zc), Tgt = synth.make_pair(640, 480)
+    K = synth.intrinsics_for(640, 480)
+    return dict(gr=capi.RgbdImagePyramid(Ir, Zr, K, 4), gc=capi.RgbdImagePyramid(Ic, Zc, K, 4),
+                orr=orc.Pyramid(Ir, Zr, K, 4), occ=orc.Pyramid(Ic, Zc, K, 4), Tgt=Tgt, K=K, frames=((Ir, Zr), (Ic, Zc)))
+
+
+def _tracker(capi, **cfg):
+    trk = capi.DenseTracker(capi.Config(**cfg))
+    trk.set_reciprocal_mode("host_sse")
+    return trk
+
+
+def test_table_reciprocal_is_the_hosts_rcpps_bit_for_bit(capi, orc):
+    trk = _tracker(capi, FirstLevel=3, LastLevel=0)
+    mode, k = trk.reciprocal_mode()
+    assert mode == "host_sse" and 8 <= k <= 23
+    print(f"\n[rcpps] this host's _mm_rcp_ps depends on the top {k} mantissa bits: a table of {1 << k} entries ({(4 << k) / 1024:.0f} KiB)")
+    rng = np.random.default_rng(20131103)
+    cases = [rng.integers(0, 2**32, size=2_000_000, dtype=np.uint64).astype(np.uint32),              # every exponent, both signs
+             (np.uint32(0x3f800000) + np.arange(1 << 23, dtype=np.uint32)[:: 7]),                    # a dense sweep of [1, 2)
+             (np.uint32(0x40000000) + rng.integers(0, 1 << 23, size=300_000).astype(np.uint32)),     # depths of 2 .. 4 m
+             np.array([0x00000000, 0x80000000, 0x00000001, 0x007fffff, 0x00800000, 0x807fffff, 0x7e800000, 0x7e7fffff, 0x7e800001,
+                       0x7f000000, 0x7f7fffff, 0x7f800000, 0xff800000, 0x7fc00000, 0x7f800001, 0xffc12345, 0x3f800000, 0x3f7fffff,
+                       0xbf800000, 0x40a00000], dtype=np.uint32)]
+    for bits in cases:
+        x = bits.view(np.float32)
+        want, got = orc.host_rcp(x).view(np.uint32), trk.table_rcp(x).view(np.uint32)
+        nan = np.isnan(x)
+        assert np.array_equal(want[~nan], got[~nan])
+        assert np.isnan(got.view(np.float32)[nan]).all()  # NaN in, NaN out (the kernels only ask whether it is one)
+    # the exact mode is the default and has no table
+    plain = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0))
+    assert plain.reciprocal_mode() == ("exact", 0)
+    with pytest.raises(capi.DvoAmdError):
+        plain.table_rcp(np.ones(4, np.float32))
+
+
+def _oracle_residual_image(orc, orr, occ, level, T, shape, mode):
+    pe, r, valid = orc.compute_residuals(orr, occ, level, T, mode)
+    rec, idx = orr.select(level)
+    img = np.full((shape[0] * shape[1], 2), np.nan, np.float32)
+    img[idx[: len(valid)][valid.astype(bool)]] = r
+    return img.reshape(shape[0], shape[1], 2), len(r)
+
+
+@pytest.mark.parametrize("level", [3, 2, 1, 0])
+def test_residuals_bit_exact_against_the_oracles_rcpps_mode(capi, orc, synth, pair, level):
+    trk = _tracker(capi, FirstLevel=3, LastLevel=0)
+    odd = synth.se3_exp([0.05, -0.08, 0.1, 0.03, -0.02, 0.04])
+    differs_from_exact = 0
+    for T in (np.eye(4), pair["Tgt"], np.linalg.inv(pair["Tgt"]), odd):
+        g, n_gpu = trk.residuals(pair["gr"], pair["gc"], level, T)
+        o, n_orc = _oracle_residual_image(orc, pair["orr"], pair["occ"], level, T, g.shape[:2], orc.RCP_SSE)
+        assert n_gpu == n_orc
+        assert np.array_equal(np.isnan(g), np.isnan(o))
+        m = ~np.isnan(g)
+        assert np.array_equal(P._bits(g[m]), P._bits(o[m]))
+        e, _ = _oracle_residual_image(orc, pair["orr"], pair["occ"], level, T, g.shape[:2], orc.RCP_EXACT)
+        both = m & ~np.isnan(e)
+        differs_from_exact += int((P._bits(g[both]) != P._bits(e[both])).sum())
+    assert differs_from_exact > 0  # (the two reciprocals are different functions: the mode is really on)
+
+
+def test_match_against_the_three_flavours_of_the_reference_sse_path(capi, orc, synth, pair, capsys):
+    """GPU in the host-rcpps mode against the oracle running the real instruction: same path -> 1e-5 (dense_tracking_impl.cpp
+    :192,:700), a fork -> the self-distance rule.  And on one line: how far the flavours of "the reference SSE path" are from
+    each other on this host -- portable build with rcpps, natively built (-O3 -march=native: contracts a*b+c into fma like the
+    reference's own flags do, dvo_core/CMakeLists.txt:40-42) with rcpps, exact reciprocal."""
+    lines = []
+    for label, (gr, gc, orr, occ), cfg in (("headline pair", (pair["gr"], pair["gc"], pair["orr"], pair["occ"]), dict(FirstLevel=3, LastLevel=0)),
+                                          ("swapped roles", (pair["gc"], pair["gr"], pair["occ"], pair["orr"]), dict(FirstLevel=3, LastLevel=0)),
+                                          ("reference default levels", (pair["gr"], pair["gc"], pair["orr"], pair["occ"]), dict(FirstLevel=3, LastLevel=1))):
+        g_sse = _tracker(capi, **cfg).match(gr, gc)
+        g_exact = capi.DenseTracker(capi.Config(**cfg)).match(gr, gc)
+        ocfg = lambda mode: orc.default_config(first_level=cfg["FirstLevel"], last_level=cfg["LastLevel"], rcp_mode=mode)  # noqa: E731
+        o_sse, o_exact = orc.match(ocfg(orc.RCP_SSE), orr, occ), orc.match(ocfg(orc.RCP_EXACT), orr, occ)
+        err = synth.pose_error(o_sse["T"], g_sse.Transformation)
+        same_path = all(Lg["TerminationCriterion"] == Lo["termination"] and len(Lg["Iterations"]) == len(Lo["iterations"])
+                        for Lg, Lo in zip(g_sse.Levels, o_sse["levels"]))
+        bar, note = (P.POSE_TOL, None) if same_path else fork_criterion.pose_bar(orc, synth, ocfg(orc.RCP_SSE), orr, occ, None, o_sse, err, P.POSE_TOL)
+        assert err <= bar, (label, err, bar, note)
+        # first iteration of the first level: identical inputs, identical reciprocal -> identical constraint count
+        assert g_sse.Levels[0]["Iterations"][0]["ValidConstraints"] == o_sse["levels"][0]["iterations"][0]["valid_constraints"]
+        lines.append(f"[rcpps] {label}: GPU(host rcpps) vs oracle(rcpps) {err:.2e} ({'same path' if same_path else 'forked, ' + (note or 'within 1e-5')}); "
+                     f"GPU(exact) vs oracle(exact) {synth.pose_error(o_exact['T'], g_exact.Transformation):.2e}; "
+                     f"oracle(rcpps) vs oracle(exact) {synth.pose_error(o_sse['T'], o_exact['T']):.2e}; "
+                     f"GPU(exact) vs oracle(rcpps) {synth.pose_error(o_sse['T'], g_exact.Transformation):.2e}")
+    # the natively built oracle (fma contraction): objects of one build must not be used under the other
+    (Ir, Zr), (Ic, Zc) = pair["frames"]
+    try:
+        orc.select_build("native")
+        n_r, n_c = orc.Pyramid(Ir, Zr, pair["K"], 4), orc.Pyramid(Ic, Zc, pair["K"], 4)
+        n_sse = orc.match(orc.default_config(first_level=3, last_level=0, rcp_mode=orc.RCP_SSE), n_r, n_c)
+        n_exact = orc.match(orc.default_config(first_level=3, last_level=0, rcp_mode=orc.RCP_EXACT), n_r, n_c)
+        del n_r, n_c
+    finally:
+        orc.select_build("parity")
+    g_sse = _tracker(capi, FirstLevel=3, LastLevel=0).match(pair["gr"], pair["gc"])
+    g_exact = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0)).match(pair["gr"], pair["gc"])
+    o_sse = orc.match(orc.default_config(first_level=3, last_level=0, rcp_mode=orc.RCP_SSE), pair["orr"], pair["occ"])
+    lines.append(f"[rcpps] headline pair, the natively built oracle (-O3 -march=native, fma-contracting): vs the portable oracle "
+                 f"(both rcpps) {synth.pose_error(o_sse['T'], n_sse['T']):.2e}; GPU(host rcpps) vs native(rcpps) "
+                 f"{synth.pose_error(n_sse['T'], g_sse.Transformation):.2e}; GPU(exact) vs native(exact) "
+                 f"{synth.pose_error(n_exact['T'], g_exact.Transformation):.2e}; GPU(exact) vs native(rcpps) "
+                 f"{synth.pose_error(n_sse['T'], g_exact.Transformation):.2e}")
+    with capsys.disabled():
+        print()
+        for ln in lines:
+            print(ln)
+
+
+def test_mode_is_per_tracker_deterministic_and_refused_while_queued(capi, synth, pair):
+    a, b = _tracker(capi, FirstLevel=3, LastLevel=0), _tracker(capi, FirstLevel=3, LastLevel=0)
+    ra = a.match(pair["gr"], pair["gc"])
+    out = b.match_batch([pair["gr"]] * 20, [pair["gc"]] * 20, in_flight=12)
+    assert all(np.array_equal(ra.Transformation, r.Transformation) for r in out)  # a function of the inputs in this mode too
+    assert np.array_equal(a.match_banded(pair["gr"], pair["gc"], 4).Transformation, ra.Transformation)
+    plain = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0)).match(pair["gr"], pair["gc"])
+    assert not np.array_equal(plain.Transformation, ra.Transformation)
+    assert synth.pose_error(plain.Transformation, ra.Transformation) < 3e-4
+    sub = b.submit([pair["gr"]] * 30, [pair["gc"]] * 30, in_flight=10)
+    with pytest.raises(capi.DvoAmdError):
+        b.set_reciprocal_mode("exact")
+    b.wait(sub)
+    b.set_reciprocal_mode("exact")
+    assert np.array_equal(b.match(pair["gr"], pair["gc"]).Transformation, plain.Transformation)
