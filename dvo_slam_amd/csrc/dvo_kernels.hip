@@ -778,7 +778,7 @@ __device__ void loglik_pass(const TickItem &it, const LevelPairDesc &d, const in
 constexpr int kOvfGroups = 64, kOvfWindow = kOvfGroups * 50;
 __global__ __launch_bounds__(kWave) void k_ll_overflow(const float2 *__restrict__ res, const int *__restrict__ seg_prefix, int seg_first,
                                                        int n_segs, int segs_per_block, int seg_px, int rank_offset, int n_px,
-                                                       int cut_rank, float P0, float P1, float P2, float P3,
+                                                       int cut_rank, int rank_end, float P0, float P1, float P2, float P3,
                                                        unsigned *__restrict__ result_host) {
   __shared__ double terms[kOvfWindow + kWave];
   const int lane = threadIdx.x;
@@ -787,9 +787,15 @@ __global__ __launch_bounds__(kWave) void k_ll_overflow(const float2 *__restrict_
   const int s1 = s0 + segs_per_block < seg_first + n_segs ? s0 + segs_per_block : seg_first + n_segs;
   const int a = rank_offset + seg_prefix[s0];                        // global rank of the chunk's first valid pixel
   // rank of the first valid pixel BEHIND the chunk (only the chunk's own segments are known to hold this pass's residuals)
-  const int e = s1 < seg_first + n_segs ? rank_offset + seg_prefix[s1] : 0x7fffffff;
+  // rank_end >= 0: the band is CLOSED -- the residuals behind it live on another GPU -- and rank_end is the rank of the first
+  // valid pixel behind it: the band's last chunk then stops at the last group that ends inside the band (the group that
+  // straddles the edge is settled by the host from the ranks' edge records, dvo_tracker.cpp: sharded_overflow)
+  const bool last_chunk = s1 >= seg_first + n_segs;
+  const int e = !last_chunk ? rank_offset + seg_prefix[s1] : (rank_end >= 0 ? rank_end : 0x7fffffff);
   const int first = a + (50 - a % 50) % 50;                          // first group that starts in the chunk
-  const int stop = e < cut_rank ? e + (50 - e % 50) % 50 : cut_rank; // ... and the end of the last one (cut_rank is a multiple of 50)
+  const int stop = e >= cut_rank ? cut_rank                          // (cut_rank is a multiple of 50)
+                   : (last_chunk && rank_end >= 0) ? e - e % 50      // closed band: complete groups only
+                                                   : e + (50 - e % 50) % 50;  // ... else the end of the group that straddles the chunk's end
   if (first >= stop) return;
   int run = a, base = first;  // rank of the next valid pixel; rank of terms[0]
   bool overflow = false;
@@ -1359,6 +1365,29 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize_small(const FinArgsSma
   finalize_block<kFinThreads, false>(args.items[blockIdx.x], args.pad == 0x57A3 && blockIdx.x == 0, nullptr, 0u);
 }
 
+// The one-hop exchange of a ready-made record (device memory): the rare second exchange of a tick of a tile-sharded pair -- the
+// band-edge terms of the reference's 50-term likelihood products (dvo_tracker.cpp: sharded_overflow) travel as a FinOut-shaped
+// record through the same mapped buffers, tags and generations as the tick records do.
+__global__ __launch_bounds__(kFinThreadsBatch) void k_exchange_record(const FinOut *__restrict__ rec, const ExchangeArgs *exchange, unsigned xseq) {
+  __shared__ __attribute__((aligned(16))) FinOut sh_out;
+  __shared__ int sh_bad;
+  const int t = threadIdx.x;
+  if (t < (int)(sizeof(FinOut) / 16)) reinterpret_cast<v4f *>(&sh_out)[t] = reinterpret_cast<const v4f *>(rec)[t];
+  if (t == 0) sh_bad = 0;
+  __syncthreads();
+  if (!exchange_records(exchange, reinterpret_cast<const unsigned *>(&sh_out), xseq, t >> 6, kFinThreadsBatch / kWave, t & (kWave - 1)))
+    atomicOr(&sh_bad, 1);
+  __syncthreads();
+  if (t == 0 && sh_bad)
+    __hip_atomic_store(((const DVO_CONST ExchangeArgs *)exchange)->host_seq, xseq | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+hipError_t launch_exchange_record(const FinOut *rec_dev, const ExchangeArgs *exchange_dev, unsigned xseq, hipStream_t stream) {
+  LaunchGuard guard;
+  hipLaunchKernelGGL(k_exchange_record, dim3(1), dim3(kFinThreadsBatch), 0, stream, rec_dev, exchange_dev, xseq);
+  return hipGetLastError();
+}
+
 hipError_t launch_rcp_table_probe(const RcpTable &rcp, const float *in, float *out, int n, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
   LaunchGuard guard;
@@ -1390,12 +1419,12 @@ hipError_t launch_finalize(const FinArgs &args, hipStream_t stream) {
 }
 
 hipError_t launch_ll_overflow(const float2 *res, const int *seg_prefix, int seg_first, int n_segs, int seg_px, int rank_offset,
-                              int n_px, int cut_rank, const float P[4], unsigned *result_host, hipStream_t stream) {
+                              int n_px, int cut_rank, int rank_end, const float P[4], unsigned *result_host, hipStream_t stream) {
   if (n_segs <= 0) return hipSuccess;
   LaunchGuard guard;
   const int segs_per_block = 8;
   hipLaunchKernelGGL(k_ll_overflow, dim3((unsigned)((n_segs + segs_per_block - 1) / segs_per_block)), dim3(kWave), 0, stream, res,
-                     seg_prefix, seg_first, n_segs, segs_per_block, seg_px, rank_offset, n_px, cut_rank, P[0], P[1], P[2], P[3],
+                     seg_prefix, seg_first, n_segs, segs_per_block, seg_px, rank_offset, n_px, cut_rank, rank_end, P[0], P[1], P[2], P[3],
                      result_host);
   return hipGetLastError();
 }

@@ -1236,8 +1236,9 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
 // r^T P r it saw; only when a group of fifty COULD have overflowed (kLlOverflowScreen) this asks k_ll_overflow, which redoes
 // the reference's own multiplications group by group over the iteration's residual buffer (still intact: the next residual pass
 // wrote the other one).  Blocking and slow (0.2 ms for a 640x480 level), and rare: never on sensor data.
-struct OvfBand {  // a band of the residual pass: wave segments [seg_first, seg_first + n_segs), valid pixels in earlier bands
-  int seg_first, n_segs, rank_offset;
+struct OvfBand {  // a band of the residual pass: wave segments [seg_first, seg_first + n_segs), valid pixels in earlier bands;
+  int seg_first, n_segs, rank_offset;  // rank_end >= 0: a closed band (its successor lives on another GPU), see launch_ll_overflow
+  int rank_end = -1;
 };
 int ll_overflowed(dvo_amd_context *ctx, const float2 *res, const int *seg_prefix, int n_blocks, int steps, int cut_rank,
                   const float P[4], const OvfBand *bands, int n_bands, bool *overflowed) {
@@ -1249,11 +1250,12 @@ int ll_overflowed(dvo_amd_context *ctx, const float2 *res, const int *seg_prefix
   }
   __atomic_store_n(ctx->ovf_host, 0u, __ATOMIC_RELEASE);
   const int seg_px = kStepPx * steps, n_px = n_blocks * kWavesPerBlock * seg_px;
-  const OvfBand whole = {0, n_blocks * kWavesPerBlock, 0};
+  OvfBand whole;
+  whole.seg_first = 0, whole.n_segs = n_blocks * kWavesPerBlock, whole.rank_offset = 0;
   for (int b = 0; b < (bands ? n_bands : 1); ++b) {
     const OvfBand &B = bands ? bands[b] : whole;
-    hipError_t e = launch_ll_overflow(res, seg_prefix, B.seg_first, B.n_segs, seg_px, B.rank_offset, n_px, cut_rank, P, ctx->ovf_dev,
-                                      ctx->stream);
+    hipError_t e = launch_ll_overflow(res, seg_prefix, B.seg_first, B.n_segs, seg_px, B.rank_offset, n_px, cut_rank, B.rank_end, P,
+                                      ctx->ovf_dev, ctx->stream);
     if (e != hipSuccess) return fail_hip("launch_ll_overflow", e);
   }
   HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1604,6 +1606,161 @@ void combine_bands(const FinOut *const *recs, int n, FinOut &out) {
   out.ll_sum = ll[0];
 }
 
+// The records of all bands of the tick (or of the overflow exchange) that was just launched on a tile-sharded pair, in band
+// order.  Peer exchange attached: the kernel that carried x_seq pushed this rank's record into every peer's mapped buffer and
+// forwards theirs to pinned host memory, which is polled here (no collective, no copy, no stream synchronisation).  Otherwise
+// the RCCL all-gather of slot 0's device record + one D2H copy.
+int collect_exchange(dvo_amd_context *ctx, int n_bands, const FinOut **recs) {
+  if (ctx->x_ranks > 0) {
+    const unsigned xseq = ctx->x_seq;  // the kernel of this exchange carried it (set before the launch)
+    for (int b = 0; b < n_bands; ++b) {
+      unsigned long long spins = 0;
+      int have = 0;
+      while ((have = take_wire(ctx->x_host + b, ctx->x_store + b, xseq, have)) != kFinWirePieces) {
+        __builtin_ia32_pause();
+        if (__atomic_load_n(ctx->x_host_seq, __ATOMIC_ACQUIRE) == (xseq | 0x80000000u)) {
+          // After a timeout the ranks no longer agree on the tick number (a peer may have taken this rank's record and
+          // moved on): the exchange is dead for good.  Later calls fail at once; all ranks must destroy and re-create it.
+          ctx->x_broken = true;
+          g_last_error = "peer exchange timed out: a rank did not publish its band record (the exchange is now unusable: "
+                         "destroy and re-create it on every rank)";
+          return DVO_AMD_ERR_COMM;
+        }
+        if ((++spins & 0xFFFFF) == 0) {
+          const hipError_t q = hipStreamQuery(ctx->stream);
+          if (q != hipErrorNotReady && q != hipSuccess) return fail_hip("stream died while waiting for the exchange", q);
+          if (q == hipSuccess && (have = take_wire(ctx->x_host + b, ctx->x_store + b, xseq, have)) != kFinWirePieces)
+            return fail_hip("exchange finished without publishing", hipErrorUnknown);
+        }
+      }
+      recs[b] = ctx->x_store + b;
+    }
+    return DVO_AMD_OK;
+  }
+  // per-iteration RCCL all-gather of the band records over xGMI, then one D2H copy of all of them
+  if (ctx->p_allgather(ctx->slots[0].out_dev, ctx->gather_dev, sizeof(FinOut), ncclChar, ctx->comm, ctx->stream) != ncclSuccess) {
+    g_last_error = "ncclAllGather failed";
+    return DVO_AMD_ERR_COMM;
+  }
+  HIP_TRY(hipMemcpyAsync(ctx->gather_host, ctx->gather_dev, sizeof(FinOut) * (size_t)n_bands, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (int b = 0; b < n_bands; ++b) recs[b] = ctx->gather_host + b;
+  return DVO_AMD_OK;
+}
+
+// The reference's overflowing 50-term likelihood product (dense_tracking_impl.cpp:413-419) for a pair tile-sharded over several
+// GPUs.  A rank holds only its own band's residuals, and a group of fifty can straddle a band edge.  All ranks see the same
+// combined record, so all of them come here together when its largest Mahalanobis distance makes an overflow possible:
+//   1. every rank judges the groups that lie inside its band (k_ll_overflow on a CLOSED band);
+//   2. it extracts its edge terms on the host from small copies of the band's ends: the `head` terms 1 + 0.2 q that complete the
+//      group begun in earlier bands, and the running product of the `tail` terms that begin a group the next band completes
+//      (multiplied from 1.0 in scan order: the reference's own loop up to that point);
+//   3. one more exchange of a record per rank (through whichever exchange the tick records use);
+//   4. every rank replays the straddling groups in band order -- acc *= term, fifty at a time, exactly the reference's loop.
+// The verdict is the reference's, bit for bit, and the same on every rank.  Rare (never on sensor data) and slow (a few copies
+// and a second exchange).
+int edge_terms(dvo_amd_context *ctx, const float2 *res, long long px_lo, long long px_hi, bool forward, int want, const float P[4],
+               std::vector<double> &terms) {
+  terms.clear();
+  std::vector<float2> buf;
+  const long long chunk = 8192;
+  long long at = forward ? px_lo : px_hi;
+  while ((int)terms.size() < want && (forward ? at < px_hi : at > px_lo)) {
+    const long long lo = forward ? at : std::max(px_lo, at - chunk), hi = forward ? std::min(px_hi, at + chunk) : at;
+    buf.resize((size_t)(hi - lo));
+    HIP_TRY(hipMemcpyAsync(buf.data(), res + lo, sizeof(float2) * (size_t)(hi - lo), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (long long k = 0; k < hi - lo && (int)terms.size() < want; ++k) {
+      const float2 r = buf[(size_t)(forward ? k : hi - lo - 1 - k)];
+      if (!(r.x == r.x)) continue;  // NaN marks an invalid pixel
+      const float t0 = r.x * P[0] + r.y * P[1];  // k_ll_overflow's expression, operation for operation (no contraction)
+      const float t1 = r.x * P[2] + r.y * P[3];
+      const float q = t0 * r.x + t1 * r.y;
+      terms.push_back(1.0 + 0.2 * (double)q);
+    }
+    at = forward ? hi : lo;
+  }
+  if ((int)terms.size() != want) return fail_hip("band edge holds fewer valid residuals than its valid count says", hipErrorUnknown);
+  if (!forward) std::reverse(terms.begin(), terms.end());  // back to scan order
+  return DVO_AMD_OK;
+}
+
+int sharded_overflow(dvo_amd_context *ctx, Job &j, int n_bands, int band, bool *overflowed) {
+  *overflowed = false;
+  const IterCtx &a = j.a;
+  if (a.cut_rank < 50) return DVO_AMD_OK;
+  int off[kMaxBands + 1], ll_count[kMaxBands], head_len[kMaxBands], tail_cnt[kMaxBands];
+  off[0] = 0;
+  for (int b = 0; b < n_bands; ++b) {
+    off[b + 1] = off[b] + a.band_valid[b];
+    ll_count[b] = std::max(0, std::min(a.cut_rank - off[b], a.band_valid[b]));  // this band's residuals that enter the likelihood
+    head_len[b] = std::min((50 - off[b] % 50) % 50, ll_count[b]);
+    tail_cnt[b] = (ll_count[b] - head_len[b]) % 50;
+  }
+  // 1. the groups inside this rank's band
+  int first = 0, count = 0;
+  band_blocks(a.n_blocks, n_bands, band, &first, &count);
+  bool inside = false;
+  if (count > 0 && ll_count[band] - head_len[band] >= 50) {
+    OvfBand ob;
+    ob.seg_first = first * kWavesPerBlock, ob.n_segs = count * kWavesPerBlock, ob.rank_offset = off[band], ob.rank_end = off[band + 1];
+    int rc = ll_overflowed(ctx, ctx->slots[0].res[a.buf], ctx->slots[0].seg_prefix[a.buf], a.n_blocks, a.steps, a.cut_rank, a.P, &ob, 1,
+                           &inside);
+    if (rc) return rc;
+  }
+  // 2. this rank's edge terms
+  FinOut rec;
+  std::memset(&rec, 0, sizeof(rec));
+  const long long block_px = (long long)kStepPx * kWavesPerBlock * a.steps;
+  const long long px_lo = first * block_px, px_hi = (long long)(first + count) * block_px;
+  std::vector<double> head, tail;
+  if (head_len[band] > 0) {
+    int rc = edge_terms(ctx, ctx->slots[0].res[a.buf], px_lo, px_hi, true, head_len[band], a.P, head);
+    if (rc) return rc;
+  }
+  double tail_acc = 1.0;
+  if (tail_cnt[band] > 0) {
+    int rc = edge_terms(ctx, ctx->slots[0].res[a.buf], px_lo, px_hi, false, tail_cnt[band], a.P, tail);
+    if (rc) return rc;
+    for (double t : tail) tail_acc *= t;
+  }
+  rec.acc[0] = inside ? 1.0 : 0.0, rec.acc[1] = (double)head_len[band], rec.acc[2] = (double)tail_cnt[band], rec.acc[3] = tail_acc;
+  for (size_t i = 0; i < head.size(); ++i) rec.acc[4 + i] = head[i];
+  static_assert(kNumAcc >= 4 + 49, "the edge record rides in the moment slots of a FinOut");
+  // 3. exchange
+  HIP_TRY(hipMemcpyAsync(ctx->slots[0].out_dev, &rec, sizeof(rec), hipMemcpyHostToDevice, ctx->stream));
+  if (ctx->x_ranks > 0) {
+    ctx->x_seq = next_seq(ctx->x_seq);
+    hipError_t e = launch_exchange_record(ctx->slots[0].out_dev, ctx->x_args_dev, ctx->x_seq, ctx->stream);
+    if (e != hipSuccess) return fail_hip("launch_exchange_record", e);
+  }
+  const FinOut *recs[kMaxBands];
+  int rc = collect_exchange(ctx, n_bands, recs);
+  if (rc) return rc;
+  // 4. the straddling groups, in band order
+  bool any = false;
+  double acc = 1.0;
+  int cnt = 0;
+  for (int b = 0; b < n_bands; ++b) {
+    const FinOut &r = *recs[b];
+    if ((int)r.acc[1] != head_len[b] || (int)r.acc[2] != tail_cnt[b]) {
+      g_last_error = "ranks disagree on the band edges of the likelihood's groups of fifty";
+      return DVO_AMD_ERR_COMM;
+    }
+    any = any || r.acc[0] != 0.0;
+    for (int i = 0; i < head_len[b]; ++i) {
+      acc *= r.acc[4 + i];
+      if (++cnt == 50) {
+        any = any || !(acc <= 1.7976931348623157e308);
+        acc = 1.0, cnt = 0;
+      }
+    }
+    if (tail_cnt[b] > 0) acc = r.acc[3], cnt = tail_cnt[b];  // (cnt is 0 here: the head closed the group before it)
+  }
+  *overflowed = any;
+  return DVO_AMD_OK;
+}
+
 int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, int n_local, bool exchange) {
   const unsigned seq = ctx->tick_seq = next_seq(ctx->tick_seq);
   if (!j.have_a && !j.have_b) return DVO_AMD_OK;
@@ -1674,42 +1831,9 @@ int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, i
   if (e != hipSuccess) return fail_hip("launch_finalize", e);
 
   const FinOut *recs[kMaxBands];
-  if (exchange && ctx->x_ranks > 0) {
-    // one hop: every rank's finalize record goes straight into every peer's mapped exchange buffer; the same kernel waits
-    // for the peers' records and forwards them to pinned host memory, which the host polls (no collective, no copy, no
-    // stream synchronisation)
-    const unsigned xseq = ctx->x_seq;  // k_finalize of this tick carried it (set above, before the launch)
-    for (int b = 0; b < n_bands; ++b) {
-      unsigned long long spins = 0;
-      int have = 0;
-      while ((have = take_wire(ctx->x_host + b, ctx->x_store + b, xseq, have)) != kFinWirePieces) {
-        __builtin_ia32_pause();
-        if (__atomic_load_n(ctx->x_host_seq, __ATOMIC_ACQUIRE) == (xseq | 0x80000000u)) {
-          // After a timeout the ranks no longer agree on the tick number (a peer may have taken this rank's record and
-          // moved on): the exchange is dead for good.  Later calls fail at once; all ranks must destroy and re-create it.
-          ctx->x_broken = true;
-          g_last_error = "peer exchange timed out: a rank did not publish its band record (the exchange is now unusable: "
-                         "destroy and re-create it on every rank)";
-          return DVO_AMD_ERR_COMM;
-        }
-        if ((++spins & 0xFFFFF) == 0) {
-          const hipError_t q = hipStreamQuery(ctx->stream);
-          if (q != hipErrorNotReady && q != hipSuccess) return fail_hip("stream died while waiting for the exchange", q);
-          if (q == hipSuccess && (have = take_wire(ctx->x_host + b, ctx->x_store + b, xseq, have)) != kFinWirePieces)
-            return fail_hip("exchange finished without publishing", hipErrorUnknown);
-        }
-      }
-      recs[b] = ctx->x_store + b;
-    }
-  } else if (exchange) {
-    // per-iteration RCCL all-gather of the band records over xGMI, then one D2H copy of all of them
-    if (ctx->p_allgather(ctx->slots[0].out_dev, ctx->gather_dev, sizeof(FinOut), ncclChar, ctx->comm, ctx->stream) != ncclSuccess) {
-      g_last_error = "ncclAllGather failed";
-      return DVO_AMD_ERR_COMM;
-    }
-    HIP_TRY(hipMemcpyAsync(ctx->gather_host, ctx->gather_dev, sizeof(FinOut) * (size_t)n_bands, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    for (int b = 0; b < n_bands; ++b) recs[b] = ctx->gather_host + b;
+  if (exchange) {
+    int rc = collect_exchange(ctx, n_bands, recs);
+    if (rc) return rc;
   } else {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     for (int b = 0; b < n_bands; ++b) {
@@ -1724,9 +1848,13 @@ int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, i
     for (int b = 0; b < n_bands; ++b) j.b.band_valid[b] = recs[b]->valid;
   if (j.sub_ll) {
     bool overflowed = false;
-    if (comb.ll_qmax >= kLlOverflowScreen && !exchange) {
-      // (all bands of the level were computed on this GPU, in slot 0's buffers: the exact check sees the whole level.  A pair
-      //  sharded over several GPUs holds only its own band here: the overflow artefact is not emulated on that path.)
+    if (comb.ll_qmax >= kLlOverflowScreen && exchange) {
+      // a pair sharded over several GPUs holds only its own band here: the ranks settle the groups of fifty that straddle band
+      // edges together (every rank sees the same combined record, so all of them take this branch in the same tick)
+      int rc = sharded_overflow(ctx, j, n_bands, band_first, &overflowed);
+      if (rc) return rc;
+    } else if (comb.ll_qmax >= kLlOverflowScreen) {
+      // (all bands of the level were computed on this GPU, in slot 0's buffers: the exact check sees the whole level)
       OvfBand ob[kMaxBands];
       int before = 0;
       for (int b = 0; b < n_bands; ++b) {  // the prefix table is relative to each band (band_blocks of the pass's blocks)

@@ -285,8 +285,13 @@ hipError_t launch_finalize(const FinArgs &args, hipStream_t stream);
 // k_ll_overflow): wave segments [seg_first, seg_first + n_segs) of seg_px pixels each, seg_prefix = the pass's prefix table
 // (valid pixels before each segment, relative to the band), rank_offset = valid pixels in earlier bands, n_px = pixels the
 // pass wrote.  *result_host (pinned, zeroed by the caller) is set to 1 when a group of fifty overflowed.
+// rank_end < 0: an open band (the residuals behind it are in the same buffer: the last chunk walks on until its last group is
+// complete); rank_end >= 0: a CLOSED band of a pair sharded over several GPUs, rank_end = rank of the first valid pixel behind
+// it -- only the groups that end inside the band are judged
 hipError_t launch_ll_overflow(const float2 *res, const int *seg_prefix, int seg_first, int n_segs, int seg_px, int rank_offset,
-                              int n_px, int cut_rank, const float P[4], unsigned *result_host, hipStream_t stream);
+                              int n_px, int cut_rank, int rank_end, const float P[4], unsigned *result_host, hipStream_t stream);
+// push a ready-made record (device memory) through the one-hop exchange as tick `xseq`
+hipError_t launch_exchange_record(const FinOut *rec_dev, const struct ExchangeArgs *exchange_dev, unsigned xseq, hipStream_t stream);
 // a Mahalanobis distance below this cannot make a group of fifty terms 1 + 0.2 q overflow a double (50 log2(1 + 0.2 q) < 1024)
 constexpr float kLlOverflowScreen = 7.0e6f;
 hipError_t read_finalize_stamps(unsigned long long out[8]);

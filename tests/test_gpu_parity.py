@@ -1154,6 +1154,30 @@ def test_sharded_match_with_single_rank_communicator(capi, synth, pair640, monke
     assert [len(L["Iterations"]) for L in sharded.Levels] == [len(L["Iterations"]) for L in whole.Levels]
 
 
+@pytest.mark.parametrize("exchange", ["rccl", "peer"])
+def test_sharded_overflow_verdict_with_a_single_rank(capi, synth, exchange):
+    """the closed-band form of k_ll_overflow, the edge record and its extra exchange, with one rank (the two-rank case runs in
+    tests/test_distributed.py): the pair whose likelihood overflows in the reference comes back as from match()"""
+    key, cands = synth.loop_closure_scenario(640, 480, 32, decoys=False)
+    K = synth.intrinsics_for(640, 480)
+    c = cands[2]
+    k_pyr, c_pyr = capi.RgbdImagePyramid(*key["frame"], K, 4), capi.RgbdImagePyramid(*c["frame"], K, 4)
+    cfg = capi.Config(FirstLevel=3, LastLevel=0, UseInitialEstimate=True)
+    trk = capi.DenseTracker(cfg)
+    if exchange == "rccl":
+        trk.comm_create(capi.comm_unique_id(), 1, 0)
+    else:
+        trk.exchange_attach([trk.exchange_create(1, 0)])
+    plain = capi.DenseTracker(cfg)
+    n_inf = 0
+    for init in (np.eye(4), np.linalg.inv(c["pose"]) @ key["pose"]):
+        a, b = plain.match(k_pyr, c_pyr, init), trk.match_sharded(k_pyr, c_pyr, init)
+        n_inf += sum(not np.isfinite(it["TDistributionLogLikelihood"]) for L in a.Levels for it in L["Iterations"])
+        assert [(L["TerminationCriterion"], len(L["Iterations"])) for L in a.Levels] == [(L["TerminationCriterion"], len(L["Iterations"])) for L in b.Levels]
+        assert np.array_equal(a.Transformation, b.Transformation)
+    assert n_inf >= 1
+
+
 def test_sharded_match_with_single_rank_peer_exchange(capi, synth, pair640, monkeypatch):
     """the one-hop exchange (exchange buffer, k_exchange, pinned forward) with one rank: equals the band pipeline"""
     trk = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0))
