@@ -182,6 +182,7 @@ def main():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     device = local_rank
     numa = pin_to_gpu_numa_node(device)
+    thread_plan = host_thread_plan(args, world, numa)
     W, H = args.width, args.height
     levels = 5 if W >= 1280 else 4
     first_level = levels - 1
@@ -408,6 +409,7 @@ def main():
                 "pyramid_working_set_mib": pyramid_bytes / 2**20,
                 "host_threads_per_gpu": T,
                 "host_threads_pinned_to_numa_node": numa,
+                "host_threads": thread_plan,
                 "pairs_in_flight_per_tracker": args.in_flight,
                 "residency": "kept across steps (next step's share submitted before the current one is collected)" if streaming
                              else "drained at the end of every step",
@@ -737,6 +739,28 @@ def tile_shard_bench(args, capi, synth, sharding, dist, rank, world, device, ref
         }), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def host_thread_plan(args, world, numa):
+    """Every host thread of a rank spins on pinned memory while it waits for a tick (wait_tick): ranks x threads spinners per
+    node.  Records what this rank runs with and caps the threads so that the ranks that share this rank's cores (all `world`
+    ranks spread evenly over the NUMA nodes, when the rank could be pinned to its GPU's node; else over the whole affinity mask)
+    leave one core in four free: 8 ranks x 6 threads are 48 spinners -- fine on the 2 x 64-core hosts of the MI355X nodes seen
+    so far, not on a 32-core host."""
+    try:
+        cpus = len(os.sched_getaffinity(0))
+        n_nodes = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()]) or 1
+    except Exception:
+        cpus, n_nodes = os.cpu_count() or 1, 1
+    sharing = -(-world // n_nodes) if numa is not None else world  # ranks that spin on the cores this rank may use
+    cap = max(1, (3 * cpus // 4) // max(1, sharing))
+    asked = args.threads
+    if args.threads > cap:
+        args.threads = cap
+    return {"threads_per_rank": args.threads, "threads_asked_for": asked, "ranks": world, "spin_polling_threads_in_the_job": args.threads * world,
+            "cpus_in_this_ranks_affinity_mask": cpus, "ranks_sharing_those_cpus": sharing, "cap_applied": asked > cap,
+            "numa_node_of_the_gpu": numa,
+            "rule": "threads per rank <= 3/4 of the cores in the rank's affinity mask / ranks sharing them"}
 
 
 def pin_to_gpu_numa_node(device):

@@ -14,16 +14,22 @@ EXE = os.path.join(ROOT, "examples", "_build", "adaptor_example")
 VEXE = os.path.join(ROOT, "examples", "_build", "validator_example")
 
 
-def _compile(name="adaptor_example"):
+MOCKS = os.path.join(ROOT, "tests", "mock_include")  # TEST-ONLY stand-ins for <Eigen/Geometry> and <opencv2/core/core.hpp>
+
+
+def _compile(name="adaptor_example", mocks=False):
+    """mocks=True: tests/mock_include in front of the include path -- the adaptor then takes its DVO_AMD_HAVE_EIGEN /
+    DVO_AMD_HAVE_OPENCV branch (Eigen::Affine3d, cv::Mat signatures) instead of the plain-C++ stand-in types"""
     from dvo_slam_amd import _build
 
     _build.build()
-    exe = os.path.join(ROOT, "examples", "_build", name)
+    exe = os.path.join(ROOT, "examples", "_build", name + ("_mock" if mocks else ""))
     os.makedirs(os.path.dirname(exe), exist_ok=True)
     libdir = os.path.join(ROOT, "dvo_slam_amd")
     # include/dvo_amd_compat in front: <dvo/dense_tracking.h>, <dvo/core/rgbd_image.h>, <dvo/core/point_selection.h> resolve
     # to the forwarding headers, as they would in a dvo_slam build with the include path switched
-    cmd = ["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-pthread", "-I" + os.path.join(ROOT, "include", "dvo_amd_compat"),
+    cmd = ["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-pthread"] + (["-I" + MOCKS] if mocks else []) + [
+           "-I" + os.path.join(ROOT, "include", "dvo_amd_compat"),
            "-I" + os.path.join(ROOT, "include"),
            os.path.join(ROOT, "examples", name + ".cpp"), "-o", exe, "-L" + libdir, "-ldvo_amd",
            "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined"]
@@ -39,6 +45,30 @@ def test_adaptor_compiles_as_plain_cxx11():
     res = subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Wpedantic", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"),
                           os.path.join(ROOT, "examples", "adaptor_example.cpp")], capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
+
+
+@pytest.mark.parametrize("name", ["adaptor_example", "boundary_callsites", "local_tracker_example", "validator_example",
+                                  "reference_signatures"])
+def test_production_branch_of_the_adaptor_compiles_against_eigen_and_opencv_mocks(name):
+    """the branch of the adaptor that carries the reference's REAL signatures --
+    bool match(..., Eigen::Affine3d&), create(const cv::Mat&, const cv::Mat&), cv::Mat computeIntensityErrorImage
+    (dvo_core/include/dvo/dense_tracking.h:156-162, core/rgbd_image.h:135) -- had never been through a compiler: neither library
+    exists in this image.  tests/mock_include holds test-only minimal <Eigen/Geometry> and <opencv2/core/core.hpp> exposing
+    exactly the members the adaptor uses; every example, and examples/reference_signatures.cpp which calls those signatures and
+    static_asserts their types, compiles against them with -std=c++11 -Wall -Wextra -Werror.  A compile proof against mocks,
+    not against the real libraries (INTEGRATION.md says so)."""
+    exe = _compile(name, mocks=True)
+    assert os.path.exists(exe)
+    # the branch was really taken: the translation unit sees Eigen's type behind dvo::core::AffineTransformd
+    probe = ('#include "dvo_amd/dense_tracking.hpp"\n#include <type_traits>\n'
+             'static_assert(std::is_same<dvo::core::AffineTransformd, Eigen::Affine3d>::value, "Eigen branch");\n'
+             '#if !defined(DVO_AMD_HAVE_OPENCV)\n#error no OpenCV branch\n#endif\nint main() { return 0; }\n')
+    res = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-I" + MOCKS, "-I" + os.path.join(ROOT, "include"), "-x", "c++", "-"],
+                         input=probe, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    if name == "boundary_callsites":  # needs no GPU: the Eigen-typed statistics dump runs
+        res = subprocess.run([exe], capture_output=True, text=True)
+        assert res.returncode == 0 and "boundary call sites ok" in res.stdout, res.stderr
 
 
 def test_constraints_adaptor_compiles_as_plain_cxx11():
@@ -252,3 +282,32 @@ def test_local_tracker_example_equals_the_python_binding(tmp_path, synth):
     err = [ln.split() for ln in res.stdout.splitlines() if ln.startswith("errorimage")][0]
     img = trk.computeIntensityErrorImage(pyr[0], pyr[1], np.eye(4), level=1)
     assert (int(err[1]), int(err[2])) == img.shape and abs(float(err[3]) - float(img.astype(np.float64).sum())) <= 1e-6 * img.size
+
+
+@pytest.mark.gpu
+def test_reference_signatures_run_on_the_gpu(tmp_path, synth):
+    """examples/reference_signatures.cpp (Eigen::Affine3d / cv::Mat signatures, compiled against the functional test mocks) fed
+    the sensor-regime frames as raw 8-bit grey + uint16 depth, the way benchmark_slam.cpp:56-80 feeds the reference: the pose it
+    prints is the Python binding's for the same frames."""
+    from dvo_slam_amd import capi
+
+    exe = _compile("reference_signatures", mocks=True)
+    w, h = 640, 480
+    ref, cur, Tgt = synth.sensor_pair(w, h)
+    K = synth.intrinsics_for(w, h)
+    paths = []
+    for name, arr in (("rg", ref[0]), ("rz", ref[1]), ("cg", cur[0]), ("cz", cur[1])):
+        p = tmp_path / (name + ".raw")
+        np.ascontiguousarray(arr).tofile(p)
+        paths.append(str(p))
+    res = subprocess.run([exe, str(w), str(h)] + [repr(float(k)) for k in K] + paths, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    lines = res.stdout.strip().splitlines()
+    assert lines[0] == "success 1" and lines[5] == "selection success 1 same 1"
+    T = np.array([[float(v) for v in ln.split()] for ln in lines[1:5]])
+    trk = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0))
+    want = trk.match(capi.RgbdImagePyramid(*synth.raw_to_float(*ref), K, 4), capi.RgbdImagePyramid(*synth.raw_to_float(*cur), K, 4))
+    assert np.array_equal(want.Transformation, T)  # same library, same planes: the same bits (printed with 17 digits)
+    assert synth.pose_error(Tgt, T) < 1e-3
+    assert abs(float(lines[6].split()[1]) - np.linalg.inv(T)[0, 3]) < 1e-12
+    assert lines[7].startswith("error_image 320 x 240 type_is_32f 1 sum ") and float(lines[7].split()[-1]) > 0
