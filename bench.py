@@ -610,17 +610,17 @@ def stats_variant(run_steps, B, args, with_stats):
 
 SIMDS = 256 * 4
 PEAK_CLOCK_HZ = 2.4e9
-VALU_ISSUE_CYCLES = 4   # one fp32 VALU wave instruction holds its SIMD for 4 cycles (measured: profiles/r03_issue.json)
+VALU_ISSUE_CYCLES = 4   # one fp32 VALU wave instruction holds its SIMD for 4 cycles (measured: profiles/r04_issue.json)
 MFMA_ISSUE_CYCLES = 32  # v_mfma_f32_16x16x4_f32 (MI355X_MICROARCH.md); 8 for v_mfma_f32_4x4x1_16B_f32
 
 
 def issue_roofline(log, k_ms):
     """The bound k_tick actually sits on: VALU + MFMA issue cycles.  Instructions per 64-pixel wave step come from the
-    committed PMC pass of the kernel (profiles/r03_issue.json: SQ_INSTS_VALU / SQ_INSTS_MFMA per step of the residual and of
+    committed PMC pass of the kernel (profiles/r04_issue.json: SQ_INSTS_VALU / SQ_INSTS_MFMA per step of the residual and of
     the likelihood pass); the steps are this run's (tick log); peak = every SIMD issuing every cycle at the 2.4 GHz peak clock."""
     try:
         here = os.path.dirname(os.path.abspath(__file__))
-        c = json.load(open(os.path.join(here, "profiles", "r03_issue.json")))
+        c = json.load(open(os.path.join(here, "profiles", "r04_issue.json")))
         res_steps, ll_steps = float(log[:, 6].sum()), float(log[:, 7].sum())
         mfma_cyc = c.get("mfma_issue_cycles", MFMA_ISSUE_CYCLES)
         cyc = (res_steps * (c["valu_per_res_step"] * VALU_ISSUE_CYCLES + c["mfma_per_res_step"] * mfma_cyc)
@@ -787,7 +787,7 @@ def pin_to_gpu_numa_node(device):
     return None
 
 
-TRAFFIC_FILE = "r03_traffic.json"
+TRAFFIC_FILE = "r04_traffic.json"
 
 
 def profiled_workload(args):
@@ -797,7 +797,7 @@ def profiled_workload(args):
 
 
 def traffic_from_profiles(args):
-    """HBM-side bytes per k_tick launch from the committed PMC passes (profiles/r03_traffic.json: rocprofv3 --pmc FETCH_SIZE
+    """HBM-side bytes per k_tick launch from the committed PMC passes (profiles/r04_traffic.json: rocprofv3 --pmc FETCH_SIZE
     and WRITE_SIZE in separate runs of the default command, gfx950 correction applied); counters cannot be read from inside
     the bench, so this is the figure of the profiled run (see traffic_source), not of this one.  null for any other workload."""
     if not profiled_workload(args):
