@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 #include "dvo_types.h"
 
@@ -144,6 +145,22 @@ struct LevelPairDesc {
   float wc[6], wr[4], ub_x, ub_y;
   RcpTable rcp;  // (only read by the RCP = 1 kernels)
 };
+
+// Block-level trace (builds with -DDVO_TRACE_BLOCKS only: scripts/variant.sh trace -DDVO_TRACE_BLOCKS; never in the shipped
+// library): every block of k_tick appends {start, after its first step, end} on the 100 MHz constant clock, what it ran and where
+// (HW_ID, XCC_ID).  scripts/block_trace.py turns a run's trace into slot occupancy and the phases of a block's life.
+#ifdef DVO_TRACE_BLOCKS
+struct BlockTrace {
+  unsigned long long t0, t_first, t_end;
+  unsigned info;   // bits 0..3 steps (log2) | bit 4 likelihood block | bits 8..15 level width / 8 | bits 16..31 blocks of the item
+  unsigned hw;     // HW_ID (bits 0..27) | XCC_ID << 28
+};
+constexpr unsigned kTraceCapacity = 1u << 22;
+__device__ BlockTrace g_trace[kTraceCapacity];
+__device__ unsigned g_trace_n;
+__device__ __forceinline__ unsigned long long trace_clock() { return __builtin_amdgcn_s_memrealtime(); }
+__shared__ unsigned long long trace_first;  // set by thread 0 of a residual block after its first step
+#endif
 
 // ------------------------------------------------------------------------------------------------------------------
 // residual pass
@@ -529,12 +546,25 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
   if (!(DVO_ABLATE & 16)) {  // (ablation 16: prologue + epilogue only)
     if (steps == 1) {
       do_step(0, 1, false);  // a one-step segment stages into buffer 1, which the epilogue consumes
+#ifdef DVO_TRACE_BLOCKS
+      if (threadIdx.x == 0) trace_first = trace_clock();
+#endif
     } else {
+#ifdef DVO_TRACE_BLOCKS
+      bool marked = false;
+#endif
       for (int step = 0; step + 2 < steps; step += 2) {
         do_step(step, 0, true);
+#ifdef DVO_TRACE_BLOCKS
+        if (!marked && threadIdx.x == 0) trace_first = trace_clock();
+        marked = true;
+#endif
         do_step(step + 1, 1, true);
       }
       do_step(steps - 2, 0, true);
+#ifdef DVO_TRACE_BLOCKS
+      if (!marked && threadIdx.x == 0) trace_first = trace_clock();
+#endif
       do_step(steps - 1, 1, false);
     }
   }
@@ -693,6 +723,17 @@ __device__ void loglik_pass(const TickItem &it, const LevelPairDesc &d, const in
   const int sub = item_ll_steps(it);                          // steps of one residual wave segment
   const int seg = blk_first * kWavesPerBlock + wave * blk_count;  // first residual wave segment of this wave
   const int steps = blk_count * sub;
+  // The first chunk of residuals is requested BEFORE the prefix table is looked at (the table decides whether the segment counts
+  // at all, but the addresses do not depend on it): one memory round trip less in the dependent chain every block starts with.
+  constexpr int kLlChunk = 16;
+  v2f cur[kLlChunk], nxt[kLlChunk];
+  const DVO_GLOBAL v2f *src = (const DVO_GLOBAL v2f *)((it.flags & kItemLlBuf) ? d.res[1] : d.res[0]) + seg * (kStepPx * sub) + lane;
+  auto load_chunk = [&](v2f(&dst)[kLlChunk], const int first) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < kLlChunk; ++k)
+      if (first + k < steps) dst[k] = src[(first + k) * kWave];
+  };
+  load_chunk(cur, 0);
   // valid pixels of this band that precede the segment (written by k_finalize of the residual pass that filled the buffer)
   const int seg_before =
       steps > 0 ? ((const DVO_GLOBAL int *)((it.flags & kItemLlBuf) ? d.seg_prefix[1] : d.seg_prefix[0]))[seg] : 0;
@@ -707,51 +748,58 @@ __device__ void loglik_pass(const TickItem &it, const LevelPairDesc &d, const in
   // group of 50 COULD have overflowed, asks k_ll_overflow for the exact answer (dvo_tracker.cpp: ll_overflowed).
   float qmax = 0.0f;
   if (steps > 0 && seg_before < cut_rank) {
-    const DVO_GLOBAL v2f *src = (const DVO_GLOBAL v2f *)((it.flags & kItemLlBuf) ? d.res[1] : d.res[0]) + seg * (kStepPx * sub) + lane;
     int run_count = seg_before;
-    // up to four steps (256 pixels) per trip; the terms 1 + 0.2 r^T P r >= 1 of a lane are multiplied up in a double and a log
+    // four steps (256 pixels) per trip; the terms 1 + 0.2 r^T P r >= 1 of a lane are multiplied up in a double and a log
     // is taken of the product, like the reference takes one log per 50 residuals (dense_tracking_impl.cpp:415-419) -- here
     // whenever the product has grown past 1e150 (checked once per trip) and at the end of the segment: the fp64 log is ninety
     // instructions, and one per sixteen terms was two fifths of this pass's issue time
     double prod = 1.0;
-    const int per_trip = steps < 4 ? steps : 4;
     const bool all_below_cut = seg_before + steps * kWave <= cut_rank;  // wave uniform: every pixel of the segment counts
-    for (int step = 0; step < steps; step += 4) {
-      v2f r[4];
+    // The residuals are fetched kLlChunk steps at a time and one chunk ahead of the arithmetic: sixteen 8-byte loads per lane in
+    // flight while the previous sixteen steps are worked through.  (Until round 4 a trip loaded its four steps and then used them:
+    // a block of the likelihood pass spent its life waiting for memory -- 24 us for 32 steps, more than a residual block's 17 us
+    // for a tenth of the instructions -- and the pass held a quarter of the GPU's block slots: scripts/block_trace.py.)  The
+    // arithmetic, and the order it is done in, are unchanged: trips of four steps, the product checked once per trip.
+    for (int c0 = 0; c0 < steps; c0 += kLlChunk) {
+      if (c0 + kLlChunk < steps) load_chunk(nxt, c0 + kLlChunk);
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (k < per_trip && step + k < steps) r[k] = src[(step + k) * kWave];
+      for (int t = 0; t < kLlChunk; t += 4) {
+        if (c0 + t >= steps) break;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (k >= per_trip || step + k >= steps) break;
-        const bool valid = r[k].x == r[k].x;
-        if (all_below_cut) {  // only the segment(s) around rank 50 * floor(V / 50) need ranks: Q6 drops at most 49 residuals
-          if (valid) {
-            const float t0 = r[k].x * P0 + r[k].y * P1;
-            const float t1 = r[k].x * P2 + r[k].y * P3;
-            const float q = t0 * r[k].x + t1 * r[k].y;
+        for (int k = 0; k < 4; ++k) {
+          if (c0 + t + k >= steps) break;
+          const v2f r = cur[t + k];
+          const bool valid = r.x == r.x;
+          if (all_below_cut) {  // only the segment(s) around rank 50 * floor(V / 50) need ranks: Q6 drops at most 49 residuals
+            if (valid) {
+              const float t0 = r.x * P0 + r.y * P1;
+              const float t1 = r.x * P2 + r.y * P3;
+              const float q = t0 * r.x + t1 * r.y;
+              prod *= ll_term(q);
+              qmax = max_raw(qmax, q);
+            }
+            continue;
+          }
+          const unsigned long long b = __ballot(valid);
+          const int rank = run_count + __popcll(b & below);
+          if (valid && rank < cut_rank) {
+            const float t0 = r.x * P0 + r.y * P1;
+            const float t1 = r.x * P2 + r.y * P3;
+            const float q = t0 * r.x + t1 * r.y;
             prod *= ll_term(q);
             qmax = max_raw(qmax, q);
           }
-          continue;
+          run_count += __popcll(b);
         }
-        const unsigned long long b = __ballot(valid);
-        const int rank = run_count + __popcll(b & below);
-        if (valid && rank < cut_rank) {
-          const float t0 = r[k].x * P0 + r[k].y * P1;
-          const float t1 = r[k].x * P2 + r[k].y * P3;
-          const float q = t0 * r[k].x + t1 * r[k].y;
-          prod *= ll_term(q);
-          qmax = max_raw(qmax, q);
+        // a log only when the running product gets large: a term is at most 1 + 0.2 * FLT_MAX < 7e37, so four more of them on top
+        // of 1e150 stay below the double range; with ordinary residuals (terms of 1 .. 20) a lane takes one log per wave segment
+        if (prod > 1e150) {
+          total += log(prod);
+          prod = 1.0;
         }
-        run_count += __popcll(b);
       }
-      // a log only when the running product gets large: a term is at most 1 + 0.2 * FLT_MAX < 7e37, so four more of them on top of
-      // 1e150 stay below the double range; with ordinary residuals (terms of 1 .. 20) a lane takes one log per wave segment
-      if (prod > 1e150) {
-        total += log(prod);
-        prod = 1.0;
-      }
+#pragma unroll
+      for (int k = 0; k < kLlChunk; ++k) cur[k] = nxt[k];
     }
     if (prod != 1.0) total += log(prod);
   }
@@ -864,12 +912,32 @@ template <int ACC, int RCP>
 __device__ __forceinline__ void tick_body(const TickItem &it, const RcpTable &rcp, const int bx) {
   const int rb = it.res_blocks;
   if (bx >= rb + it.ll_blocks) return;
+#ifdef DVO_TRACE_BLOCKS
+  const unsigned long long trace_t0 = trace_clock();
+  if (threadIdx.x == 0) trace_first = 0;
+#endif
   LevelPairDesc d = load_desc(it);
   d.rcp = rcp;
   if (bx < rb)
     residual_pass<ACC, RCP>(it, d, it.res_first + xcd_contiguous_block(bx, rb));
   else
     loglik_pass(it, d, (int)it.ll_first + (bx - rb));
+#ifdef DVO_TRACE_BLOCKS
+  if (threadIdx.x == 0) {
+    const unsigned slot = atomicAdd(&g_trace_n, 1u);
+    if (slot < kTraceCapacity) {
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      BlockTrace t;
+      t.t0 = trace_t0, t.t_first = trace_first, t.t_end = trace_clock();
+      t.info = (unsigned)(bx < rb ? (it.steps_log2 & 15) : (it.steps_log2 >> 4)) | (bx < rb ? 0u : 16u) | ((unsigned)(d.w / 8) << 8) |
+               ((unsigned)(bx < rb ? rb : it.ll_blocks) << 16);
+      t.hw = (hw & 0x0fffffffu) | (xcc << 28);
+      g_trace[slot] = t;
+    }
+  }
+#endif
 }
 
 // Which item owns this block, and which of the item's blocks is it?  Two-dimensional grid: (block, item).  One-dimensional
@@ -1393,6 +1461,31 @@ hipError_t launch_rcp_table_probe(const RcpTable &rcp, const float *in, float *o
   LaunchGuard guard;
   hipLaunchKernelGGL(k_rcp_table_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rcp, in, out, n);
   return hipGetLastError();
+}
+
+// (trace builds only) copies up to `capacity` block records (5 x 64-bit words each: t0, t_first, t_end, info | hw << 32, 0) out and
+// resets the trace; returns the number of blocks recorded, or -1 in a build without the trace
+long long read_block_trace(unsigned long long *out, long long capacity) {
+#ifdef DVO_TRACE_BLOCKS
+  unsigned n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_trace_n), sizeof(n)) != hipSuccess) return -2;
+  const unsigned have = n < kTraceCapacity ? n : kTraceCapacity;
+  const unsigned take = (long long)have < capacity ? have : (unsigned)capacity;
+  if (out && take) {
+    std::vector<BlockTrace> tmp(take);
+    if (hipMemcpyFromSymbol(tmp.data(), HIP_SYMBOL(g_trace), sizeof(BlockTrace) * take) != hipSuccess) return -2;
+    for (unsigned i = 0; i < take; ++i) {
+      out[4 * i] = tmp[i].t0, out[4 * i + 1] = tmp[i].t_first, out[4 * i + 2] = tmp[i].t_end;
+      out[4 * i + 3] = (unsigned long long)tmp[i].info | ((unsigned long long)tmp[i].hw << 32);
+    }
+  }
+  const unsigned zero = 0;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_n), &zero, sizeof(zero));
+  return (long long)n;
+#else
+  (void)out, (void)capacity;
+  return -1;
+#endif
 }
 
 hipError_t read_finalize_stamps(unsigned long long out[8]) {

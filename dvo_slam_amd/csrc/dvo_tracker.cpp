@@ -2908,6 +2908,12 @@ int dvo_amd_bench_residual_pass(dvo_amd_context *ctx, dvo_amd_pyramid *reference
   return dvo_amd_bench_residual_pass_pairs(ctx, n_items, r.data(), c.data(), level, T, rounds, reps, avg_ms, alg_bytes, n_launches);
 }
 
+long long dvo_amd_debug_block_trace(dvo_amd_context *ctx, unsigned long long *out, long long capacity_blocks) {
+  if (!ctx) return -(long long)DVO_AMD_ERR_INVALID_ARGUMENT;
+  if (hipSetDevice(ctx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -(long long)DVO_AMD_ERR_HIP;
+  return read_block_trace(out, capacity_blocks);
+}
+
 int dvo_amd_debug_finalize_stamps(dvo_amd_context *ctx, unsigned long long *stamps8) {
   if (!ctx || !stamps8) return DVO_AMD_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(ctx->device));

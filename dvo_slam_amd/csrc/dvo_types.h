@@ -295,6 +295,7 @@ hipError_t launch_exchange_record(const FinOut *rec_dev, const struct ExchangeAr
 // a Mahalanobis distance below this cannot make a group of fifty terms 1 + 0.2 q overflow a double (50 log2(1 + 0.2 q) < 1024)
 constexpr float kLlOverflowScreen = 7.0e6f;
 hipError_t read_finalize_stamps(unsigned long long out[8]);
+long long read_block_trace(unsigned long long *out, long long capacity);  // -1: not a trace build (see dvo_kernels.hip)
 // out[i] = the table reciprocal of in[i] (device pointers): the unit test of the opt-in host-rcpps mode
 hipError_t launch_rcp_table_probe(const RcpTable &rcp, const float *in, float *out, int n, hipStream_t stream);
 

@@ -150,6 +150,10 @@ int dvo_amd_context_device(const dvo_amd_context *ctx, int *device);
 #define DVO_AMD_RCP_HOST_SSE 1
 int dvo_amd_set_reciprocal_mode(dvo_amd_context *ctx, int mode);
 int dvo_amd_get_reciprocal_mode(const dvo_amd_context *ctx, int *mode, int *table_mantissa_bits);
+/* (diagnostic; libraries built with -DDVO_TRACE_BLOCKS only, else -1) the per-block trace of every k_tick block since the last
+ * call: 4 x 64-bit words per block {start, after the first step, end (100 MHz clock), info | hw_id << 32}; returns the number of
+ * blocks recorded and resets the trace.  scripts/block_trace.py */
+long long dvo_amd_debug_block_trace(dvo_amd_context *ctx, unsigned long long *out, long long capacity_blocks);
 /* (test entry) out[i] = the table reciprocal of in[i] as the kernels compute it; needs DVO_AMD_RCP_HOST_SSE */
 int dvo_amd_debug_rcp(dvo_amd_context *ctx, int n, const float *in, float *out);
 int dvo_amd_configure(dvo_amd_context *ctx, const dvo_amd_config *cfg);
