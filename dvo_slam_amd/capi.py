@@ -34,7 +34,7 @@ EXPORTS = [
     "dvo_amd_format_trajectory_line", "dvo_amd_debug_tick_log", "dvo_amd_debug_iteration", "dvo_amd_match_selection", "dvo_amd_bench_residual_pass_pairs",
     "dvo_amd_exchange_create", "dvo_amd_exchange_attach", "dvo_amd_exchange_destroy",
     "dvo_amd_match_submit", "dvo_amd_match_wait", "dvo_amd_match_poll", "dvo_amd_debug_next_seq",
-    "dvo_amd_set_reciprocal_mode", "dvo_amd_get_reciprocal_mode", "dvo_amd_debug_rcp",
+    "dvo_amd_set_reciprocal_mode", "dvo_amd_get_reciprocal_mode", "dvo_amd_debug_rcp", "dvo_amd_debug_block_trace",
 ]
 
 
@@ -181,6 +181,8 @@ def lib():
     L.dvo_amd_match_sharded.argtypes = [vp, vp, vp, dp, C.POINTER(CResult)]
     L.dvo_amd_match_banded.argtypes = [vp, vp, vp, dp, C.POINTER(CResult), C.c_int]
     L.dvo_amd_debug_combine_bands.argtypes = [C.c_int, dp, dp]
+    L.dvo_amd_debug_block_trace.restype = C.c_longlong
+    L.dvo_amd_debug_block_trace.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_longlong]
     L.dvo_amd_debug_wire_layout.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.dvo_amd_debug_take_wire.argtypes = [C.POINTER(C.c_uint), C.c_uint, C.c_int, C.POINTER(C.c_uint)]
     L.dvo_amd_debug_next_seq.argtypes = [C.c_uint]
