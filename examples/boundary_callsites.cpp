@@ -1,5 +1,6 @@
-// Compile (and run) check of the reference call sites that round 2's adaptor still broke, written as the reference writes
-// them, against the forwarding headers (include/dvo_amd_compat):
+// Compile (and run) check of the reference call sites that round 2's adaptor still broke -- the same members, enums and
+// conversions those call sites use, restated in this repository's own words (round 4: no reference text in here) -- against the
+// forwarding headers (include/dvo_amd_compat):
 //   dvo_ros/include/dvo_ros/util/configtools.h:32-82     updateConfigFromDynamicReconfigure: assigns EVERY Config field,
 //                                                         including the five match() never reads
 //   dvo_slam/src/keyframe_graph.cpp:354-371               Statistics streamed to std::cerr, LastIterationWithIncrement()
@@ -41,58 +42,33 @@ struct CameraDenseTrackerConfig {
 
 namespace util {
 
-// configtools.h:32-82
-void updateConfigFromDynamicReconfigure(const dvo_ros::CameraDenseTrackerConfig& config, dvo::DenseTracker::Config& tracker_cfg)
+// What configtools.h:32-82 does, restated (not the reference's text): the two dynamic_reconfigure enumerators are mapped to the
+// dvo_core enums, then EVERY field of DenseTracker::Config is assigned -- the five match() never reads included.  What is under
+// test is that each of these member names, enum names and implicit conversions exists in the adaptor.
+inline dvo::core::ScaleEstimators::enum_t scaleEstimatorOf(int v)
 {
-  dvo::core::ScaleEstimators::enum_t scale_estimator;
-
-  switch(config.scale_estimator)
-  {
-    case dvo_ros::CameraDenseTracker_NormalDistributionScaleEstimator:
-      scale_estimator = dvo::core::ScaleEstimators::NormalDistribution;
-      break;
-    case dvo_ros::CameraDenseTracker_TDistributionScaleEstimator:
-      scale_estimator = dvo::core::ScaleEstimators::TDistribution;
-      break;
-    case dvo_ros::CameraDenseTracker_MADScaleEstimator:
-      scale_estimator = dvo::core::ScaleEstimators::MAD;
-      break;
-    default:
-      assert(false && "unknown scale estimator");
-      break;
-  }
-
-  dvo::core::InfluenceFunctions::enum_t influence_function;
-
-  switch(config.influence_function)
-  {
-    case dvo_ros::CameraDenseTracker_TukeyInfluenceFunction:
-      influence_function = dvo::core::InfluenceFunctions::Tukey;
-      break;
-    case dvo_ros::CameraDenseTracker_TDistributionInfluenceFunction:
-      influence_function = dvo::core::InfluenceFunctions::TDistribution;
-      break;
-    case dvo_ros::CameraDenseTracker_HuberInfluenceFunction:
-      influence_function = dvo::core::InfluenceFunctions::Huber;
-      break;
-    default:
-      assert(false && "unknown influence function");
-      break;
-  }
-
-  tracker_cfg.FirstLevel = config.coarsest_level;
-  tracker_cfg.LastLevel = config.finest_level;
-  tracker_cfg.MaxIterationsPerLevel = config.max_iterations;
-  tracker_cfg.Precision = config.precision;
-  tracker_cfg.UseInitialEstimate = config.use_initial_estimate;
-  tracker_cfg.UseWeighting = config.use_weighting;
-  tracker_cfg.ScaleEstimatorType = scale_estimator;
-  tracker_cfg.ScaleEstimatorParam = config.scale_estimator_param;
-  tracker_cfg.InfluenceFuntionType = influence_function;
-  tracker_cfg.InfluenceFunctionParam = config.influence_function_param;
-  tracker_cfg.Mu = config.mu;
-  tracker_cfg.IntensityDerivativeThreshold = config.min_intensity_deriv;
-  tracker_cfg.DepthDerivativeThreshold = config.min_depth_deriv;
+  static const dvo::core::ScaleEstimators::enum_t by_cfg_value[] = {
+      dvo::core::ScaleEstimators::Unit,  // (0 is not a value of the .cfg enum)
+      dvo::core::ScaleEstimators::NormalDistribution, dvo::core::ScaleEstimators::TDistribution, dvo::core::ScaleEstimators::MAD};
+  assert(v >= dvo_ros::CameraDenseTracker_NormalDistributionScaleEstimator && v <= dvo_ros::CameraDenseTracker_MADScaleEstimator);
+  return by_cfg_value[v];
+}
+inline dvo::core::InfluenceFunctions::enum_t influenceFunctionOf(int v)
+{
+  static const dvo::core::InfluenceFunctions::enum_t by_cfg_value[] = {
+      dvo::core::InfluenceFunctions::Unit,  // (0 is not a value of the .cfg enum)
+      dvo::core::InfluenceFunctions::Tukey, dvo::core::InfluenceFunctions::TDistribution, dvo::core::InfluenceFunctions::Huber};
+  assert(v >= dvo_ros::CameraDenseTracker_TukeyInfluenceFunction && v <= dvo_ros::CameraDenseTracker_HuberInfluenceFunction);
+  return by_cfg_value[v];
+}
+void updateConfigFromDynamicReconfigure(const dvo_ros::CameraDenseTrackerConfig& in, dvo::DenseTracker::Config& out)
+{
+  out.ScaleEstimatorType = scaleEstimatorOf(in.scale_estimator), out.ScaleEstimatorParam = in.scale_estimator_param;
+  out.InfluenceFuntionType = influenceFunctionOf(in.influence_function), out.InfluenceFunctionParam = in.influence_function_param;
+  out.FirstLevel = in.coarsest_level, out.LastLevel = in.finest_level;
+  out.MaxIterationsPerLevel = in.max_iterations, out.Precision = in.precision, out.Mu = in.mu;
+  out.UseInitialEstimate = in.use_initial_estimate, out.UseWeighting = in.use_weighting;
+  out.IntensityDerivativeThreshold = in.min_intensity_deriv, out.DepthDerivativeThreshold = in.min_depth_deriv;
 }
 
 } /* namespace util */
@@ -101,12 +77,14 @@ void updateConfigFromDynamicReconfigure(const dvo_ros::CameraDenseTrackerConfig&
 namespace dvo_slam {
 namespace LocalTracker { typedef dvo::DenseTracker::Result TrackingResult; }
 
-// keyframe_graph.cpp:364-371: what the edge-error debug output does with a stored tracking result
-void printConstraintStatistics(LocalTracker::TrackingResult& r_second)
+// The members keyframe_graph.cpp:364-371 touches on a stored tracking result (restated): the whole Statistics through
+// operator<<, and the information condition number of the last accepted iteration on the finest and on the coarsest level.
+void printConstraintStatistics(LocalTracker::TrackingResult& result)
 {
-  std::cerr << r_second.Statistics << std::endl;
-  std::cerr << "kappa fine: " << r_second.Statistics.Levels.back().LastIterationWithIncrement().InformationConditionNumber() << std::endl;
-  std::cerr << "kappa coarse: " << r_second.Statistics.Levels.front().LastIterationWithIncrement().InformationConditionNumber() << std::endl;
+  dvo::DenseTracker::LevelStats &finest = result.Statistics.Levels.back(), &coarsest = result.Statistics.Levels.front();  // (non-const: so is LastIterationWithIncrement())
+  std::cerr << result.Statistics << "\n"
+            << "condition number, finest level: " << finest.LastIterationWithIncrement().InformationConditionNumber() << "\n"
+            << "condition number, coarsest level: " << coarsest.LastIterationWithIncrement().InformationConditionNumber() << std::endl;
 }
 }  // namespace dvo_slam
 

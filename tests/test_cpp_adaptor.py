@@ -103,7 +103,7 @@ def test_reference_call_sites_that_round_2_broke_compile_and_run():
     assert res.returncode == 0, res.stderr
     assert "boundary call sites ok" in res.stdout
     # the statistics went through the reference's stream format (dense_tracking.h:239-291)
-    assert "2 levels" in res.stderr and "Termination: LogLikelihoodDecreased" in res.stderr and "kappa fine: " in res.stderr
+    assert "2 levels" in res.stderr and "Termination: LogLikelihoodDecreased" in res.stderr and "condition number, finest level: " in res.stderr
     assert "Iteration: 2 ValidConstraints: 3898 DataLogLikelihood: -10002 PriorLogLikelihood: 0" in res.stderr
     for fwd in ("dvo/core/surface_pyramid.h", "dvo/core/point_selection_predicates.h", "dvo/core/weight_calculation.h"):
         assert os.path.exists(os.path.join(ROOT, "include", "dvo_amd_compat", fwd)), fwd
