@@ -78,7 +78,7 @@ def parse():
     if args.threads is None:
         args.threads = 8 if big else 6
     if args.in_flight is None:
-        args.in_flight = 72 if big else 96
+        args.in_flight = 72 if big else 124  # two groups of 62 pairs per tracker: every tick one full launch (kMaxItemsPerLaunch)
     return args
 
 
@@ -793,7 +793,7 @@ TRAFFIC_FILE = "r04_traffic.json"
 def profiled_workload(args):
     """The counter passes ran the default workload (the driver's command): their figure says nothing about another one."""
     return (args.width, args.height, args.batch, args.distinct, args.distinct_refs, args.threads, args.in_flight) == \
-           (640, 480, 1152, 96, 12, 6, 96) and not args.no_stats and not args.drain_between_steps
+           (640, 480, 1152, 96, 12, 6, 124) and not args.no_stats and not args.drain_between_steps
 
 
 def traffic_from_profiles(args):

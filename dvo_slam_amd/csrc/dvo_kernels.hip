@@ -947,7 +947,8 @@ template <class Args>
 __device__ __forceinline__ int tick_locate(const Args &args, int &bx) {
   constexpr int kSlots = (int)(sizeof(args.group_first) / sizeof(args.group_first[0]));
   if (!args.compact) {
-    bx = (int)blockIdx.x;
+    const int rot = args.xcd_rot[blockIdx.y];
+    bx = (int)((blockIdx.x & ~7u) | ((blockIdx.x + rot) & 7u));
     return (int)blockIdx.y;
   }
   const int lane = threadIdx.x & (kWave - 1);
@@ -955,6 +956,7 @@ __device__ __forceinline__ int tick_locate(const Args &args, int &bx) {
   const unsigned first = lane <= args.n_items ? (unsigned)args.group_first[lane < kSlots ? lane : 0] : 0xFFFFFFFFu;
   const int idx = __builtin_amdgcn_readfirstlane(__popcll(__ballot(first <= g)) - 1);
   bx = (int)blockIdx.x - ((int)args.group_first[idx] << 3);
+  bx = (bx & ~7) | ((bx + (int)args.xcd_rot[idx]) & 7);
   return idx;
 }
 
@@ -1027,6 +1029,34 @@ static int tick_args_layout_impl(Args &args, int max_blocks) {
     groups += ((unsigned)args.items[i].res_blocks + args.items[i].ll_blocks + 7u) >> 3;
   }
   for (int i = args.n_items; i < kSlots; ++i) args.group_first[i] = (uint16_t)groups;
+  // even out the XCDs' shares (see TickArgs::xcd_rot): greedy over the items in launch order, loads in units of ~0.1 us of block
+  // life as the block trace measures it (a residual block: 3.3 us + 2.1 us per step; a likelihood block about half of that)
+  static const bool rotate = [] {
+    const char *e = getenv("DVO_AMD_XCD_ROTATE");
+    return !(e && e[0] == '0');
+  }();
+  long long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < args.n_items; ++i) {
+    const TickItem &it = args.items[i];
+    const int rb = it.res_blocks, lb = it.ll_blocks;
+    const long long w_res = 33 + 21 * item_res_steps(it), w_ll = 40 + 7 * item_ll_steps(it);
+    long long phase[8];
+    for (int f = 0; f < 8; ++f) {
+      const int n_res = (rb >> 3) + (f < (rb & 7) ? 1 : 0);
+      const int all = ((rb + lb) >> 3) + (f < ((rb + lb) & 7) ? 1 : 0);
+      phase[f] = w_res * n_res + w_ll * (all - n_res);
+    }
+    int best = 0;
+    long long best_max = -1;
+    for (int rot = 0; rotate && rot < 8; ++rot) {  // XCD x does the blocks of phase (x + rot) & 7
+      long long mx = 0;
+      for (int x = 0; x < 8; ++x) mx = std::max(mx, load[x] + phase[(x + rot) & 7]);
+      if (best_max < 0 || mx < best_max) best_max = mx, best = rot;
+    }
+    args.xcd_rot[i] = (uint8_t)best;
+    for (int x = 0; x < 8; ++x) load[x] += phase[(x + best) & 7];
+  }
+  for (int i = args.n_items; i < (int)(sizeof(args.xcd_rot) / sizeof(args.xcd_rot[0])); ++i) args.xcd_rot[i] = 0;
   const long long grid2d = (long long)((max_blocks + 7) & ~7) * args.n_items;
   static const int mode = [] {  // DVO_AMD_COMPACT_GRID=0 / 1 forces a layout (tuning)
     const char *e = getenv("DVO_AMD_COMPACT_GRID");

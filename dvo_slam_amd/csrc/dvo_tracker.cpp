@@ -495,6 +495,7 @@ struct dvo_amd_context {
   long long level_steps_at[4] = {70, 250, 1000, 9600};
   int fault_slot_alloc = -1;           // DVO_AMD_FAULT_SLOT_ALLOC: fail the allocation of this slot once (tests of the error path)
   bool fin_stamps = false;             // DVO_AMD_FIN_STAMPS=1: k_finalize records phase stamps (diagnostic)
+  bool sort_items = true;              // longest-lived blocks first inside a launch (DVO_AMD_SORT_ITEMS=0: slot order)
   bool fin_priority = true;            // the batch reducer's waves run at raised issue priority (DVO_AMD_FIN_PRIORITY=0: off)
   bool small_args = true;              // ticks of at most kMaxSmallItems pairs use the small argument blocks (DVO_AMD_SMALL_ARGS=0: never)
   bool poll = true;                    // wait for a tick by polling the records' sequence words instead of hipStreamSynchronize
@@ -1170,8 +1171,19 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
     ta.compact = 0;
     ta.rcp = ctx->rcp;
     int max_blocks = 0;
+    // Blocks are dispatched in grid order and a launch ends with its last block: items whose blocks live longest (the most steps
+    // per wave segment) go first, so that the launch's tail is made of short blocks.  The order of the items inside a launch
+    // changes no result (every item's blocks, records and reducer are its own).  DVO_AMD_SORT_ITEMS=0: slot order.
+    int order[kMaxItemsPerLaunch];
+    for (int i = 0; i < n_here; ++i) order[i] = i;
+    if (ctx->sort_items)
+      std::stable_sort(order, order + n_here, [&](int a, int b) {
+        const TickItem &x = items[first + (size_t)a], &y = items[first + (size_t)b];
+        const int kx = x.res_blocks ? item_res_steps(x) : 0, ky = y.res_blocks ? item_res_steps(y) : 0;
+        return kx > ky;
+      });
     for (int i = 0; i < n_here; ++i) {
-      ta.items[i] = items[first + i];
+      ta.items[i] = items[first + (size_t)order[i]];
       max_blocks = std::max(max_blocks, (int)ta.items[i].res_blocks + (int)ta.items[i].ll_blocks);
     }
     size_t ev = 0;
@@ -1204,7 +1216,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
       if (es == hipSuccess) {
         FinArgsSmall fs;
         fs.n_items = n_here, fs.pad = ctx->fin_stamps ? 0x57A3 : 0;
-        for (int i = 0; i < kMaxSmallItems; ++i) fs.items[i] = fin_items[first + (size_t)(i < n_here ? i : 0)];
+        for (int i = 0; i < kMaxSmallItems; ++i) fs.items[i] = fin_items[first + (size_t)order[i < n_here ? i : 0]];
         const hipError_t ef = launch_finalize_small(fs, st);
         if (ef != hipSuccess) return fail_hip("launch_finalize", ef);
         continue;
@@ -1220,7 +1232,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
     fa.n_items = n_here;
     fa.pad = ctx->fin_stamps ? 0x57A3 : 0;
     fa.exchange = nullptr, fa.xseq = 0, fa.pad2 = ctx->fin_priority ? kFinFlagPriority : 0u;
-    for (int i = 0; i < n_here; ++i) fa.items[i] = fin_items[first + (size_t)i];
+    for (int i = 0; i < n_here; ++i) fa.items[i] = fin_items[first + (size_t)order[i]];
     for (int i = n_here; i < kMaxFinItems; ++i) fa.items[i] = fa.items[0];  // the whole block is copied by the launch: no stale stack bytes
     e = launch_finalize(fa, st);
     if (e != hipSuccess) return fail_hip("launch_finalize", e);
@@ -2082,6 +2094,7 @@ int dvo_amd_context_create(int device, const dvo_amd_config *cfg, dvo_amd_contex
   ctx->fin_stamps = fs && fs[0] == '1';
   const char *fp = getenv("DVO_AMD_FIN_PRIORITY");
   ctx->fin_priority = !(fp && fp[0] == '0');
+  if (const char *so = getenv("DVO_AMD_SORT_ITEMS")) ctx->sort_items = so[0] != '0';
   const char *sa = getenv("DVO_AMD_SMALL_ARGS");
   ctx->small_args = !(sa && sa[0] == '0');
   const char *hp = getenv("DVO_AMD_HOST_PROF");

@@ -151,7 +151,7 @@ constexpr unsigned kItemLlBuf = 2;        // which residual buffer the log-likel
 constexpr unsigned kItemUnitWeights = 4;  // first iteration on a level: weights = 1 (dense_tracking.cpp:286-289)
 static_assert(sizeof(TickItem) == 104, "TickItem is packed to fit many items into one kernel-argument block");
 
-constexpr int kMaxItemsPerLaunch = 36;
+constexpr int kMaxItemsPerLaunch = 62;  // (tick_locate: lanes 0 .. n_items of one wave look the owner of a block up)
 // Opt-in reciprocal mode (dvo_amd_set_reciprocal_mode): the HOST's _mm_rcp_ps, reproduced bit for bit from a table of
 // rcpps(1.m) indexed by the top mantissa bits that instruction looks at on this machine (probed when the mode is switched on,
 // csrc/dvo_tracker.cpp host_rcp_table).  table == nullptr: the default, exactly truncated quotient / v_rcp_f32.
@@ -167,9 +167,14 @@ struct TickArgs {
   // compact grid: item i owns block groups [group_first[i], group_first[i + 1]) of 8 blocks each (its blocks start on a
   // multiple of 8, so that "blocks b and b + 8 share an XCD" holds inside every item)
   uint16_t group_first[kMaxItemsPerLaunch + 4];
+  // Workgroup i of a launch runs on XCD i mod 8, and an item's blocks start on a multiple of 8: without more, the blocks that
+  // exist only on some XCDs (the item's count is no multiple of 8; its likelihood blocks are lighter than its residual blocks)
+  // always favour the same XCDs.  xcd_rot[i] rotates item i's blocks within their groups of eight -- block b of the grid does
+  // the work of block (b & ~7) | ((b + rot) & 7) -- chosen by tick_args_layout so that the XCDs' shares of the launch even out.
+  uint8_t xcd_rot[kMaxItemsPerLaunch + 2] = {};
   TickItem items[kMaxItemsPerLaunch];
 };
-static_assert(sizeof(TickArgs) <= 3950, "kernel argument block too large");
+static_assert(sizeof(TickArgs) <= 8192, "kernel argument block too large");
 
 // what the finalize kernel hands to the host for one job (lives in pinned host memory)
 struct FinOut {
@@ -245,7 +250,7 @@ struct FinArgs {
   unsigned pad2;          // kFinFlag* bits
   FinItem items[kMaxFinItems];
 };
-static_assert(sizeof(FinArgs) <= 2400, "kernel argument block too large");
+static_assert(sizeof(FinArgs) <= 4096, "kernel argument block too large");
 
 // A tick of at most eight pairs (a single match(), the two-pair front-end step, small batches) goes out with argument blocks a tenth the size:
 // the runtime copies the kernel arguments into device-visible memory at every launch, and both launches sit on the critical
@@ -256,6 +261,7 @@ struct TickArgsSmall {
   int compact;
   RcpTable rcp;
   uint16_t group_first[kMaxSmallItems + 4];
+  uint8_t xcd_rot[kMaxSmallItems] = {};
   TickItem items[kMaxSmallItems];
 };
 struct FinArgsSmall {
