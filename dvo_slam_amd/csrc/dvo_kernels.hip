@@ -36,6 +36,9 @@ namespace dvo_amd {
 // Make a value opaque to the optimiser.  Every float that is live across a rounding-mode switch goes through this once
 // before and once after the s_setreg, so no operation producing or consuming it can be scheduled on the wrong side.
 #define DVO_OPAQUE(x) asm volatile("" : "+v"(x))
+#ifndef DVO_KT_SGPR
+#define DVO_KT_SGPR 1
+#endif
 
 __device__ __forceinline__ void round_toward_zero() { __builtin_amdgcn_s_setreg(DVO_HWREG_MODE_FP32_ROUND, 3); }
 __device__ __forceinline__ void round_to_nearest() { __builtin_amdgcn_s_setreg(DVO_HWREG_MODE_FP32_ROUND, 0); }
@@ -246,6 +249,18 @@ __device__ __forceinline__ void finish_pixel_rtz(const LevelPairDesc &d, const P
 }
 
 typedef float v4acc __attribute__((ext_vector_type(4)));
+// The Gram matrix of the staged 16-vector v = sqrt(w) (Ja[0..5], Jb[0..5], r0, r1, 0, 0), as 4 x 4 tiles of 4-component chunks:
+// of the 16 chunk pairs only the 9 with ci <= cj < 4, ci < 3 hold moments (the tile is symmetric, r r^T is not needed).
+// v_mfma_f32_4x4x1_16b_f32 forms sixteen independent 4 x 4 outer products per instruction in 8 issue cycles (measured 8.9;
+// the 16x16x4 form: 33 for 4 points x 256 products, and matrix and vector instructions of a SIMD do NOT overlap on gfx950 --
+// scripts/probes/mfma_valu_coexec.hip, mfma_4x4_blocks.hip): block b of an instruction is point 16 g + b of the step, so 4 x 9 = 36
+// instructions (320 cycles) do the work of sixteen 16x16x4 ones (530).  DVO_GRAM_BLOCKS=0 builds the 16x16x4 form.
+#ifndef DVO_GRAM_BLOCKS
+#define DVO_GRAM_BLOCKS 1
+#endif
+constexpr int kGramPairs = 9;
+// tile index of the chunk pair (ci <= cj): (0,0) (0,1) (0,2) (0,3) (1,1) (1,2) (1,3) (2,2) (2,3)
+__host__ __device__ constexpr int gram_pair(int ci, int cj) { return ci == 0 ? cj : ci == 1 ? 3 + cj : 5 + cj; }
 
 // wave-local LDS hand-off: the LDS queue of a wave is in order, the fences only pin the compiler
 #define DVO_WAVE_LDS_SYNC()                                 \
@@ -293,6 +308,9 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
 #pragma unroll
   for (int i = 0; i < (ACC == 0 ? kNumAcc : 1); ++i) acc[i] = 0.0f;
   v4acc gram_a = {0.0f, 0.0f, 0.0f, 0.0f}, gram_b = {0.0f, 0.0f, 0.0f, 0.0f};
+  v4acc gram_p[kGramPairs];  // (DVO_GRAM_BLOCKS) one 4 x 4 tile per needed pair of 4-component chunks, 16 point classes each
+#pragma unroll
+  for (int k = 0; k < kGramPairs; ++k) gram_p[k] = v4acc{0.0f, 0.0f, 0.0f, 0.0f};
   // staging for the MFMA operands: [wave][point = lane][16 components], 16-byte chunks XOR-swizzled by point
   __shared__ __attribute__((aligned(16))) float stage[ACC >= 1 ? kWavesPerBlock * kBufs * kWave * 16 : 4];
   float S0[3] = {0.0f, 0.0f, 0.0f}, S1[3] = {0.0f, 0.0f, 0.0f};
@@ -312,7 +330,10 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
 #pragma unroll
   for (int i = 0; i < 12; ++i) {
     kt[i] = it.kt[i];
-    DVO_OPAQUE(kt[i]);
+    if (DVO_KT_SGPR)
+      asm volatile("" : "+s"(kt[i]));
+    else
+      DVO_OPAQUE(kt[i]);
   }
   const bool unit_w = (it.flags & kItemUnitWeights) != 0;
   const float P0 = it.P[0], P1 = it.P[1], P2 = it.P[2], P3 = it.P[3];
@@ -336,7 +357,31 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
   const int g_comp = lane & 15, g_sub = lane >> 4, g_cb = (g_comp >> 2) ^ (g_sub >> 1);
   const float *const g_even = stage + (wave * kBufs * kWave + g_sub) * 16 + ((g_cb << 2) | (g_comp & 3));
   const float *const g_odd = stage + (wave * kBufs * kWave + g_sub) * 16 + (((g_cb ^ 2) << 2) | (g_comp & 3));
+  // The 4 x 4 form: lane l supplies component l & 3 of chunk c of point 16 g + (l >> 2) as the A (row) and B (column) operand of
+  // the tiles chunk c takes part in.  The point's swizzle ((p >> 1) & 3 = (l >> 3) & 3, the same for every g) makes the four
+  // chunk positions lane constants; g and the buffer are immediates.  Eight consecutive points x one chunk = 32 distinct banks.
+  const int b_swz = (lane >> 3) & 3;
+  const float *const b_base = stage + (wave * kBufs * kWave + (lane >> 2)) * 16 + (lane & 3);
+  const float *const b_c0 = b_base + 4 * (0 ^ b_swz), *const b_c1 = b_base + 4 * (1 ^ b_swz), *const b_c2 = b_base + 4 * (2 ^ b_swz),
+                     *const b_c3 = b_base + 4 * (3 ^ b_swz);
   auto gram_from_stage = [&](const int q) __attribute__((always_inline)) {
+    if (DVO_GRAM_BLOCKS) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int off = (q & (kBufs - 1)) * kWave * 16 + g * 16 * 16;
+        const float x0 = b_c0[off], x1 = b_c1[off], x2 = b_c2[off], x3 = b_c3[off];
+        gram_p[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(x0, x0, gram_p[0], 0, 0, 0);
+        gram_p[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(x0, x1, gram_p[1], 0, 0, 0);
+        gram_p[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(x0, x2, gram_p[2], 0, 0, 0);
+        gram_p[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(x0, x3, gram_p[3], 0, 0, 0);
+        gram_p[4] = __builtin_amdgcn_mfma_f32_4x4x1f32(x1, x1, gram_p[4], 0, 0, 0);
+        gram_p[5] = __builtin_amdgcn_mfma_f32_4x4x1f32(x1, x2, gram_p[5], 0, 0, 0);
+        gram_p[6] = __builtin_amdgcn_mfma_f32_4x4x1f32(x1, x3, gram_p[6], 0, 0, 0);
+        gram_p[7] = __builtin_amdgcn_mfma_f32_4x4x1f32(x2, x2, gram_p[7], 0, 0, 0);
+        gram_p[8] = __builtin_amdgcn_mfma_f32_4x4x1f32(x2, x3, gram_p[8], 0, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int m = 0; m < 16; m += 2) {
       const float va = g_even[(q & (kBufs - 1)) * kWave * 16 + 64 * m];
@@ -570,7 +615,9 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
   }
 
   if (DVO_ABLATE & 32) {  // (ablation 32: no epilogue -- keep the accumulators alive, write nothing)
-    DVO_KEEP(S0[0] + S1[0] + first_w + gram_a[0] + gram_b[0] + (float)run_count);
+    float keep = S0[0] + S1[0] + first_w + gram_a[0] + gram_b[0] + (float)run_count;
+    for (int k = 0; k < kGramPairs; ++k) keep += gram_p[k][0];
+    DVO_KEEP(keep);
     return;
   }
   if (ACC >= 1 && !(DVO_ABLATE & 1) && steps > 0) gram_from_stage(1);  // the last step (odd index) staged into buffer 1
@@ -589,8 +636,26 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
     float *gsm = stage + wave * kBufs * kWave * 16;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if (DVO_GRAM_BLOCKS) {
+      // D layout of the 4 x 4 form: register r of lane l = tile[block l >> 2][row r][column l & 3].  The four blocks of a
+      // 16-lane row are added in registers, (b0 + b1) + (b2 + b3); the four rows and the four waves by the threads that
+      // gather the moments below: gsm[tile][row of lanes][column][row] (one 16-byte store per tile)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) gsm[((lane >> 4) * 4 + r) * 16 + (lane & 15)] = gram_a[r] + gram_b[r];
+      for (int k = 0; k < kGramPairs; ++k) {
+        v4acc t = gram_p[k];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = t[r];
+          v += dpp_read<0x124, 0xF>(v);  // row_ror:4
+          v += dpp_read<0x128, 0xF>(v);  // row_ror:8
+          t[r] = v;
+        }
+        if ((lane & 12) == 0) *reinterpret_cast<v4f *>(gsm + ((k * 4 + (lane >> 4)) * 4 + (lane & 3)) * 4) = v4f{t[0], t[1], t[2], t[3]};
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gsm[((lane >> 4) * 4 + r) * 16 + (lane & 15)] = gram_a[r] + gram_b[r];
+    }
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -629,6 +694,11 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
       const int q = tid - kAccAR0, grp = q / 6, i = q - grp * 6;  // AR0, AR1, BR0, BR1
       e0 = ((grp >> 1) * 6 + i) * 16 + 12 + (grp & 1);
     }
+    if (DVO_GRAM_BLOCKS) {  // entry (row, column), row <= column chunk-wise -> offset of gsm[tile][0][column & 3][row & 3]
+      auto at = [](const int e) { return ((gram_pair((e >> 4) >> 2, (e & 15) >> 2) * 4) * 4 + (e & 3)) * 4 + ((e >> 4) & 3); };
+      e0 = at(e0);
+      if (e1 >= 0) e1 = at(e1);
+    }
   }
   __syncthreads();
 
@@ -642,8 +712,16 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
       rec[kRecAcc + tid] = (sm[0][kRecAcc + tid] + sm[1][kRecAcc + tid]) + (sm[2][kRecAcc + tid] + sm[3][kRecAcc + tid]);
     } else {
       constexpr int kW = kBufs * kWave * 16;  // floats between the staging areas of two waves
-      float v = (stage[e0] + stage[kW + e0]) + (stage[2 * kW + e0] + stage[3 * kW + e0]);
-      if (e1 >= 0) v += (stage[e1] + stage[kW + e1]) + (stage[2 * kW + e1] + stage[3 * kW + e1]);
+      float v;
+      if (DVO_GRAM_BLOCKS) {
+        auto rows = [&](const float *p) { return (p[0] + p[16]) + (p[32] + p[48]); };  // the four 16-lane rows of a wave
+        auto waves = [&](const int e) { return (rows(stage + e) + rows(stage + kW + e)) + (rows(stage + 2 * kW + e) + rows(stage + 3 * kW + e)); };
+        v = waves(e0);
+        if (e1 >= 0) v += waves(e1);
+      } else {
+        v = (stage[e0] + stage[kW + e0]) + (stage[2 * kW + e0] + stage[3 * kW + e0]);
+        if (e1 >= 0) v += (stage[e1] + stage[kW + e1]) + (stage[2 * kW + e1] + stage[3 * kW + e1]);
+      }
       rec[kRecAcc + tid] = v;
     }
   } else if (tid == 128) {

@@ -1087,12 +1087,16 @@ def _track_frame_case(capi, orc, synth, render, _PATHS, gt_tol=1e-3):
         # both alignments against the oracle's of the same (reference, current, initial transformation): 1e-5, or -- when the
         # paths forked -- as far as the oracle lands from itself under re-associated sums (tests/fork_criterion.py)
         init_kf = np.linalg.inv(last_kf_pose)
+        fork_slack = 0.0  # how far a forked alignment (adjudicated below) sits from the oracle's: the criteria inherit it
+        forked_names = []  # criteria of an alignment whose last iteration is not the oracle's last iteration
         for got, want, o_ref, T0 in ((rk, ok, o[0], init_kf), (ro, oo, o[1], np.eye(4))):
             err = synth.pose_error(got.Transformation, want["T"])
             if [(L["TerminationCriterion"], len(L["Iterations"])) for L in got.Levels] == \
                     [(L["termination"], len(L["iterations"])) for L in want["levels"]]:
                 assert err <= POSE_TOL, err
             else:
+                fork_slack = max(fork_slack, err)
+                forked_names.append("keyframe" if got is rk else "odometry")
                 _PATHS["forked"].append(f"track_frame {sorted(cfg_kw.items())} {'keyframe' if got is rk else 'odometry'}")
                 _PATHS["fork_err"].append(err)
                 _PATHS["reports"].append((_PATHS["forked"][-1], fork_criterion.adjudicate(
@@ -1106,7 +1110,10 @@ def _track_frame_case(capi, orc, synth, render, _PATHS, gt_tol=1e-3):
                 assert got == want, name
             else:
                 rtol = 3e-2 if name.endswith("neg_loglik") else 2e-3
-                assert abs(got - want) <= rtol * abs(want) + 1e-6, (name, got, want)
+                if any(name.startswith(f) for f in forked_names):
+                    rtol = 5e-2  # statistics of a different last iteration (condition number, constraint ratio): percent level
+                # (a translation norm / an angle moves by at most ~2x the largest difference of two pose entries)
+                assert abs(got - want) <= rtol * abs(want) + 1e-6 + 2.0 * fork_slack, (name, got, want)
         # one two-pair batch == the two single alignments the reference runs side by side
         init = np.eye(4)
         init[:3, :3], init[:3, 3] = last_kf_pose[:3, :3].T, -last_kf_pose[:3, :3].T @ last_kf_pose[:3, 3]
