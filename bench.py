@@ -611,7 +611,7 @@ def stats_variant(run_steps, B, args, with_stats):
 SIMDS = 256 * 4
 PEAK_CLOCK_HZ = 2.4e9
 VALU_ISSUE_CYCLES = 4   # one fp32 VALU wave instruction holds its SIMD for 4 cycles (measured: profiles/r04_issue.json)
-MFMA_ISSUE_CYCLES = 32  # v_mfma_f32_16x16x4_f32 (MI355X_MICROARCH.md); 8 for v_mfma_f32_4x4x1_16B_f32
+MFMA_ISSUE_CYCLES = 32  # v_mfma_f32_16x16x4_f32 (MI355X_MICROARCH.md); the profile file says 8 for the nine-tile form (v_mfma_f32_4x4x1_16B_f32)
 
 
 def issue_roofline(log, k_ms):

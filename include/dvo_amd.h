@@ -454,7 +454,7 @@ int dvo_amd_error_image(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_am
  * `reps` timed repetitions of the fused residual pass over `n_items` copies of one (reference level, current level) pair
  * at the float transform T (column-major 4x4), `rounds` 256-pixel rounds (four 64-pixel steps each) per wave segment (1, 2, 4, 8 or 16; 0 = the driver's choice).
  * avg_ms: HIP-event time per repetition on the context's stream; alg_bytes: 56 B x selected points x n_items;
- * n_launches: kernel launches one repetition needs (the argument block holds 36 items). */
+ * n_launches: kernel launches one repetition needs (the argument block holds 62 items). */
 int dvo_amd_bench_residual_pass(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, int level,
                                 const float *T, int n_items, int rounds, int reps, double *avg_ms, double *alg_bytes,
                                 int *n_launches);

@@ -52,6 +52,9 @@ def fit(run_json, batch_csv, isolated_csv, isolated_steps_per_launch):
     ll_per = (valu_batch - valu_per * b["res_steps"]) / max(b["ll_steps"], 1.0)
     print(json.dumps({
         "valu_per_res_step": valu_per, "mfma_per_res_step": mfma_per, "valu_per_ll_step": ll_per,
+        # 36 per step: the nine-tile form, v_mfma_f32_4x4x1_16b_f32, two passes = 8 issue cycles (8.9 measured back to back,
+        # scripts/probes/mfma_4x4_blocks.hip); 16 per step: v_mfma_f32_16x16x4_f32, 32 cycles
+        "mfma_issue_cycles": 8 if mfma_per > 24 else 32,
         "mfma_check_batch": tot["SQ_INSTS_MFMA"] / max(b["res_steps"], 1.0),
         "source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA: isolated level-0 residual pass (36 pairs per launch, prologue / "
                   "epilogue amortised over the steps) and one 72-pair batch in timing mode (scripts/issue_counts.py)",

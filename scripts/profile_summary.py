@@ -34,12 +34,21 @@ def main():
         print(f"ratio {bench['roofline']['avg_launch_us'] / (sum(timed) / len(timed)):.3f}")
     elif mode == "traffic":
         out = {}
-        for name, path in (("FETCH_SIZE", sys.argv[2]), ("WRITE_SIZE", sys.argv[3])):
-            v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
-                 if "k_tick<" in r["Kernel_Name"] and r["Counter_Name"] == name]  # (the batch form: see k_tick_rows)
-            out[name + "_kb_avg_per_launch"] = sum(v) / len(v)
-            out[name + "_dispatches"] = len(v)
         bench = json.loads(open(sys.argv[4]).read().strip().splitlines()[-1])
+        # Like for like: bench.py's algorithmic bytes per launch are those of its single-stream timing pass, the LAST
+        # roofline.launches batch-form dispatches of the run (--no-extras: nothing of that form follows); the counters are
+        # averaged over exactly those dispatches.  The average over every dispatch of the run (streaming region, warm-up,
+        # priming included, whose launches carry other mixes of levels) is kept beside it.
+        n_timed = int(bench["roofline"]["launches"])
+        for name, path in (("FETCH_SIZE", sys.argv[2]), ("WRITE_SIZE", sys.argv[3])):
+            rows = [r for r in csv.DictReader(open(path))
+                    if "k_tick<" in r["Kernel_Name"] and r["Counter_Name"] == name]  # (the batch form: see k_tick_rows)
+            rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+            v = [float(r["Counter_Value"]) for r in rows]
+            out[name + "_kb_avg_per_launch"] = sum(v[-n_timed:]) / n_timed
+            out[name + "_kb_avg_over_every_dispatch_of_the_run"] = sum(v) / len(v)
+            out[name + "_dispatches"] = len(v)
+        out["launches_averaged"] = n_timed
         # FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read on gfx950: doubled (upper bound for this kernel,
         # whose reads are a mix of 16-byte gathers and 4-byte streaming loads); WRITE_SIZE is exact for streaming stores
         out["traffic_bytes_per_launch"] = (2.0 * out["FETCH_SIZE_kb_avg_per_launch"] + out["WRITE_SIZE_kb_avg_per_launch"]) * 1024.0
@@ -48,13 +57,14 @@ def main():
                           "FETCH_SIZE and --pmc WRITE_SIZE (one pass each)")
         out["bench_value_under_pmc"] = bench["value"]
         out["alg_bytes_per_launch"] = bench["roofline"]["alg_bytes_per_launch"]
-        out["note"] = ("average over every k_tick dispatch of the run (default workload: every pair of a step a different "
+        out["note"] = ("average over the k_tick dispatches of the run's single-stream timing pass, the launches alg_bytes_per_launch "
+                       "describes (default workload: every pair of a step a different "
                        "(keyframe, frame) combination, 108 pyramids = 2.1 GB, far beyond the 256 MiB Infinity Cache).  FETCH_SIZE "
                        "counts 64 B per 128-B request of a wide coalesced read on gfx950, so the corrected figure (2 x FETCH + "
                        "WRITE) is an upper bound for this kernel's mix of 16-byte gathers and 4-byte streaming loads and the "
                        "uncorrected one a lower bound; alg_bytes_per_launch is the algorithmic figure (56 B per selected pixel) of "
-                       "the single-stream timing pass of the same run.  Traffic <= algorithmic bytes: no wasted re-reads; the "
-                       "residual spill / re-read (16 of the 56 B) mostly stays in L2 / Infinity Cache.")
+                       "the single-stream timing pass of the same run.  The algorithmic figure lies between the two bounds: no wasted "
+                       "re-reads; part of the residual spill / re-read (16 of the 56 B) stays in L2 / Infinity Cache.")
         print(json.dumps(out, indent=1))
 
 
