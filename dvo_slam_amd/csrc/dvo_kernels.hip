@@ -591,7 +591,7 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
   if (!(DVO_ABLATE & 16)) {  // (ablation 16: prologue + epilogue only)
     if (steps == 1) {
       do_step(0, 1, false);  // a one-step segment stages into buffer 1, which the epilogue consumes
-#ifdef DVO_TRACE_BLOCKS
+#if defined(DVO_TRACE_BLOCKS) && !defined(DVO_TRACE_DESC)
       if (threadIdx.x == 0) trace_first = trace_clock();
 #endif
     } else {
@@ -600,14 +600,14 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
 #endif
       for (int step = 0; step + 2 < steps; step += 2) {
         do_step(step, 0, true);
-#ifdef DVO_TRACE_BLOCKS
+#if defined(DVO_TRACE_BLOCKS) && !defined(DVO_TRACE_DESC)
         if (!marked && threadIdx.x == 0) trace_first = trace_clock();
         marked = true;
 #endif
         do_step(step + 1, 1, true);
       }
       do_step(steps - 2, 0, true);
-#ifdef DVO_TRACE_BLOCKS
+#if defined(DVO_TRACE_BLOCKS) && !defined(DVO_TRACE_DESC)
       if (!marked && threadIdx.x == 0) trace_first = trace_clock();
 #endif
       do_step(steps - 1, 1, false);
@@ -995,6 +995,13 @@ __device__ __forceinline__ void tick_body(const TickItem &it, const RcpTable &rc
   if (threadIdx.x == 0) trace_first = 0;
 #endif
   LevelPairDesc d = load_desc(it);
+#ifdef DVO_TRACE_DESC  // (a variant of the trace: the "first step" stamp is taken when the descriptors have arrived instead)
+  if (threadIdx.x == 0) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    DVO_KEEP(d.w);
+    trace_first = trace_clock();
+  }
+#endif
   d.rcp = rcp;
   if (bx < rb)
     residual_pass<ACC, RCP>(it, d, it.res_first + xcd_contiguous_block(bx, rb));

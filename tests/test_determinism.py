@@ -63,10 +63,11 @@ def singles(capi, frames):
     return {ij: trk.match(frames[ij[0]], frames[ij[1]]) for ij in _pairs(frames, 30)}
 
 
-@pytest.mark.parametrize("residency", [2, 8, 9, 36, 96])
+@pytest.mark.parametrize("residency", [2, 8, 9, 36, 62, 96, 124])
 def test_batch_at_any_residency_equals_single_match(capi, frames, singles, residency):
     """2 and 8 resident pairs run behind the small argument blocks and the 512-thread reducer, 9 and more behind the full-size
-    launch and the 256-thread reducer, 96 in three groups on their own streams: the same bits every time"""
+    launch and the 256-thread reducer; 62 fill one launch (items sorted by block life, blocks rotated over the XCDs per item),
+    96 and 124 make two groups on their own streams: the same bits every time"""
     trk = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0))
     pairs = _pairs(frames, 130)
     out = trk.match_batch([frames[i] for i, _ in pairs], [frames[j] for _, j in pairs], in_flight=residency)
