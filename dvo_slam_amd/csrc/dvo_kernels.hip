@@ -1530,9 +1530,9 @@ __device__ __forceinline__ void finalize_block(const FinItem &it, const bool sta
   DVO_FIN_STAMP(3);
 }
 
-// The batch form (256 threads) is built for 96 registers: next to four k_tick waves of 104 registers a SIMD has 96 left, so a
-// reducer block can start on a CU that is full of k_tick blocks (its 11 KB of LDS fit beside their 4 x 36.5 KB) instead of
-// waiting for one of them to retire.
+// The batch form (256 threads) is built for under 96 registers and 11 KB of LDS (beside 4 x 36.5 KB of k_tick blocks).  Until the
+// Gram matrix moved to nine tiles a SIMD full of k_tick waves (4 x 104 registers) had 96 left and a reducer block could start on
+// a full CU; with 4 x 128 it takes the place of the next k_tick block that retires there (one retires somewhere every ~20 ns).
 template <int NT, bool EXCHANGE>
 __global__ __launch_bounds__(NT, NT == kFinThreadsBatch ? 5 : 1) void k_finalize(const FinArgs args) {
   // A reducer block is a few thousand cycles of work on the critical path of its group's tick, started on a CU whose SIMDs are
