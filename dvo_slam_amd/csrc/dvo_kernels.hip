@@ -163,6 +163,7 @@ __device__ BlockTrace g_trace[kTraceCapacity];
 __device__ unsigned g_trace_n;
 __device__ __forceinline__ unsigned long long trace_clock() { return __builtin_amdgcn_s_memrealtime(); }
 __shared__ unsigned long long trace_first;  // set by thread 0 of a residual block after its first step
+__shared__ unsigned long long trace_tail;   // -DDVO_TRACE_TAIL: when thread 128 (the ordered combine of the four wave segments) was done
 #endif
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -432,6 +433,7 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
       } else {
         g = gather_pixel(d, p.base);
       }
+
       // While this step's gathers are in flight, feed the matrix pipe with the vectors the PREVIOUS step staged
       // (v_mfma_f32 ignores MODE.FP_ROUND -- probed on gfx950, scripts/probes/mfma_round.hip -- so it may sit in
       // the toward-zero window).  This overlaps ~512 matrix-pipe cycles with the gather latency and with the next
@@ -768,6 +770,9 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
     rec[kRecLastR + 1] = l1;
     for (int i = 0; i < 3; ++i) rec[kRecS0 + i] = s0[i], rec[kRecS1 + i] = s1[i];
     rec[14] = 0.0f, rec[15] = 0.0f;
+#if defined(DVO_TRACE_BLOCKS) && defined(DVO_TRACE_TAIL)
+    __hip_atomic_store(&trace_tail, trace_clock(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
   }
 }
 
@@ -992,7 +997,10 @@ __device__ __forceinline__ void tick_body(const TickItem &it, const RcpTable &rc
   if (bx >= rb + it.ll_blocks) return;
 #ifdef DVO_TRACE_BLOCKS
   const unsigned long long trace_t0 = trace_clock();
-  if (threadIdx.x == 0) trace_first = 0;
+  // (the record's slot is taken NOW: the atomic's round trip, ~0.6 us under load, must not sit in front of the end stamp -- it did
+  //  until the end of round 4, and every block looked that much longer)
+  unsigned trace_slot = 0;
+  if (threadIdx.x == 0) trace_first = 0, trace_tail = 0, trace_slot = atomicAdd(&g_trace_n, 1u);
 #endif
   LevelPairDesc d = load_desc(it);
 #ifdef DVO_TRACE_DESC  // (a variant of the trace: the "first step" stamp is taken when the descriptors have arrived instead)
@@ -1009,13 +1017,22 @@ __device__ __forceinline__ void tick_body(const TickItem &it, const RcpTable &rc
     loglik_pass(it, d, (int)it.ll_first + (bx - rb));
 #ifdef DVO_TRACE_BLOCKS
   if (threadIdx.x == 0) {
-    const unsigned slot = atomicAdd(&g_trace_n, 1u);
+    const unsigned long long trace_t1 = trace_clock();
+    const unsigned slot = trace_slot;
     if (slot < kTraceCapacity) {
       unsigned hw, xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
       BlockTrace t;
-      t.t0 = trace_t0, t.t_first = trace_first, t.t_end = trace_clock();
+      t.t0 = trace_t0, t.t_first = trace_first, t.t_end = trace_t1;
+#ifdef DVO_TRACE_TAIL  // (the block's other tail: spin until thread 128 has stamped, at most ~20 us; t_first carries its stamp)
+      if (bx < rb) {
+        const unsigned long long t_spin = trace_clock();
+        unsigned long long tail = 0;
+        while ((tail = __hip_atomic_load(&trace_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0 && trace_clock() - t_spin < 2000) {}
+        t.t_first = tail;
+      }
+#endif
       t.info = (unsigned)(bx < rb ? (it.steps_log2 & 15) : (it.steps_log2 >> 4)) | (bx < rb ? 0u : 16u) | ((unsigned)(d.w / 8) << 8) |
                ((unsigned)(bx < rb ? rb : it.ll_blocks) << 16);
       t.hw = (hw & 0x0fffffffu) | (xcc << 28);
