@@ -7,10 +7,12 @@
 #include <cstdio>
 #include <vector>
 
+// ticks: a block's stay; ticks_spread > 0: block b stays ticks + (hash(b) % ticks_spread) instead (uneven block lives)
 template <int LDS_BYTES, int NV, bool SLEEP>
-__global__ __launch_bounds__(256, 4) void spin(unsigned long long ticks, unsigned long long *stamps, float *sink) {
+__global__ __launch_bounds__(256, 4) void spin(unsigned long long ticks, unsigned long long *stamps, float *sink, unsigned ticks_spread = 0) {
   __shared__ float lds[LDS_BYTES / 4];
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  if (ticks_spread) ticks += (blockIdx.x * 2654435761u >> 8) % ticks_spread;
   float v[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) v[i] = (float)(threadIdx.x + i);
@@ -34,11 +36,12 @@ __global__ __launch_bounds__(256, 4) void spin(unsigned long long ticks, unsigne
 }
 
 template <int LDS_BYTES, int NV, bool SLEEP>
-int run(double T, unsigned long long *stamps, float *sink) {
+int run(double T, unsigned long long *stamps, float *sink, double spread = 0.0) {
   const int n = 16 * 1024;
   const unsigned long long ticks = (unsigned long long)(T * 100.0);
   for (int rep = 0; rep < 2; ++rep) {
-    hipLaunchKernelGGL((spin<LDS_BYTES, NV, SLEEP>), dim3(n), dim3(256), 0, 0, ticks, stamps, sink);
+    hipLaunchKernelGGL((spin<LDS_BYTES, NV, SLEEP>), dim3(n), dim3(256), 0, 0, ticks, stamps, sink, (unsigned)(spread * 100.0));
+    if (spread > 0.0 && rep == 1) printf("(block lives T .. T + %.0f us, hashed) ", spread);
     if (hipDeviceSynchronize() != hipSuccess) return 2;
   }
   std::vector<unsigned long long> h(2 * n);
@@ -77,5 +80,7 @@ int main() {
   run<1024, 40, true>(18.0, stamps, sink);
   run<36592, 100, true>(5.0, stamps, sink);
   run<36592, 100, true>(36.0, stamps, sink);
+  run<36592, 100, true>(7.0, stamps, sink, 15.0);  // uneven lives: 7 .. 22 us, as in a batch launch
+  run<36592, 100, true>(14.5, stamps, sink);       // ... against even ones of the same mean
   return 0;
 }
