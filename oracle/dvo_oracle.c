@@ -953,10 +953,18 @@ static double inf_norm6(const double x[6]) {
   return m;
 }
 
-int orc_match(const orc_config *cfg, orc_pyramid *ref, orc_pyramid *cur, const double *T_init, orc_result *res) {
+/* The driver proper.  `from` == NULL: DenseTracker::match from its beginning.  Otherwise the loop is entered at the top of the
+ * iteration body (:259) of level from->level with the state a run of the reference would hold there -- see orc_match_state in
+ * dvo_oracle.h.  Nothing else differs: a continuation from a state this function itself passed through reproduces the rest of
+ * that run bit for bit (tests/test_oracle.py::test_continuation_reproduces_the_rest_of_a_match). */
+static int match_run(const orc_config *cfg, orc_pyramid *ref, orc_pyramid *cur, const double *T_init, const orc_match_state *from,
+                     orc_result *res) {
   const int n_levels_needed = cfg->first_level + 1;
   if (cfg->first_level < cfg->last_level || cfg->last_level < 0) return -1;
   if (ref->n_levels < n_levels_needed || cur->n_levels < n_levels_needed) return -2;
+  if (from && (from->level > cfg->first_level || from->level < cfg->last_level || from->iteration < 0 ||
+               from->iteration >= cfg->max_iterations_per_level))
+    return -4;
 
   double nan = NAN;
   res->n_levels = 0;
@@ -965,14 +973,23 @@ int orc_match(const orc_config *cfg, orc_pyramid *ref, orc_pyramid *cur, const d
 
   /* :137-150 */
   se3 inc, initial, initial_old, estimate, estimate_old;
-  if (cfg->use_initial_estimate && T_init)
-    se3_from_matrix(T_init, &inc);
-  else
+  if (from) {
+    /* `inc` is overwritten by exp(x) before it is read (:259); initial / estimate are the Revertables' current values */
     se3_identity(&inc);
-  initial = inc;
-  initial_old = inc;
-  se3_identity(&estimate);
-  se3_identity(&estimate_old);
+    se3_from_matrix(from->initial, &initial);
+    se3_from_matrix(from->estimate, &estimate);
+    initial_old = initial;
+    estimate_old = estimate;
+  } else {
+    if (cfg->use_initial_estimate && T_init)
+      se3_from_matrix(T_init, &inc);
+    else
+      se3_identity(&inc);
+    initial = inc;
+    initial_old = inc;
+    se3_identity(&estimate);
+    se3_identity(&estimate_old);
+  }
 
   const size_t max_pts = (size_t)ref->lv[cfg->last_level].w * ref->lv[cfg->last_level].h;
   orc_record *points_error = (orc_record *)xalloc(max_pts * sizeof(orc_record));
@@ -999,11 +1016,17 @@ int orc_match(const orc_config *cfg, orc_pyramid *ref, orc_pyramid *cur, const d
   g_sum_mode = cfg->sum_mode; /* (reset before the single return below) */
   g_ll_guard = cfg->ll_guard;
 
-  for (int level = cfg->first_level; level >= cfg->last_level; --level) {
+  for (int level = from ? from->level : cfg->first_level; level >= cfg->last_level; --level) {
     orc_level_stats *ls = &res->levels[res->n_levels++];
     memset(precision, 0, sizeof(precision));
     int iteration = 0;
     double error = DBL_MAX, last_error = DBL_MAX;
+    const int resumed = from && level == from->level;
+    if (resumed) { /* the level's own state: Iteration (:354), Error (:304), the precision the next weights use (:291) */
+      iteration = from->iteration;
+      error = from->last_error;
+      memcpy(precision, from->precision, sizeof(precision));
+    }
 
     orc_level *C = &cur->lv[level];
     orc_level *R = &ref->lv[level];
@@ -1020,7 +1043,10 @@ int orc_match(const orc_config *cfg, orc_pyramid *ref, orc_pyramid *cur, const d
     ls->first_iteration = res->n_iterations;
     last_level_first_iter = res->n_iterations;
 
-    se3_log(&inc, x); /* :238, Q1 */
+    if (resumed)
+      memcpy(x, from->x, sizeof(x)); /* the increment the resumed iteration applies (at a level start: the caller's log(inc)) */
+    else
+      se3_log(&inc, x); /* :238, Q1 */
     int accept = 1;
 
     do {
@@ -1046,6 +1072,7 @@ int orc_match(const orc_config *cfg, orc_pyramid *ref, orc_pyramid *cur, const d
       se3_to_matrix(&estimate, Td);
       for (int i = 0; i < 16; ++i) Tf[i] = (float)Td[i];
       memcpy(it->estimate, Td, sizeof(Td));
+      se3_to_matrix(&initial, it->initial);
 
       wa.first = R->sel;
       wa.n_sel = R->n_sel;
@@ -1132,6 +1159,10 @@ int orc_match(const orc_config *cfg, orc_pyramid *ref, orc_pyramid *cur, const d
   if (lit && lit->has_increment) {
     for (int i = 0; i < 36; ++i) res->information[i] = lit->information[i] * 0.008 * 0.008;
     res->loglik = lit->tdist_loglik + lit->prior_loglik;
+  } else if (li == -1 && from && from->level == cfg->last_level && from->iteration > 0 && from->has_previous) {
+    /* resumed inside the last level and rejected at once: the statistics entry :369-372 reads is the one before the resume */
+    for (int i = 0; i < 36; ++i) res->information[i] = from->previous_information[i] * 0.008 * 0.008;
+    res->loglik = from->previous_loglik;
   } else {
     /* the reference reads an uninitialised / out-of-range IterationStats here (Q9): report NaN */
     for (int i = 0; i < 36; ++i) res->information[i] = nan;
@@ -1151,6 +1182,15 @@ int orc_match(const orc_config *cfg, orc_pyramid *ref, orc_pyramid *cur, const d
   free(residuals);
   free(weights);
   return 0;
+}
+
+int orc_match(const orc_config *cfg, orc_pyramid *ref, orc_pyramid *cur, const double *T_init, orc_result *res) {
+  return match_run(cfg, ref, cur, T_init, NULL, res);
+}
+
+int orc_match_from(const orc_config *cfg, orc_pyramid *ref, orc_pyramid *cur, const orc_match_state *from, orc_result *res) {
+  if (!from) return -4;
+  return match_run(cfg, ref, cur, NULL, from, res);
 }
 
 /* One Gauss-Newton iteration body at a FIXED pose and a FIXED previous precision (dense_tracking.cpp:271-347 without the

@@ -89,6 +89,7 @@ typedef struct {
   int has_increment;
   double estimate[16];       /* extra: the transform (column-major 4x4, estimate()) whose float cast the residual stage of this
                                 iteration used, dense_tracking.cpp:263 */
+  double initial[16];        /* extra: initial() behind :260 of this iteration (what a continuation from here resumes with) */
 } orc_iteration_stats;
 
 /* DenseTracker::LevelStats (dense_tracking.h:103-116) */
@@ -144,6 +145,32 @@ int orc_compute_residuals(orc_pyramid *ref, orc_pyramid *cur, int level, float t
 
 /* DenseTracker::match(RgbdImagePyramid&, RgbdImagePyramid&, Result&): dense_tracking.cpp:123-376 */
 int orc_match(const orc_config *cfg, orc_pyramid *ref, orc_pyramid *cur, const double *T_init, orc_result *res);
+
+/* TEST INSTRUMENTATION (not a reference entry): the state DenseTracker::match holds at the top of an iteration body
+ * (dense_tracking.cpp:259), from which orc_match_from continues the reference's control flow (:247-363 and the level loop around
+ * it) exactly as orc_match would.  It exists for the fork criterion of the parity tests (tests/fork_criterion.py): when a
+ * free-running GPU match and the oracle take different decisions at some iteration, the oracle is continued from the GPU's OWN
+ * state behind that decision and the GPU's remaining iterations are held to that continuation.
+ *   level, iteration    the level and the value of `Iteration` (:354) = index of the iteration about to run; 0 = a level start
+ *   estimate, initial   the Revertables' current values (:147-150), column-major 4x4, BEFORE the increment x is applied
+ *   x                   the increment the iteration applies (:259): the previous iteration's solution (:347), or at a level
+ *                       start log(inc) of the last applied increment (:238, Q1)
+ *   last_error          `Error` (:304): -ll of the level's last accepted iteration; DBL_MAX at a level start (:210)
+ *   precision           the 2x2 precision of the previous iteration of this level (weights of the resumed one, :291), column-major
+ *   previous_*          Information / (TDistributionLogLikelihood + PriorLogLikelihood) of that previous iteration: what :369-372
+ *                       reads when the resumed iteration of the LAST level is rejected at once */
+typedef struct {
+  int level, iteration;
+  double estimate[16], initial[16];
+  double x[6];
+  double last_error;
+  float precision[4];
+  int has_previous;
+  double previous_information[36];
+  double previous_loglik;
+} orc_match_state;
+/* res->levels[0] is from->level and counts only the iterations run here (their ids continue at from->iteration).  -4: bad state */
+int orc_match_from(const orc_config *cfg, orc_pyramid *ref, orc_pyramid *cur, const orc_match_state *from, orc_result *res);
 
 /* Frame ingest.
  * depth: SurfacePyramid::convertRawDepthImage / ...Sse (surface_pyramid.cpp:44-105): 0 -> NaN, else (float)raw * scale

@@ -79,7 +79,15 @@ class IterationStats(C.Structure):
     _fields_ = [("id", C.c_int), ("valid_constraints", C.c_int), ("tdist_loglik", C.c_double),
                 ("tdist_mean", C.c_double * 2), ("tdist_precision", C.c_double * 4), ("prior_loglik", C.c_double),
                 ("increment", C.c_double * 6), ("information", C.c_double * 36), ("rhs", C.c_double * 6),
-                ("scale", C.c_float * 4), ("has_increment", C.c_int), ("estimate", C.c_double * 16)]
+                ("scale", C.c_float * 4), ("has_increment", C.c_int), ("estimate", C.c_double * 16),
+                ("initial", C.c_double * 16)]
+
+
+class MatchState(C.Structure):
+    """orc_match_state (dvo_oracle.h): the state DenseTracker::match holds at the top of an iteration body"""
+    _fields_ = [("level", C.c_int), ("iteration", C.c_int), ("estimate", C.c_double * 16), ("initial", C.c_double * 16),
+                ("x", C.c_double * 6), ("last_error", C.c_double), ("precision", C.c_float * 4), ("has_previous", C.c_int),
+                ("previous_information", C.c_double * 36), ("previous_loglik", C.c_double)]
 
 
 class LevelStats(C.Structure):
@@ -116,6 +124,7 @@ def lib():
         L.orc_compute_residuals.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, fp, C.c_int, fp, fp,
                                             C.POINTER(C.c_ubyte)]
         L.orc_match.argtypes = [C.POINTER(Config), C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(Result)]
+        L.orc_match_from.argtypes = [C.POINTER(Config), C.c_void_p, C.c_void_p, C.POINTER(MatchState), C.POINTER(Result)]
         L.orc_ingest_depth_u16.argtypes = [C.POINTER(C.c_ushort), C.c_int, C.c_int, C.c_int, C.c_float, fp]
         L.orc_ingest_gray_from_bgr8.argtypes = [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, fp]
         L.orc_ingest_gray_from_gray8.argtypes = [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, fp]
@@ -217,6 +226,30 @@ def iteration(ref: Pyramid, cur: Pyramid, level, T, prec_in=None, rcp_mode=RCP_E
 
 def match(cfg: Config, ref: Pyramid, cur: Pyramid, T_init=None):
     """DenseTracker::match.  Returns a dict with T (4x4), information (6x6), loglik, levels, iterations."""
+    return _run_match(cfg, ref, cur, T_init, None)
+
+
+def match_from(cfg: Config, ref: Pyramid, cur: Pyramid, *, level, iteration, estimate, initial, x, last_error=None, precision=None,
+               previous_information=None, previous_loglik=None):
+    """orc_match_from: the reference's control flow continued from the state it holds at the top of iteration `iteration` of
+    `level` (test instrumentation, dvo_oracle.h).  estimate / initial: 4x4 before the increment x is applied; last_error None =
+    DBL_MAX (a level start); precision: the previous iteration's 2x2.  Returns match()'s dict; levels[0] is `level` and holds only
+    the iterations run here."""
+    st = MatchState()
+    st.level, st.iteration = int(level), int(iteration)
+    st.estimate[:] = np.asarray(estimate, np.float64).T.ravel()
+    st.initial[:] = np.asarray(initial, np.float64).T.ravel()
+    st.x[:] = np.asarray(x, np.float64).ravel()
+    st.last_error = float(np.finfo(np.float64).max) if last_error is None else float(last_error)
+    st.precision[:] = (np.zeros(4, np.float32) if precision is None else np.asarray(precision, np.float32).T.ravel())
+    st.has_previous = int(previous_information is not None)
+    if previous_information is not None:
+        st.previous_information[:] = np.asarray(previous_information, np.float64).T.ravel()
+        st.previous_loglik = float(previous_loglik)
+    return _run_match(cfg, ref, cur, None, st)
+
+
+def _run_match(cfg, ref, cur, T_init, state):
     cap = (cfg.first_level - cfg.last_level + 1) * (cfg.max_iterations_per_level + 1)
     its = (IterationStats * cap)()
     res = Result()
@@ -226,9 +259,12 @@ def match(cfg: Config, ref: Pyramid, cur: Pyramid, T_init=None):
     if T_init is not None:
         T0a = np.ascontiguousarray(np.asarray(T_init, dtype=np.float64).T)
         T0 = T0a.ctypes.data_as(C.POINTER(C.c_double))
-    rc = lib().orc_match(C.byref(cfg), ref.h, cur.h, T0, C.byref(res))
+    if state is None:
+        rc = lib().orc_match(C.byref(cfg), ref.h, cur.h, T0, C.byref(res))
+    else:
+        rc = lib().orc_match_from(C.byref(cfg), ref.h, cur.h, C.byref(state), C.byref(res))
     if rc != 0:
-        raise RuntimeError(f"orc_match failed: {rc}")
+        raise RuntimeError(f"orc_match{'_from' if state is not None else ''} failed: {rc}")
     out = {
         "T": np.array(res.T[:]).reshape(4, 4).T.copy(),
         "information": np.array(res.information[:]).reshape(6, 6).T.copy(),
@@ -248,6 +284,7 @@ def match(cfg: Config, ref: Pyramid, cur: Pyramid, T_init=None):
                 "information": np.array(it.information[:]).reshape(6, 6).T.copy(), "rhs": np.array(it.rhs[:]),
                 "scale": np.array(it.scale[:]).reshape(2, 2).T.copy(),
                 "estimate": np.array(it.estimate[:]).reshape(4, 4).T.copy(),
+                "initial": np.array(it.initial[:]).reshape(4, 4).T.copy(),
             })
         out["levels"].append({"id": L.id, "max_valid_pixels": L.max_valid_pixels, "valid_pixels": L.valid_pixels,
                               "termination": L.termination, "iterations": iters})

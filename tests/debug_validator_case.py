@@ -67,7 +67,7 @@ for k in range(12):
     ds.append(synth.pose_error(ro["T"], orc.match(ocfg, opyr[ref], opyr[cur], synth.se3_exp(xi) @ init)["T"]))
 print("oracle under 1e-9 perturbations of the initial transform:", ["%.1e" % d for d in ds])
 try:
-    for line in fork_criterion.adjudicate(orc, synth, ocfg, opyr[ref], opyr[cur], init, rg, ro, err, 1e-5):
+    for line in fork_criterion.adjudicate(orc, synth, ocfg, opyr[ref], opyr[cur], init, rg, ro, err, 1e-5)[0]:
         print(line)
 except AssertionError as exc:
     print("ADJUDICATION FAILED:", exc)

@@ -2,11 +2,12 @@
 import numpy as np
 
 
-def f64_iteration(orc, orr, occ, level, T, prec_in, P_eval, ti=0.0, td=0.0):
+def f64_iteration(orc, orr, occ, level, T, prec_in, P_eval, ti=0.0, td=0.0, rcp_mode=None):
     """A third, independent restatement of one iteration body (numpy, float64 sums) on the oracle's bit-exact residual
     records: what the sums would be without any accumulation error.  Q5 pairing and Q6 cut included.  Returns
     (n, cov 2x2, A 6x6 under P_eval, b 6 under P_eval, Cauchy-Schwarz scale of b, ll under P_eval)."""
-    pe, res, _ = orc.compute_residuals(orr, occ, level, T, orc.RCP_EXACT, ti, td)  # ti, td: the point-selection thresholds
+    # ti, td: the point-selection thresholds; rcp_mode: the reciprocal the residual records are formed with (default: exact)
+    pe, res, _ = orc.compute_residuals(orr, occ, level, T, orc.RCP_EXACT if rcp_mode is None else rcp_mode, ti, td)
     r = res.astype(np.float64)
     n = len(r)
     if prec_in is None:

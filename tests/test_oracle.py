@@ -495,3 +495,113 @@ def test_float64_restatement_brackets_the_oracles_sequential_fp32_sums(orc, synt
             prec = it["precision"]
     assert worst["scale"] <= 1e-3 and worst["A"] <= 3e-4 and worst["b"] <= 3e-5 and worst["ll"] <= 2e-6, worst
     assert worst["scale"] >= 1e-7  # it is an fp32 sum: if this ever reads 0 the comparison has stopped comparing
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the continuation entry (orc_match_from) and the deterministic fork criterion built on it (tests/fork_criterion.py)
+# ---------------------------------------------------------------------------------------------------------------------
+def _path(r):
+    return [(L["id"], L["termination"], len(L["iterations"])) for L in r["levels"]]
+
+
+def test_continuation_reproduces_the_rest_of_a_match(orc, synth):
+    """orc_match_from entered with the state orc_match itself held at the top of ANY iteration body -- inside a level or at a
+    level start -- runs the rest of that match: same iterations, same terminations, same numbers, same result
+    (dense_tracking.cpp:247-363 and the level loop around it hold no other state)."""
+    import fork_criterion as F
+
+    (Ir, Zr), (Ic, Zc), _ = synth.make_pair(320, 240)
+    K = synth.intrinsics_for(320, 240)
+    pr, pc = orc.Pyramid(Ir, Zr, K, 3), orc.Pyramid(Ic, Zc, K, 3)
+    n_states = 0
+    for kw, T0 in ((dict(), None), (dict(mu=0.05, use_initial_estimate=1, precision=1e-4), synth.se3_exp([0.01, 0, -0.01, 0, 0.004, 0]))):
+        cfg = orc.default_config(first_level=2, last_level=0, rcp_mode=orc.RCP_EXACT, **kw)
+        base = orc.match(cfg, pr, pc, T0)
+        O = F.oracle_levels(base)
+        for li, L in enumerate(O):
+            for k in range(len(L["iters"])):
+                st = F.state_behind(orc, O, cfg, T0, li, k)
+                if st is None:
+                    continue
+                rest = orc.match_from(cfg, pr, pc, **st)
+                n_states += 1
+                want = _path(base)[li + 1:] if st["iteration"] == 0 else \
+                    [(L["id"], L["termination"], len(L["iters"]) - k - 1)] + _path(base)[li + 1:]
+                assert _path(rest) == want, (li, k, _path(rest), want)
+                assert synth.pose_error(base["T"], rest["T"]) < 1e-13
+                assert np.allclose(rest["information"], base["information"], rtol=1e-12, equal_nan=True)
+                assert rest["loglik"] == base["loglik"] or (np.isnan(rest["loglik"]) and np.isnan(base["loglik"]))
+                # every continued iteration is the original's, number for number
+                spliced = F.splice(O, li, k, st, F.oracle_levels(rest))
+                for La, Lb in zip(spliced, O):
+                    assert len(La["iters"]) == len(Lb["iters"])
+                    for ia, ib in zip(La["iters"], Lb["iters"]):
+                        assert ia["V"] == ib["V"] and ia["nll"] == ib["nll"] and ia["has_inc"] == ib["has_inc"]
+                        if ia["has_inc"]:
+                            assert np.allclose(ia["inc"], ib["inc"], rtol=1e-9, atol=1e-15)
+    assert n_states >= 20
+    # a state the reference cannot be in is refused
+    with pytest.raises(RuntimeError):
+        orc.match_from(cfg, pr, pc, level=5, iteration=0, estimate=np.eye(4), initial=np.eye(4), x=np.zeros(6))
+
+
+class _StandIn:
+    """an oracle run in capi.Result's shape: stands in for the GPU where there is none (the fork criterion on the CPU)"""
+
+    def __init__(self, r):
+        self.Transformation, self.Information, self.LogLikelihood = r["T"], r["information"], r["loglik"]
+        self.Levels = [{"Id": L["id"], "TerminationCriterion": L["termination"], "ValidPixels": L["valid_pixels"],
+                        "MaxValidPixels": L["max_valid_pixels"],
+                        "Iterations": [{"ValidConstraints": it["valid_constraints"], "TDistributionLogLikelihood": it["tdist_loglik"],
+                                        "has_increment": it["has_increment"], "EstimateIncrement": it["increment"],
+                                        "TDistributionPrecision": it["precision"], "estimate": it["estimate"], "initial": it["initial"],
+                                        "EstimateInformation": it["information"], "PriorLogLikelihood": it["prior_loglik"]}
+                                       for it in L["iterations"]]} for L in r["levels"]]
+
+    def isNaN(self):
+        return False
+
+
+def test_fork_criterion_resynchronises_a_stand_in(orc, synth, capsys):
+    """The criterion of tests/fork_criterion.py end to end on the CPU.  The stand-in for the GPU is the oracle with its fp32 terms
+    accumulated in double (another summation order, like any GPU): on the "larger motion" pair it forks from the reference-order
+    oracle and lands 5.5e-5 from it -- beyond the 1e-5 bar, which rounds 3-4 excused with a sampled self-distance.  Now: the
+    flipped decision is adjudicated, the reference-order oracle is continued from the stand-in's own state behind it, the rest is
+    same-path and the final pose is within 1e-5 of the continuation's.  And a stand-in whose pose bookkeeping is WRONG behind the
+    fork is caught."""
+    import copy
+
+    import fork_criterion as F
+
+    (Ir, Zr), _, _ = synth.make_pair(640, 480)
+    K = synth.intrinsics_for(640, 480)
+    ref = orc.Pyramid(Ir, Zr, K, 4)
+    cur_frame = synth.render(640, 480, synth.se3_exp([0.04, -0.02, 0.03, 0.015, -0.02, 0.01]), frame_id=5)
+    cur = orc.Pyramid(cur_frame[0], cur_frame[1], K, 4)
+    ocfg = orc.default_config(first_level=3, last_level=0, rcp_mode=orc.RCP_EXACT)
+    ro = orc.match(ocfg, ref, cur)
+    lines = []
+    n_forked = 0
+    for mode in (orc.SUM_FP64, orc.SUM_BLOCKED):
+        other = orc.match(orc.default_config(first_level=3, last_level=0, rcp_mode=orc.RCP_EXACT, sum_mode=mode), ref, cur)
+        g = _StandIn(other)
+        err = synth.pose_error(ro["T"], g.Transformation)
+        if F.same_path(g, ro):
+            continue
+        n_forked += 1
+        report, O, final = F.adjudicate(orc, synth, ocfg, ref, cur, None, g, ro, err, 1e-5)
+        assert F.first_fork(F.gpu_levels(g), O) is None
+        assert synth.pose_error(final["T"], g.Transformation) <= 1e-5 and np.allclose(final["information"], g.Information, rtol=5e-3)
+        lines += [f"[stand-in sum_mode {mode}] {ln}" for ln in report]
+        if err > 1e-5:
+            # a run that is NOT the reference algorithm behind the fork: its last level's estimates moved by 3e-5
+            bad = copy.deepcopy(g)
+            shift = synth.se3_exp([3e-5, 0, 0, 0, 0, 0])
+            bad.Transformation = bad.Transformation @ shift
+            with pytest.raises(AssertionError):
+                F.adjudicate(orc, synth, ocfg, ref, cur, None, bad, ro, err, 1e-5)
+    assert n_forked >= 1
+    with capsys.disabled():
+        print()
+        for ln in lines:
+            print(ln)

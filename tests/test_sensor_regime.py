@@ -113,7 +113,9 @@ def _check(capi, orc, synth, d, cfg_kw, T_init=None, swap=False):
     # (drift band of the per-iteration comparison: on sensor input the two sides' poses are ~1e-7 .. 1e-6 apart at the late
     #  iterations, and the 2 % of missing depth readings give a level some 50 000 cell edges a projected point can sit next to:
     #  a handful to a few dozen valid-constraint flips, against 0 .. 3 on the noise-free frames)
-    return P._check_match(capi, orc, synth, gr, gc, orr, occ, cfg_kw, T_init, paths=SENSOR_PATHS, label=label, count_slack=40)
+    # (and the same drift moves an increment by a few per cent of its largest component: increment_band, this regime only)
+    return P._check_match(capi, orc, synth, gr, gc, orr, occ, cfg_kw, T_init, paths=SENSOR_PATHS, label=label, count_slack=40,
+                          increment_band=0.05)
 
 
 def test_match_640x480_4_levels(capi, orc, synth, spair):
@@ -176,7 +178,7 @@ def test_track_frame_on_sensor_frames(capi, orc, synth):
     def render(w, h, T, frame_id=0):
         return synth.raw_to_float(*synth.sensor_frame(w, h, T, frame_id=frame_id))
 
-    P._track_frame_case(capi, orc, synth, render, SENSOR_PATHS, gt_tol=3e-3)
+    P._track_frame_case(capi, orc, synth, render, SENSOR_PATHS, gt_tol=3e-3, count_slack=40, increment_band=0.05)
 
 
 def test_zz_book_of_the_sensor_regime(capsys):
@@ -188,6 +190,8 @@ def test_zz_book_of_the_sensor_regime(capsys):
               f"forked: {len(S['forked'])}; configurations beyond 1e-5 of the oracle: {sum(e > 1e-5 for e in S['errs'])} of "
               f"{len(S['errs'])}, worst {max(S['errs'] or [0.0]):.2e}; pose errors of the forked configurations: "
               f"{['%.1e' % e for e in S['fork_err']]}")
+        print("[re-syncs per forked configuration, sensor regime] "
+              + "; ".join(f"{label}: {sum(ln.startswith('re-sync') for ln in report)}" for label, report in S["reports"]))
         for label, report in S["reports"]:
             print(f"[fork, sensor regime] {label}")
             for line in report:
