@@ -8,7 +8,7 @@ BUILD_ID := $(shell python3 dvo_slam_amd/_build.py --print-id)
 all: $(LIB)
 
 $(LIB): $(SRC)/dvo_kernels.hip $(SRC)/dvo_tracker.cpp $(SRC)/dvo_validator.cpp $(SRC)/dvo_frontend.cpp $(SRC)/dvo_tum.cpp \
-        $(SRC)/dvo_types.h $(SRC)/se3.h include/dvo_amd.h
+        $(SRC)/dvo_types.h $(SRC)/se3.h include/dvo_amd.h include/dvo_amd_debug.h
 	$(HIPCC) $(FLAGS) '-DDVO_AMD_BUILD_ID="$(BUILD_ID)"' -x hip $(SRC)/dvo_kernels.hip $(SRC)/dvo_tracker.cpp $(SRC)/dvo_validator.cpp $(SRC)/dvo_frontend.cpp \
 	    $(SRC)/dvo_tum.cpp -lz -o $@
 

@@ -17,7 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("DVO_AMD_LIB") or os.path.join(_HERE, "libdvo_amd.so")
 SOURCES = ["dvo_kernels.hip", "dvo_tracker.cpp", "dvo_validator.cpp", "dvo_frontend.cpp", "dvo_tum.cpp"]
-HEADERS = ["dvo_types.h", "se3.h", os.path.join("..", "..", "include", "dvo_amd.h")]
+HEADERS = ["dvo_types.h", "se3.h", os.path.join("..", "..", "include", "dvo_amd.h"),
+           os.path.join("..", "..", "include", "dvo_amd_debug.h")]
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off",          # the warp/residual stage must round every product and sum separately

@@ -35,6 +35,7 @@ EXPORTS = [
     "dvo_amd_exchange_create", "dvo_amd_exchange_attach", "dvo_amd_exchange_destroy",
     "dvo_amd_match_submit", "dvo_amd_match_wait", "dvo_amd_match_poll", "dvo_amd_debug_next_seq",
     "dvo_amd_set_reciprocal_mode", "dvo_amd_get_reciprocal_mode", "dvo_amd_debug_rcp", "dvo_amd_debug_block_trace",
+    "dvo_amd_debug_ll_overflow",
 ]
 
 
@@ -135,6 +136,8 @@ def lib():
     L.dvo_amd_set_reciprocal_mode.argtypes = [vp, C.c_int]
     L.dvo_amd_get_reciprocal_mode.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.dvo_amd_debug_rcp.argtypes = [vp, C.c_int, fp, fp]
+    L.dvo_amd_debug_ll_overflow.argtypes = [vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp,
+                                            C.POINTER(C.c_int)]
     L.dvo_amd_pyramid_create.argtypes = [C.c_int, fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
                                          C.c_float, C.c_int, C.c_double, C.POINTER(vp)]
     L.dvo_amd_pyramid_create_from_device.argtypes = [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
@@ -618,6 +621,18 @@ class DenseTracker:
                 "precision": np.array(pr.precision[:], np.float32).reshape(2, 2).T.copy(), "ll": float(pr.loglik),
                 "A": np.array(pr.information[:]).reshape(6, 6).T.copy(), "b": np.array(pr.rhs[:]),
                 "moments": np.array(pr.moments[:]), "scale_sums": np.array(pr.scale_sums[:]), "ll_sum": pr.loglik_sum}
+
+    def ll_overflow_probe(self, residuals, n_blocks: int, steps: int, seg_first: int, n_segs: int, rank_offset: int, rank_end: int,
+                          cut_rank: int, precision) -> bool:
+        """(test entry, dvo_amd_debug.h) k_ll_overflow over a caller-supplied residual buffer [n_blocks * 4 * 64 * steps, 2] for
+        the band of wave segments [seg_first, seg_first + n_segs); rank_end >= 0: a closed band"""
+        r = np.ascontiguousarray(residuals, dtype=np.float32)
+        assert r.shape == (n_blocks * 4 * 64 * steps, 2)
+        P = np.ascontiguousarray(np.asarray(precision, np.float32).T).ravel()
+        out = C.c_int(0)
+        _check(lib().dvo_amd_debug_ll_overflow(self._h, _fp(r), n_blocks, steps, seg_first, n_segs, rank_offset, rank_end, cut_rank,
+                                               _fp(P), C.byref(out)), "dvo_amd_debug_ll_overflow")
+        return bool(out.value)
 
     def computeIntensityErrorImage(self, reference, current, T, level: int = 0) -> np.ndarray:
         w, h, _ = reference.level_info(level)

@@ -42,7 +42,7 @@ class CVote(C.Structure):
 class CProposal(C.Structure):
     _fields_ = [("reference", C.c_int), ("current", C.c_int), ("initial_transformation", C.c_double * 16),
                 ("tracking_result", capi.CResult), ("n_votes", C.c_int), ("votes", CVote * MAX_VOTERS),
-                ("origin", C.c_int), ("reserved", C.c_int)]
+                ("origin", C.c_int), ("reserved", C.c_int), ("stage_initial_transformation", C.c_double * 16)]
 
 
 _bound = False
@@ -259,6 +259,7 @@ class ConstraintProposalValidator:
             p.TrackingResult = capi.Result(c.tracking_result, None)
             p.Votes = [Vote(c.votes[k]) for k in range(c.n_votes)]
             p.origin = c.origin  # instrumentation: index of the input proposal it descends from, -(i + 1) for its inverse
+            p.stage_initial = np.array(c.stage_initial_transformation[:]).reshape(4, 4).T  # ... what the last stage started from
             out.append(p)
         proposals[:] = out
         return proposals

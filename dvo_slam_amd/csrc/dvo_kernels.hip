@@ -289,8 +289,10 @@ __host__ __device__ constexpr int gram_pair(int ci, int cj) { return ci == 0 ? c
 //        through LDS (lane-per-point -> lane-per-component) and accumulated by v_mfma_f32_16x16x4_f32 into 2 x 4
 //        registers.  The MFMA sums over the points itself, so no 87-value wave reduction is needed and the kernel fits
 //        4 waves per SIMD (the 87-register form is capped at 2).
-// (Measured and removed in round 3, DESIGN.md section 10: the Gram matrix from 4x4-block MFMAs, a five-waves-per-SIMD build,
-// physical blocks walking several logical ones, item tables in device memory.)
+//        (round 4: as nine 4 x 4 tiles on v_mfma_f32_4x4x1_16b_f32 into 9 x 4 registers, DVO_GRAM_BLOCKS above -- the default;
+//        round 2's first 4x4 build had spills at four waves per SIMD and was dropped then.)
+// (Measured and removed in round 3, DESIGN.md section 10: a five-waves-per-SIMD build, physical blocks walking several logical
+// ones, item tables in device memory.)
 // RCP 0 (default): 1 / z of the projection is the exactly truncated quotient, the t-distribution weight 7 v_rcp_f32(5 + d).
 // RCP 1 (dvo_amd_set_reciprocal_mode): both reciprocals are the host's _mm_rcp_ps, bit for bit (dense_tracking_impl.cpp:192,700).
 template <int ACC, int RCP>
@@ -924,9 +926,18 @@ __global__ __launch_bounds__(kWave) void k_ll_overflow(const float2 *__restrict_
   const bool last_chunk = s1 >= seg_first + n_segs;
   const int e = !last_chunk ? rank_offset + seg_prefix[s1] : (rank_end >= 0 ? rank_end : 0x7fffffff);
   const int first = a + (50 - a % 50) % 50;                          // first group that starts in the chunk
-  const int stop = e >= cut_rank ? cut_rank                          // (cut_rank is a multiple of 50)
-                   : (last_chunk && rank_end >= 0) ? e - e % 50      // closed band: complete groups only
-                                                   : e + (50 - e % 50) % 50;  // ... else the end of the group that straddles the chunk's end
+  int stop = e >= cut_rank ? cut_rank                                // (cut_rank is a multiple of 50)
+             : (last_chunk && rank_end >= 0) ? e - e % 50            // closed band: complete groups only
+                                             : e + (50 - e % 50) % 50;  // ... else the end of the group that straddles the chunk's end
+  // A closed band: NO chunk may follow a group past the band's last valid pixel -- a chunk that is not the band's last one can
+  // still hold the start of the group that straddles the band edge when fewer than fifty valid pixels lie behind it (a depth
+  // hole at the band edge); the residuals behind the edge are another GPU's, this rank's copy of them is stale
+  int px_end = n_px;
+  if (rank_end >= 0) {
+    const int closed = rank_end - rank_end % 50;
+    stop = stop < closed ? stop : closed;
+    px_end = (seg_first + n_segs) * seg_px;
+  }
   if (first >= stop) return;
   int run = a, base = first;  // rank of the next valid pixel; rank of terms[0]
   bool overflow = false;
@@ -939,7 +950,7 @@ __global__ __launch_bounds__(kWave) void k_ll_overflow(const float2 *__restrict_
     }
     __syncthreads();
   };
-  for (int i0 = s0 * seg_px; i0 < n_px && run < stop; i0 += kWave) {
+  for (int i0 = s0 * seg_px; i0 < px_end && run < stop; i0 += kWave) {
     const float2 r = res[i0 + lane];  // (the buffer is padded to whole wave segments)
     const bool valid = r.x == r.x;
     const unsigned long long b = __ballot(valid);
@@ -1107,7 +1118,7 @@ struct LaunchGuard {
 };
 
 // DVO_AMD_ACCUM=valu: 87 register accumulators; default: the Gram matrix on the matrix pipe
-static int acc_mode() {
+int acc_mode() {
   static const int m = [] {
     const char *a = getenv("DVO_AMD_ACCUM");
     return (a && (a[0] == 'v' || a[0] == 'V' || a[0] == '0')) ? 0 : 1;
@@ -1171,7 +1182,7 @@ int tick_args_layout(TickArgs &args, int max_blocks) { return tick_args_layout_i
 int tick_args_layout(TickArgsSmall &args, int max_blocks) { return tick_args_layout_impl(args, max_blocks); }
 
 hipError_t launch_tick_small(const TickArgsSmall &args, int max_blocks, hipStream_t stream, hipEvent_t t_start, hipEvent_t t_stop) {
-  if (acc_mode() != 1 && !args.rcp.table) return hipErrorNotSupported;
+  if (acc_mode() != 1) return hipErrorNotSupported;  // (with or without the reciprocal table: launch_tick decides)
   if (args.n_items <= 0 || max_blocks <= 0) return hipSuccess;
   LaunchGuard guard;
   dim3 grid((unsigned)((max_blocks + 7) & ~7), (unsigned)args.n_items, 1);
@@ -1190,6 +1201,9 @@ hipError_t launch_tick_small(const TickArgsSmall &args, int max_blocks, hipStrea
 }
 
 hipError_t launch_tick(const TickArgs &args, int max_blocks, hipStream_t stream, hipEvent_t t_start, hipEvent_t t_stop) {
+  // the host-rcpps mode is built for the default accumulator only: under DVO_AMD_ACCUM=valu (the cross-check of the summation) it
+  // is refused rather than silently run on the matrix pipe (dvo_amd_set_reciprocal_mode refuses first, with the reason)
+  if (args.rcp.table && acc_mode() == 0) return hipErrorNotSupported;
   TickKernel kernel = pick_tick_kernel(args.rcp.table != nullptr);
   if (args.n_items <= 0 || max_blocks <= 0) return hipSuccess;
   LaunchGuard guard;

@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "../../include/dvo_amd.h"
+#include "../../include/dvo_amd_debug.h"
 #include "dvo_types.h"
 #include "se3.h"
 
@@ -1414,6 +1415,15 @@ int runner_fail(dvo_amd_context *ctx, int code) {
   return code;
 }
 
+// the same for a failure that goes straight back to the caller of the failing submit / wait / poll: that caller has been told,
+// so wait / poll of ticket 0 must not report it a second time after a clean run; the submissions that were
+// open keep their status and report it through their own tickets
+int runner_fail_told(dvo_amd_context *ctx, int code) {
+  (void)runner_fail(ctx, code);
+  ctx->runner->unreported_failure = DVO_AMD_OK;
+  return code;
+}
+
 // what wait / poll of `ticket` returns once the ticket is no longer open: the status its submission was dropped with, if it
 // was; ticket 0 ("everything submitted so far") reports a failure that no wait / poll has returned yet
 int runner_reported_status(Runner &R, unsigned long long ticket) {
@@ -1485,7 +1495,7 @@ int runner_drain(dvo_amd_context *ctx) {
     const size_t g = R.next_group;
     R.next_group = (R.next_group + 1) % R.groups.size();
     int rc = runner_step(ctx, g);
-    if (rc) return runner_fail(ctx, rc);
+    if (rc) return runner_fail_told(ctx, rc);
   }
   return DVO_AMD_OK;
 }
@@ -1707,7 +1717,11 @@ int sharded_overflow(dvo_amd_context *ctx, Job &j, int n_bands, int band, bool *
     off[b + 1] = off[b] + a.band_valid[b];
     ll_count[b] = std::max(0, std::min(a.cut_rank - off[b], a.band_valid[b]));  // this band's residuals that enter the likelihood
     head_len[b] = std::min((50 - off[b] % 50) % 50, ll_count[b]);
-    tail_cnt[b] = (ll_count[b] - head_len[b]) % 50;
+    // the trailing partial group of a band is completed by the next band only when the band's whole tail enters the likelihood;
+    // when the cut falls inside the band (ll_count < band_valid) nothing behind it counts (cut_rank is a multiple of 50: the
+    // residuals up to it end on a group boundary) -- and edge_terms(forward = false) would read the band's LAST residuals, which
+    // are not the ones ranked below the cut
+    tail_cnt[b] = ll_count[b] < a.band_valid[b] ? 0 : (ll_count[b] - head_len[b]) % 50;
   }
   // 1. the groups inside this rank's band
   int first = 0, count = 0;
@@ -2182,6 +2196,10 @@ int dvo_amd_set_reciprocal_mode(dvo_amd_context *ctx, int mode) {
     ctx->rcp = RcpTable{nullptr, 0, 0};
     return DVO_AMD_OK;
   }
+  if (acc_mode() == 0) {  // (the mode used to run the matrix-pipe accumulator silently under the switch)
+    g_last_error = "the host-rcpps mode is built for the default accumulator only: unset DVO_AMD_ACCUM=valu";
+    return DVO_AMD_ERR_INVALID_ARGUMENT;
+  }
   const HostRcp &h = host_rcp_table();
   if (!h.problem.empty()) {
     g_last_error = "the host's _mm_rcp_ps cannot be reproduced from a table: " + h.problem;
@@ -2384,7 +2402,7 @@ int dvo_amd_match_submit(dvo_amd_context *ctx, int n, dvo_amd_pyramid *const *re
   for (size_t g = 0; g < R.groups.size(); ++g)
     if (!R.groups[g].in_flight) {
       rc = runner_step(ctx, g);
-      if (rc) return runner_fail(ctx, rc);
+      if (rc) return runner_fail_told(ctx, rc);
     }
   return DVO_AMD_OK;
 }
@@ -2405,7 +2423,7 @@ int dvo_amd_match_wait(dvo_amd_context *ctx, unsigned long long ticket) {
     const size_t g = R.next_group;
     R.next_group = (R.next_group + 1) % R.groups.size();
     int rc = runner_step(ctx, g);
-    if (rc) return runner_fail(ctx, rc);
+    if (rc) return runner_fail_told(ctx, rc);
   }
   while (!R.batches.empty() && R.batches.front().remaining == 0) R.batches.pop_front();
   return runner_reported_status(R, ticket);
@@ -2422,7 +2440,7 @@ int dvo_amd_match_poll(dvo_amd_context *ctx, unsigned long long ticket, int *don
   for (size_t g = 0; g < R.groups.size(); ++g) {
     if (R.groups[g].in_flight && !tick_landed(ctx, R.jobs, R.groups[g])) continue;
     int rc = runner_step(ctx, g);
-    if (rc) return runner_fail(ctx, rc);
+    if (rc) return runner_fail_told(ctx, rc);
   }
   for (const Batch &b : R.batches)
     if ((ticket == 0 || b.id == ticket) && b.remaining > 0) *done = 0;
@@ -2919,6 +2937,44 @@ int dvo_amd_bench_residual_pass(dvo_amd_context *ctx, dvo_amd_pyramid *reference
   if (n_items < 1 || n_items > 1024) return DVO_AMD_ERR_INVALID_ARGUMENT;
   std::vector<dvo_amd_pyramid *> r((size_t)n_items, reference), c((size_t)n_items, current);
   return dvo_amd_bench_residual_pass_pairs(ctx, n_items, r.data(), c.data(), level, T, rounds, reps, avg_ms, alg_bytes, n_launches);
+}
+
+int dvo_amd_debug_ll_overflow(dvo_amd_context *ctx, const float *residuals, int n_blocks, int steps, int seg_first, int n_segs,
+                              int rank_offset, int rank_end, int cut_rank, const float *precision, int *overflowed) {
+  if (!ctx || !residuals || !precision || !overflowed || n_blocks < 1 || steps < 1 || seg_first < 0 || n_segs < 1 ||
+      seg_first + n_segs > n_blocks * kWavesPerBlock)
+    return DVO_AMD_ERR_INVALID_ARGUMENT;
+  int rc = queue_must_be_idle(ctx, "dvo_amd_debug_ll_overflow");
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int seg_px = kStepPx * steps, n_px = n_blocks * kWavesPerBlock * seg_px;
+  // the prefix table as k_finalize leaves it: valid pixels of the band before each of its wave segments
+  std::vector<int> prefix((size_t)n_blocks * kWavesPerBlock, 0);
+  int run = 0;
+  for (int sgi = seg_first; sgi < seg_first + n_segs; ++sgi) {
+    prefix[(size_t)sgi] = run;
+    for (int i = 0; i < seg_px; ++i) {
+      const float x = residuals[2 * ((size_t)sgi * seg_px + i)];
+      run += x == x ? 1 : 0;
+    }
+  }
+  float2 *res_dev = nullptr;
+  int *prefix_dev = nullptr;
+  HIP_TRY(hipMalloc((void **)&res_dev, sizeof(float2) * (size_t)n_px));
+  hipError_t e = hipMalloc((void **)&prefix_dev, sizeof(int) * prefix.size());
+  if (e == hipSuccess) e = hipMemcpy(res_dev, residuals, sizeof(float2) * (size_t)n_px, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(prefix_dev, prefix.data(), sizeof(int) * prefix.size(), hipMemcpyHostToDevice);
+  bool ovf = false;
+  if (e == hipSuccess) {
+    OvfBand ob;
+    ob.seg_first = seg_first, ob.n_segs = n_segs, ob.rank_offset = rank_offset, ob.rank_end = rank_end;
+    rc = ll_overflowed(ctx, res_dev, prefix_dev, n_blocks, steps, cut_rank, precision, &ob, 1, &ovf);
+  }
+  (void)hipFree(res_dev);
+  if (prefix_dev) (void)hipFree(prefix_dev);
+  if (e != hipSuccess) return fail_hip("dvo_amd_debug_ll_overflow", e);
+  *overflowed = ovf ? 1 : 0;
+  return rc;
 }
 
 long long dvo_amd_debug_block_trace(dvo_amd_context *ctx, unsigned long long *out, long long capacity_blocks) {

@@ -305,6 +305,8 @@ long long read_block_trace(unsigned long long *out, long long capacity);  // -1:
 // out[i] = the table reciprocal of in[i] (device pointers): the unit test of the opt-in host-rcpps mode
 hipError_t launch_rcp_table_probe(const RcpTable &rcp, const float *in, float *out, int n, hipStream_t stream);
 
+int acc_mode();  // 1: Gram matrix on the matrix pipe (default); 0: DVO_AMD_ACCUM=valu, the 87-register cross-check form
+
 // prep (pyramid construction) kernels
 hipError_t launch_pyr_down(const float *i_prev, const float *z_prev, int w_prev, float *i_out, float *z_out, int w, int h,
                            hipStream_t stream);

@@ -336,6 +336,7 @@ int dvo_amd_validate_proposals(dvo_amd_context *ctx, int n_keyframes, const dvo_
       for (size_t i = 0; i < n; ++i) {
         refs[i] = keyframes[live[i].p.reference].image, curs[i] = keyframes[live[i].p.current].image;
         std::memcpy(&inits[16 * i], live[i].p.initial_transformation, sizeof(double) * 16);
+        std::memcpy(live[i].p.stage_initial_transformation, live[i].p.initial_transformation, sizeof(double) * 16);  // (instrumentation)
         std::memset(&results[i], 0, sizeof(dvo_amd_result));
         results[i].iterations = &its[i * (size_t)its_per_pair];
         results[i].iterations_capacity = its_per_pair;

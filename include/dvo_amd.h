@@ -141,21 +141,18 @@ int dvo_amd_context_device(const dvo_amd_context *ctx, int *device);
  *   DVO_AMD_RCP_EXACT (default): 1 / z of the projection is the exactly truncated quotient, the weight's reciprocal is within
  *     1 ulp: the same on every machine.
  *   DVO_AMD_RCP_HOST_SSE: both are THIS HOST's _mm_rcp_ps, bit for bit, from a table probed on the host when the mode is
- *     switched on (2^11 entries on the Xeons / EPYCs seen so far): residuals and validity decisions are then bit-identical to
- *     the reference's SSE path as this host runs it.  (The reference uses an exact division for the last V mod 4 weights,
- *     :702-706; here every weight uses the table.)  Returns DVO_AMD_ERR_INVALID_ARGUMENT with a reason in dvo_amd_last_error()
- *     if the host's instruction does not have the structure the table assumes; refused while pairs are queued.
+ *     switched on (2^11 or 2^12 entries on the Xeons / EPYCs seen so far): residuals and validity decisions are then
+ *     bit-identical to the reference's SSE path as this host runs it, and so is every t-distribution weight except the last
+ *     V mod 4 of an iteration (the reference divides exactly there, :702-706; here every weight uses the table: <= 3 pixels
+ *     of ~200 000, a stated deviation -- whole-match parity in this mode is therefore not bit-for-bit).  Returns
+ *     DVO_AMD_ERR_INVALID_ARGUMENT with a reason in dvo_amd_last_error() if the host's instruction does not have the
+ *     structure the table assumes, or under DVO_AMD_ACCUM=valu (the mode is built for the default accumulator only); refused
+ *     while pairs are queued.
  * DVO_AMD_RCP=host in the environment makes it the default of every new context. */
 #define DVO_AMD_RCP_EXACT 0
 #define DVO_AMD_RCP_HOST_SSE 1
 int dvo_amd_set_reciprocal_mode(dvo_amd_context *ctx, int mode);
 int dvo_amd_get_reciprocal_mode(const dvo_amd_context *ctx, int *mode, int *table_mantissa_bits);
-/* (diagnostic; libraries built with -DDVO_TRACE_BLOCKS only, else -1) the per-block trace of every k_tick block since the last
- * call: 4 x 64-bit words per block {start, after the first step, end (100 MHz clock), info | hw_id << 32}; returns the number of
- * blocks recorded and resets the trace.  scripts/block_trace.py */
-long long dvo_amd_debug_block_trace(dvo_amd_context *ctx, unsigned long long *out, long long capacity_blocks);
-/* (test entry) out[i] = the table reciprocal of in[i] as the kernels compute it; needs DVO_AMD_RCP_HOST_SSE */
-int dvo_amd_debug_rcp(dvo_amd_context *ctx, int n, const float *in, float *out);
 int dvo_amd_configure(dvo_amd_context *ctx, const dvo_amd_config *cfg);
 int dvo_amd_get_config(const dvo_amd_context *ctx, dvo_amd_config *cfg);
 
@@ -277,21 +274,6 @@ int dvo_amd_match_sharded(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_
                           dvo_amd_result *result);
 int dvo_amd_match_banded(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, const double *T_init,
                          dvo_amd_result *result, int n_bands);
-/* host-only: the ordered combine of band records {valid, first_w, last_r0, last_r1, S[3], S_odd[3]} (10 doubles per band)
- * -> {valid, S[3], S_odd[3]}; exported for the CPU tests of the multi-GPU path */
-int dvo_amd_debug_combine_bands(int n_bands, const double *bands, double *out);
-/* host-only: the receiving side of the record hand-off.  A tick's 784-byte record reaches the host (and, for a sharded pair,
- * the peers) as `*n_pieces` pieces of 16 bytes -- two 8-byte halves {payload word, tick number} -- each written by one store
- * of the device; a piece counts when BOTH its tags are the tick waited for, in whatever order the pieces arrive (so a piece
- * that should ever arrive as two 8-byte halves is simply not accepted until both are there).
- * dvo_amd_debug_wire_layout reports the piece and payload-word counts; dvo_amd_debug_take_wire copies the payload of the
- * pieces from `from_piece` on that carry `tick` out of `wire` (16-byte aligned, 4 words per piece) into `record_words`
- * and returns the index of the first piece that does not (n_pieces when the record is complete), or minus an error code.
- * Exported for the CPU tests. */
-/* host-only: the successor of a tick number (32 bits; never 0, the value of a fresh buffer; the wrap keeps the parity alternating) */
-unsigned dvo_amd_debug_next_seq(unsigned seq);
-int dvo_amd_debug_wire_layout(int *n_pieces, int *n_record_words);
-int dvo_amd_debug_take_wire(const unsigned *wire, unsigned tick, int from_piece, unsigned *record_words);
 
 /*
  * Batched 2-stage loop-closure validation: dvo_slam::constraints::ConstraintProposalValidator::validate
@@ -359,6 +341,10 @@ typedef struct {
    * compare a survivor with the alignment of the SAME (reference, current, initial transformation) on its own side. */
   int origin;
   int reserved;
+  /* instrumentation, out only: the initial transformation the LAST stage aligned this proposal from (initial_transformation
+   * above is updated behind every stage to the inverse of the stage's estimate, validator.cpp:95-100, and the inverse proposals
+   * of the cross-validation are formed inside the call): what a checker needs to repeat exactly this alignment */
+  double stage_initial_transformation[16];
 } dvo_amd_constraint_proposal;
 
 /* the two stages KeyframeGraph builds (keyframe_graph.cpp:500-523) with the tracker configs of configureValidationTracking
@@ -422,57 +408,10 @@ int dvo_amd_format_trajectory_line(double timestamp, const double *T, char *buf,
  * selected or its warp is invalid.  Used by the parity tests and by dvo_amd_error_image. */
 int dvo_amd_residuals(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, int level,
                       const float *T, float *residuals, int *n_valid);
-/* Stage-wise probe of ONE Gauss-Newton iteration body at a fixed pose (dense_tracking.cpp:271-347 without the accept test and
- * the solve): computeResidualsSse, computeWeightsSse (unit weights when precision_in is NULL = first iteration of a level,
- * else the t-distribution weights of the column-major 2x2 precision_in), computeScaleSse + inverse, the normal equations
- * (Mu = 0) and computeCompleteDataLogLikelihood, through exactly the kernels and host arithmetic dvo_amd_match uses (two
- * ticks).  Exists so that the parity tests can compare the weighted stages (iterations k >= 1) with their CPU checker directly
- * instead of only through the final pose. */
-typedef struct {
-  int valid_constraints;
-  int reserved;
-  double scale_sums[3];   /* unscaled pair sums (xx, xy, yy) of computeScaleSse incl. the Q5 pairing */
-  float scale[4];         /* column-major 2x2: sums / (V - 3) */
-  float precision[4];     /* its inverse (Eigen Matrix2f::inverse) */
-  double moments[87];     /* the P-free sums (layout: dvo_types.h kAcc*) */
-  double information[36]; /* A = sum w J^T P J, column-major 6x6 */
-  double rhs[6];          /* b = -sum w J^T P r */
-  double loglik_sum;      /* sum of log(1 + 0.2 r^T P r) over the first 50 floor(V/50) valid residuals (Q6) */
-  float loglik;           /* what computeCompleteDataLogLikelihood returns */
-  float reserved_f;
-} dvo_amd_iteration_probe;
-/* precision_eval (column-major 2x2, may be NULL): evaluate information / rhs / loglik with this precision instead of the one the
- * probe computed itself (out->precision is the computed one either way) */
-int dvo_amd_debug_iteration(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, int level,
-                            const float *T, const float *precision_in, const float *precision_eval,
-                            dvo_amd_iteration_probe *out);
 /* DenseTracker::computeIntensityErrorImage, dense_tracking.cpp:378-444: |intensity residual| per reference pixel, 0 elsewhere */
 int dvo_amd_error_image(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, const double *T,
                         int level, float *image);
 
-/* Micro-benchmark of the dominant kernel alone (used by bench.py for the roofline figure and by the tuning scripts):
- * `reps` timed repetitions of the fused residual pass over `n_items` copies of one (reference level, current level) pair
- * at the float transform T (column-major 4x4), `rounds` 256-pixel rounds (four 64-pixel steps each) per wave segment (1, 2, 4, 8 or 16; 0 = the driver's choice).
- * avg_ms: HIP-event time per repetition on the context's stream; alg_bytes: 56 B x selected points x n_items;
- * n_launches: kernel launches one repetition needs (the argument block holds 62 items). */
-int dvo_amd_bench_residual_pass(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, int level,
-                                const float *T, int n_items, int rounds, int reps, double *avg_ms, double *alg_bytes,
-                                int *n_launches);
-
-/* the same over n_items DIFFERENT (reference, current) pairs (same size): no two items of a launch read the same planes, so
- * nothing is deduplicated by the caches */
-int dvo_amd_bench_residual_pass_pairs(dvo_amd_context *ctx, int n_items, dvo_amd_pyramid *const *references,
-                                      dvo_amd_pyramid *const *currents, int level, const float *T, int rounds, int reps,
-                                      double *avg_ms, double *alg_bytes, int *n_launches);
-
-/* Diagnostic: with DVO_AMD_FIN_STAMPS=1 in the environment the finalize kernel records 8 shader-clock stamps of its phases
- * (block 0 of the most recent launch); this reads them back. */
-int dvo_amd_debug_finalize_stamps(dvo_amd_context *ctx, unsigned long long *stamps8);
-
-/* Diagnostic: while dvo_amd_kernel_timing is enabled every k_tick launch is logged as 8 doubles {ms, items, residual-pass
- * blocks, likelihood blocks, grid.x, selected reference pixels of the residual items, 64-pixel wave steps of the residual
- * items, 64-pixel wave steps of the likelihood items}; this reads and clears the log (out may be NULL to query the count). */
-int dvo_amd_debug_tick_log(dvo_amd_context *ctx, double *out, int capacity_records, int *n_records);
 
 /* Host-side helpers (no GPU needed): the SE(3) exponential / logarithm with Sophus' tangent order (upsilon, omega) and the
  * pivoted LDL^T 6x6 solve the driver uses in place of Sophus::SE3d::exp/log and Eigen::LDLT (dense_tracking.cpp:238,259,347).
@@ -481,9 +420,10 @@ void dvo_amd_se3_exp(const double *xi, double *T);
 void dvo_amd_se3_log(const double *T, double *xi);
 void dvo_amd_solve6(const double *A, const double *b, double *x);
 
-/* timing helper for bench.py: HIP-event milliseconds the context's stream spent in its residual-pass kernel since the last
- * reset, and the number of launches */
-int dvo_amd_kernel_timing(dvo_amd_context *ctx, int enable, double *ms_residual_pass, long long *n_launches, int reset);
+
+/* Test probes, diagnostics and micro-benchmarks (dvo_amd_debug_*, dvo_amd_bench_*, dvo_amd_kernel_timing) are exported by the
+ * same library but declared in dvo_amd_debug.h: they are scaffolding of this repository's tests and bench, not part of the
+ * boundary a caller of the reference would bind. */
 
 #ifdef __cplusplus
 }

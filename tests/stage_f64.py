@@ -12,6 +12,16 @@ def f64_iteration(orc, orr, occ, level, T, prec_in, P_eval, ti=0.0, td=0.0, rcp_
     n = len(r)
     if prec_in is None:
         wg = np.ones(n)
+    elif rcp_mode is not None and rcp_mode == orc.RCP_SSE:
+        # the rcpps mode's weights are 7 * rcpps(5 + d) (dense_tracking_impl.cpp:700), off the exact quotient by up to 2^-12 in ONE
+        # direction per table cell: "the same terms, summed exactly" must take the weights as that mode forms them
+        import ctypes as C
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+        res32 = np.ascontiguousarray(res, np.float32)
+        pin = np.ascontiguousarray(np.asarray(prec_in, np.float32).T).ravel()
+        w32, cov, P = np.zeros(max(n, 1), np.float32), np.zeros(4, np.float32), np.zeros(4, np.float32)
+        orc.lib().orc_weights_scale_loglik(fp(res32), n, fp(pin), 0, rcp_mode, fp(w32), fp(cov), fp(P))
+        wg = w32[:n].astype(np.float64)
     else:
         d = np.einsum("ni,ij,nj->n", r, np.asarray(prec_in, np.float64), r)
         wg = 7.0 / (5.0 + d)

@@ -1,4 +1,4 @@
-"""CPU tests of the C-ABI library: it loads, exports every symbol include/dvo_amd.h declares, its host-side helpers are
+"""CPU tests of the C-ABI library: it loads, exports every symbol include/dvo_amd.h and include/dvo_amd_debug.h declare, its host-side helpers are
 correct, and without a GPU every compute entry point fails loudly (there is no CPU fallback in the product path)."""
 import ctypes as C
 import os
@@ -18,15 +18,19 @@ def capi():
     return c
 
 
-def _declared_functions():
-    text = open(os.path.join(ROOT, "include", "dvo_amd.h")).read()
+def _declared_functions(header="dvo_amd.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(dvo_amd_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol(capi):
-    declared = _declared_functions()
-    assert len(declared) >= 20
+    boundary, scaffolding = _declared_functions(), _declared_functions("dvo_amd_debug.h")
+    # the boundary header holds no test probe, diagnostic or micro-benchmark; the debug header holds nothing else
+    assert not [n for n in boundary if "_debug_" in n or "_bench_" in n or n == "dvo_amd_kernel_timing"]
+    assert all("_debug_" in n or "_bench_" in n or n == "dvo_amd_kernel_timing" for n in scaffolding) and len(scaffolding) >= 10
+    declared = sorted(set(boundary + scaffolding))
+    assert len(boundary) >= 20
     L = capi.lib()
     missing = [name for name in declared if not hasattr(L, name)]
     assert not missing, missing

@@ -310,8 +310,11 @@ def _check_match(capi, orc, synth, g_ref, g_cur, o_ref, o_cur, cfg_kw, T_init=No
         _PATHS.setdefault("fork_err", []).append(err)
     if same_path:
         assert err <= tol, err
-        # every Gauss-Newton iteration, not only the final pose
-        n_it, n_same_v = _compare_iterations(rg.Levels, _oracle_levels(ro), label, count_slack=count_slack, increment_band=increment_band)
+        # every Gauss-Newton iteration, not only the final pose; a constraint count that differs from the oracle's (pose drift) is
+        # held to the reference's residual stage at the GPU's own pose, exactly (fork_criterion.count_probe)
+        n_it, n_same_v = fork_criterion.compare_iterations(fork_criterion.gpu_levels(rg), fork_criterion.oracle_levels(ro), label,
+                                                           count_slack=count_slack, increment_band=increment_band,
+                                                           probe=fork_criterion.count_probe(orc, ocfg, o_ref, o_cur))
         print(f"[iterations] {label}: {n_it} compared, {n_same_v} with identical ValidConstraints, pose err {err:.2e}")
     else:
         # no blanket tolerance and nothing sampled: the flipped decision is adjudicated, the oracle is continued from the GPU's own
@@ -323,8 +326,11 @@ def _check_match(capi, orc, synth, g_ref, g_cur, o_ref, o_cur, cfg_kw, T_init=No
         for Lg, Lo in zip(rg.Levels, ro["levels"]):
             if len(Lg["Iterations"]) != len(Lo["iterations"]) or Lg["TerminationCriterion"] != Lo["termination"]:
                 break
-            _compare_iterations([Lg], _oracle_levels({"levels": [Lo]}), label + " (prefix)", first_is_identical=Lg is rg.Levels[0],
-                                count_slack=count_slack, increment_band=increment_band)
+            li = rg.Levels.index(Lg)
+            fork_criterion.compare_iterations(fork_criterion.gpu_levels(rg), fork_criterion.oracle_levels(ro), label + " (prefix)",
+                                              start=(li, 0), until=(li, len(Lg["Iterations"]) - 1), first_is_identical=li == 0,
+                                              count_slack=count_slack, increment_band=increment_band,
+                                              probe=fork_criterion.count_probe(orc, ocfg, o_ref, o_cur))
     assert rg.isNaN() == ro["is_nan"]
     assert [L["Id"] for L in rg.Levels] == [L["id"] for L in ro["levels"]]
     for Lg, Lo in zip(rg.Levels, ro["levels"]):
@@ -1147,6 +1153,43 @@ def test_sharded_overflow_verdict_with_a_single_rank(capi, synth, exchange):
         assert [(L["TerminationCriterion"], len(L["Iterations"])) for L in a.Levels] == [(L["TerminationCriterion"], len(L["Iterations"])) for L in b.Levels]
         assert np.array_equal(a.Transformation, b.Transformation)
     assert n_inf >= 1
+
+
+def test_closed_band_never_reads_behind_its_edge(capi):
+    """ADVICE round 4.  k_ll_overflow on a CLOSED band (a rank of a tile-sharded pair: the residuals behind the band are another
+    GPU's, this rank's copy of them is stale).  A chunk of the band that is not its last one can still hold the start of the group
+    of fifty that straddles the band edge -- when fewer than fifty valid pixels lie behind it (a depth hole at the band edge).
+    Until round 4 only the band's LAST chunk stopped at the last complete group: the other chunk walked on into the stale data
+    and could raise an overflow no single-GPU match() sees.  The buffer here: a band of two chunks (16 wave segments); chunk 0
+    holds 1001 valid residuals (group [1000, 1050) starts in it), chunk 1 five and then a hole, and behind the band stale
+    residuals whose fifty-term product overflows."""
+    trk = capi.DenseTracker(capi.Config(FirstLevel=0, LastLevel=0))
+    steps, n_blocks, seg_px = 2, 8, 128
+    n_px = n_blocks * 4 * seg_px
+    P = np.array([[1e9, 0.0], [0.0, 1e9]], np.float32)
+    res = np.full((n_px, 2), np.nan, np.float32)
+    res[:1001] = 1e-6                      # chunk 0 (segments 0..7 = 1024 pixels): terms 1 + 0.2 * 2e-3
+    res[1024:1029] = 1e-6                  # chunk 1: five valid pixels, then the hole up to the band edge (pixel 2048)
+    res[2048:] = 1e3                       # behind the band: q = 2e15 per pixel, fifty of them overflow a double
+    band_valid = 1006
+    kw = dict(n_blocks=n_blocks, steps=steps, seg_first=0, n_segs=16, rank_offset=0, cut_rank=5000, precision=P)
+    assert trk.ll_overflow_probe(res, rank_end=band_valid, **kw) is False      # closed: group [1000, 1050) is the host's business
+    assert trk.ll_overflow_probe(res, rank_end=-1, **kw) is True               # open band: the same walk may (and must) run on
+    # a band that starts inside a group (rank_offset 30): its first complete group is [50, 100) = its pixels 20..69
+    assert trk.ll_overflow_probe(res, rank_end=30 + band_valid, **dict(kw, rank_offset=30)) is False
+    inside = res.copy()
+    inside[520:570] = 1e3                  # ranks 520..569 of the band: group [550, 600) holds 20 huge terms only ...
+    assert trk.ll_overflow_probe(inside, rank_end=band_valid, **kw) is False
+    inside[500:550] = 1e3                  # ... now group [500, 550) is all huge: overflows inside the band
+    assert trk.ll_overflow_probe(inside, rank_end=band_valid, **kw) is True
+    # the last chunk of a closed band: 60 valid pixels behind the last group boundary, none of them judged
+    tail = np.full((n_px, 2), np.nan, np.float32)
+    tail[:1000] = 1e-6
+    tail[1024:1084] = 1e3                  # ranks 1000..1059: group [1000, 1050) is complete INSIDE the band: judged, overflows
+    assert trk.ll_overflow_probe(tail, rank_end=1060, **kw) is True
+    tail[1024:1084] = np.nan
+    tail[1024:1064] = 1e3                  # ranks 1000..1039 only: the group is completed by the next rank
+    assert trk.ll_overflow_probe(tail, rank_end=1040, **kw) is False
 
 
 def test_sharded_match_with_single_rank_peer_exchange(capi, synth, pair640, monkeypatch):

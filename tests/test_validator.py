@@ -215,7 +215,10 @@ def _like_with_like(orc, synth, ov, stage, g_props, notes, sensor=False):
             key = tuple(getattr(ocfg, f) for f, _ in ocfg._fields_)
             if key not in _REMATCH:
                 _REMATCH[key] = capi.DenseTracker(fork_criterion.gpu_config_of(capi, ocfg))
-            rg = _REMATCH[key].match(p.Reference.image, p.Current.image, init)
+            # the very alignment the validator ran: the initial transformation it started this proposal from (the inverse proposals
+            # of the cross-validation are formed inside the call; theirs differs from the oracle's numpy inverse in the last bit)
+            assert np.allclose(p.stage_initial, init, rtol=0, atol=1e-13)
+            rg = _REMATCH[key].match(p.Reference.image, p.Current.image, p.stage_initial)
             forked, report = fork_criterion.settle(orc, synth, ocfg, ov.images[rid], ov.images[cid], init, rg, ro, POSE_TOL,
                                                    batch_T=p.TrackingResult.Transformation, count_slack=40 if sensor else None,
                                                    increment_band=0.05 if sensor else 0.0)
