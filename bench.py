@@ -54,6 +54,13 @@ def parse():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the informational side measurements (cache-resident variant, STREAM copy, frame ingest, "
                          "loop-closure validator, all-core CPU baseline); rank 0 at N=1 only")
+    ap.add_argument("--counter-leg", action="store_true",
+                    help="the short run a rocprofv3 counter pass profiles (bench.py starts two of them itself, see "
+                         "--no-live-counters): like --no-extras --no-cpu-baseline, and without the single-pair latency probe and the "
+                         "timed-region check")
+    ap.add_argument("--no-live-counters", action="store_true",
+                    help="do not run the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) as child processes of this run; "
+                         "roofline.traffic then comes from the committed profile of the same command (traffic_source says which)")
     ap.add_argument("--tile-shard", action="store_true",
                     help="BASELINE config 4 instead of the default: ONE pair at a time, every level tile-sharded over the "
                          "N GPUs with a per-iteration exchange of the band records (strong scaling, expected to be "
@@ -74,6 +81,10 @@ def parse():
                          "delivered, as the reference's callers read them (keyframe_tracker.cpp:167, "
                          "constraint_proposal_voter.cpp:128)")
     args = ap.parse_args()
+    if args.counter_leg:
+        args.no_extras = args.no_cpu_baseline = True
+    if args.no_extras:
+        args.no_live_counters = True  # (the counter passes are a side measurement of the full line)
     big = args.width >= 1280
     if args.threads is None:
         args.threads = 8 if big else 6
@@ -300,17 +311,20 @@ def main():
     # single-pair latency (informational)
     n_lat = 10
     lat_rounds = []
-    for _ in range(3):  # the median of three rounds of ten: one round is at the mercy of whatever the box does in those 7 ms
+    for _ in range(0 if args.counter_leg else 3):  # the median of three rounds of ten: one round is at the mercy of whatever the box does in those 7 ms
         t0 = time.perf_counter()
         for i in range(n_lat):
             r1 = trk.match(ref, curs[i % len(curs)])
         lat_rounds.append((time.perf_counter() - t0) * 1e3 / n_lat)
-    single_ms = sorted(lat_rounds)[1]
+    single_ms = sorted(lat_rounds)[1] if lat_rounds else None
 
     # With one host thread the HIP events around every k_tick launch are taken inside the timed region.  With several
     # threads kernels of different streams overlap on the GPU, so the per-launch durations are measured in a second,
     # single-stream pass of the same batch right after the timed region.
+    # The launches the per-launch roofline figures describe are bracketed by two no-op dispatches named k_marker, so that a
+    # profiler's summary can pick exactly them (dvo_slam_amd/pmc.py).
     if T == 1:
+        trk.marker(1)
         trk.kernel_timing(True, reset=True)
     sync_all()
     t0 = time.perf_counter()
@@ -319,7 +333,9 @@ def main():
     run_steps(args.steps, col, keep=kept)
     sync_all()
     elapsed = time.perf_counter() - t0
-    region_check = check_timed_region(capi, synth, cfg, device, kept, refs, curb)
+    if T == 1:
+        trk.marker(2)
+    region_check = None if args.counter_leg else check_timed_region(capi, synth, cfg, device, kept, refs, curb)
     alg_bytes = sum(c[0] for c in col)
     discarded_bytes = sum(c[4] for c in col)
     passes = sum(c[1] for c in col)
@@ -331,10 +347,12 @@ def main():
         log = trk.tick_log()
     else:
         # one host thread's share of the batch, same residency as in the timed region, on one stream
+        trk.marker(1)
         trk.kernel_timing(True, reset=True)
         idx0 = shares[0]
         out = trk.match_batch([refs[i] for i in idx0], [curb[i] for i in idx0], stats=False, in_flight=args.in_flight)
         k_ms, k_launches = trk.kernel_timing(False)
+        trk.marker(2)
         log = trk.tick_log()
         alg_bytes_k = sum(o.alg_bytes for o in out)
         discarded_k = sum(o.alg_bytes_discarded for o in out)
@@ -422,11 +440,12 @@ def main():
             "build_id": capi.build_id(),
             "iterations_per_pair": iterations_delivered / max(1, B * args.steps),
             "timed_region_check": region_check,
-            "max_deviation_from_single_match": region_check["max_deviation_from_single_match"],
+            "max_deviation_from_single_match": region_check["max_deviation_from_single_match"] if region_check else None,
             "single_pair_latency_ms": single_ms,
             "prep_ms_per_frame": prep_ms,
             "prep_ms_per_frame_first_use": prep_first_ms,
-            "end_to_end_ms_per_frame_one_stream": prep_ms + single_ms,  # build the new frame's pyramid from host planes + one match()
+            # build the new frame's pyramid from host planes + one match()
+            "end_to_end_ms_per_frame_one_stream": None if single_ms is None else prep_ms + single_ms,
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved,
@@ -438,8 +457,8 @@ def main():
                                "upper-level view, not the bytes HBM actually moved: see `traffic` and `issue`",
                 "speculation_waste": {"discarded_fraction_of_submitted_bytes": (discarded_k / alg_bytes_k) if alg_bytes_k else None,
                                       "achieved_counting_discarded_passes": alg_bytes_k / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0},
-                "traffic": traffic_from_profiles(args),
-                "traffic_source": traffic_source(args),
+                "traffic": None,          # filled in below: roofline_traffic()
+                "traffic_source": None,
                 "kernel": "k_tick (fused warp+residual+weights+normal equations, with the log-likelihood items of the tick)",
                 "launches": int(k_launches),
                 "avg_launch_us": (k_ms * 1e3 / k_launches) if k_launches else None,
@@ -458,7 +477,10 @@ def main():
                 "issue": issue_roofline(log, k_ms),
             },
         }
+        line["roofline"]["traffic"], line["roofline"]["traffic_source"] = roofline_traffic(args, world, line)
         try:
+            if args.no_extras:  # (a counter / trace pass must not find batch-form k_tick launches behind the timing pass)
+                raise RuntimeError("skipped under --no-extras")
             # (8 steps per wave: what suits a launch that has the GPU to itself; the driver's own choice for this many pixels is
             # 16, tuned for launches that share the GPU with three others)
             ms_i, ab_i, nl_i = trk.bench_residual_pass(ref, curs[0], 0, cur_pose(0), 36, 2, reps=20)
@@ -614,7 +636,8 @@ def stats_variant(run_steps, B, args, with_stats):
 SIMDS = 256 * 4
 PEAK_CLOCK_HZ = 2.4e9
 VALU_ISSUE_CYCLES = 4   # one fp32 VALU wave instruction holds its SIMD for 4 cycles (measured: profiles/r04_issue.json)
-MFMA_ISSUE_CYCLES = 32  # v_mfma_f32_16x16x4_f32 (MI355X_MICROARCH.md); the profile file says 8 for the nine-tile form (v_mfma_f32_4x4x1_16B_f32)
+MFMA_ISSUE_CYCLES = 8   # v_mfma_f32_4x4x1_16b_f32, the nine-tile Gram form (8.9 measured back to back, scripts/probes/mfma_4x4_blocks.hip)
+ISSUE_FILES = ("r05_issue.json", "r04_issue.json")  # the newest committed PMC pass of the kernel that exists
 
 
 def issue_roofline(log, k_ms):
@@ -623,7 +646,8 @@ def issue_roofline(log, k_ms):
     the likelihood pass); the steps are this run's (tick log); peak = every SIMD issuing every cycle at the 2.4 GHz peak clock."""
     try:
         here = os.path.dirname(os.path.abspath(__file__))
-        c = json.load(open(os.path.join(here, "profiles", "r04_issue.json")))
+        name = next(f for f in ISSUE_FILES if os.path.exists(os.path.join(here, "profiles", f)))
+        c = json.load(open(os.path.join(here, "profiles", name)))
         res_steps, ll_steps = float(log[:, 6].sum()), float(log[:, 7].sum())
         mfma_cyc = c.get("mfma_issue_cycles", MFMA_ISSUE_CYCLES)
         cyc = (res_steps * (c["valu_per_res_step"] * VALU_ISSUE_CYCLES + c["mfma_per_res_step"] * mfma_cyc)
@@ -632,7 +656,9 @@ def issue_roofline(log, k_ms):
         return {"bound": "VALU+MFMA issue", "valu_per_res_step": c["valu_per_res_step"], "mfma_per_res_step": c["mfma_per_res_step"],
                 "valu_per_ll_step": c["valu_per_ll_step"], "valu_issue_cycles": VALU_ISSUE_CYCLES, "mfma_issue_cycles": mfma_cyc,
                 "res_steps": res_steps, "ll_steps": ll_steps, "issue_cycles": cyc, "peak_cycles": peak, "frac": cyc / peak,
-                "source": c.get("source")}
+                "source": c.get("source"), "file": "profiles/" + name,
+                "measured": "instruction counts per step: not in this run (a committed SQ_INSTS_VALU / SQ_INSTS_MFMA pass of this "
+                            "kernel); steps and launch time: this run"}
     except Exception as exc:
         return {"error": repr(exc)}
 
@@ -790,7 +816,7 @@ def pin_to_gpu_numa_node(device):
     return None
 
 
-TRAFFIC_FILE = "r04_traffic.json"
+TRAFFIC_FILE = "r05_traffic.json"
 
 
 def profiled_workload(args):
@@ -799,29 +825,49 @@ def profiled_workload(args):
            (640, 480, 1152, 96, 12, 6, 124) and not args.no_stats and not args.drain_between_steps
 
 
-def traffic_from_profiles(args):
-    """HBM-side bytes per k_tick launch from the committed PMC passes (profiles/r04_traffic.json: rocprofv3 --pmc FETCH_SIZE
-    and WRITE_SIZE in separate runs of the default command, gfx950 correction applied); counters cannot be read from inside
-    the bench, so this is the figure of the profiled run (see traffic_source), not of this one.  null for any other workload."""
-    if not profiled_workload(args):
-        return None
-    try:
-        here = os.path.dirname(os.path.abspath(__file__))
-        return json.load(open(os.path.join(here, "profiles", TRAFFIC_FILE)))["traffic_bytes_per_launch"]
-    except Exception:
-        return None
+def roofline_traffic(args, world, line):
+    """HBM-side bytes per k_tick launch of the timing pass: (traffic, traffic_source).
 
+    A property of THIS run when it can be: on rank 0 of a one-GPU run bench.py starts the two rocprofv3 counter passes itself
+    (--pmc FETCH_SIZE and --pmc WRITE_SIZE, one pass each: they do not fit one) as child processes running the same workload
+    in its short form (--counter-leg), and summarises the k_tick dispatches between the two k_marker dispatches that bracket
+    the timing pass (dvo_slam_amd/pmc.py; corrected as MI355X_MICROARCH.md prescribes for gfx950).  `traffic` is the upper
+    bound (2 x FETCH_SIZE + WRITE_SIZE); the bounds, the write ratio and the wasted-traffic ratio are in traffic_source.
+    Otherwise (--no-live-counters, several GPUs, no rocprofv3, a failing pass): the committed profile of the driver's command,
+    for that workload only; null for any other."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    why_not = None
+    if world == 1 and not args.no_live_counters and os.environ.get("DVO_BENCH_LIVE_COUNTERS", "1") != "0":
+        from dvo_slam_amd import pmc
 
-def traffic_source(args):
+        leg = ["--counter-leg", "--steps", "1", "--warmup", "0", "--prime", "1", "--batch", str(args.batch), "--width", str(args.width),
+               "--height", str(args.height), "--distinct", str(args.distinct), "--distinct-refs", str(args.distinct_refs),
+               "--threads", str(args.threads), "--in-flight", str(args.in_flight)]
+        leg += ["--no-stats"] if args.no_stats else []
+        leg += ["--drain-between-steps"] if args.drain_between_steps else []
+        try:
+            t0 = time.perf_counter()
+            d = pmc.measure_traffic_live(os.path.abspath(__file__), leg)
+            d["measured"] = "in this run"
+            d["seconds_spent_on_the_two_counter_passes"] = time.perf_counter() - t0
+            d["alg_bytes_per_launch_of_this_runs_timing_pass"] = line["roofline"]["alg_bytes_per_launch"]
+            return d["traffic_bytes_per_launch"], d
+        except Exception as exc:  # the bench line never depends on the profiler
+            why_not = repr(exc)[:400]
     if not profiled_workload(args):
-        return None
+        return None, ({"live_counter_passes_failed": why_not} if why_not else None)
     try:
-        here = os.path.dirname(os.path.abspath(__file__))
         d = json.load(open(os.path.join(here, "profiles", TRAFFIC_FILE)))
-        return {"file": "profiles/" + TRAFFIC_FILE, "command": d.get("command"), "alg_bytes_per_launch_of_that_run":
-                d.get("alg_bytes_per_launch"), "pairs_per_s_under_pmc": d.get("bench_value_under_pmc")}
+        src = {"measured": "not in this run: the committed counter passes of the same command", "file": "profiles/" + TRAFFIC_FILE,
+               "command": d.get("command"), "alg_bytes_per_launch_of_that_run": d.get("alg_bytes_per_launch"),
+               "pairs_per_s_under_pmc": d.get("bench_value_under_pmc"),
+               "wasted_traffic_ratio_bounds": d.get("wasted_traffic_ratio_bounds"),
+               "write_ratio_to_algorithmic": d.get("write_ratio_to_algorithmic")}
+        if why_not:
+            src["live_counter_passes_failed"] = why_not
+        return d["traffic_bytes_per_launch"], src
     except Exception:
-        return None
+        return None, ({"live_counter_passes_failed": why_not} if why_not else None)
 
 
 def stream_copy(device):

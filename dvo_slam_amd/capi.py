@@ -35,7 +35,7 @@ EXPORTS = [
     "dvo_amd_exchange_create", "dvo_amd_exchange_attach", "dvo_amd_exchange_destroy",
     "dvo_amd_match_submit", "dvo_amd_match_wait", "dvo_amd_match_poll", "dvo_amd_debug_next_seq",
     "dvo_amd_set_reciprocal_mode", "dvo_amd_get_reciprocal_mode", "dvo_amd_debug_rcp", "dvo_amd_debug_block_trace",
-    "dvo_amd_debug_ll_overflow",
+    "dvo_amd_debug_ll_overflow", "dvo_amd_debug_marker",
 ]
 
 
@@ -136,6 +136,7 @@ def lib():
     L.dvo_amd_set_reciprocal_mode.argtypes = [vp, C.c_int]
     L.dvo_amd_get_reciprocal_mode.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.dvo_amd_debug_rcp.argtypes = [vp, C.c_int, fp, fp]
+    L.dvo_amd_debug_marker.argtypes = [vp, C.c_uint]
     L.dvo_amd_debug_ll_overflow.argtypes = [vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp,
                                             C.POINTER(C.c_int)]
     L.dvo_amd_pyramid_create.argtypes = [C.c_int, fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
@@ -671,6 +672,10 @@ class DenseTracker:
         out = np.zeros((max(n.value, 1), 8))
         _check(L.dvo_amd_debug_tick_log(self._h, out.ctypes.data_as(C.POINTER(C.c_double)), n.value, C.byref(n)), "tick_log")
         return out[: n.value]
+
+    def marker(self, tag: int = 0):
+        """(profiling aid) a no-op dispatch named k_marker on this tracker's main stream (dvo_amd_debug.h)"""
+        _check(lib().dvo_amd_debug_marker(self._h, int(tag)), "dvo_amd_debug_marker")
 
     def kernel_timing(self, enable: bool, reset: bool = False):
         ms = C.c_double()

@@ -3006,6 +3006,15 @@ int dvo_amd_debug_tick_log(dvo_amd_context *ctx, double *out, int capacity_recor
   return DVO_AMD_OK;
 }
 
+int dvo_amd_debug_marker(dvo_amd_context *ctx, unsigned tag) {
+  if (!ctx) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(ctx->device));
+  const hipError_t e = launch_marker(tag, ctx->stream);
+  if (e != hipSuccess) return fail_hip("launch_marker", e);
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return DVO_AMD_OK;
+}
+
 int dvo_amd_kernel_timing(dvo_amd_context *ctx, int enable, double *ms_residual_pass, long long *n_launches, int reset) {
   if (!ctx) return DVO_AMD_ERR_INVALID_ARGUMENT;
   if (ms_residual_pass) *ms_residual_pass = ctx->timing_ms;

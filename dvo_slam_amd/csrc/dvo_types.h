@@ -305,6 +305,7 @@ long long read_block_trace(unsigned long long *out, long long capacity);  // -1:
 // out[i] = the table reciprocal of in[i] (device pointers): the unit test of the opt-in host-rcpps mode
 hipError_t launch_rcp_table_probe(const RcpTable &rcp, const float *in, float *out, int n, hipStream_t stream);
 
+hipError_t launch_marker(unsigned tag, hipStream_t stream);  // a no-op dispatch named k_marker (profile bracketing)
 int acc_mode();  // 1: Gram matrix on the matrix pipe (default); 0: DVO_AMD_ACCUM=valu, the 87-register cross-check form
 
 // prep (pyramid construction) kernels

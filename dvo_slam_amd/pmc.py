@@ -1,0 +1,145 @@
+"""Summaries of rocprofv3 runs of bench.py: which dispatches belong to the timing pass, HBM-side traffic per k_tick launch.
+
+bench.py brackets its single-stream timing pass -- the launches `roofline.launches`, `roofline.avg_launch_us` and
+`roofline.alg_bytes_per_launch` describe -- with two no-op dispatches named `k_marker` (dvo_amd_debug_marker).  Everything
+here selects the batch-form k_tick dispatches BETWEEN the two markers, so a figure quoted per launch is a figure of exactly
+those launches (until round 4 the counter summary took "the last N k_tick dispatches of the run", and 21 launches of an
+isolated level-0 micro-benchmark that ran behind the timing pass were averaged in: VERDICT round 4).
+
+Used by scripts/profile_summary.py (the committed profiles/) and by bench.py itself, which runs the two counter passes as
+child processes of the very run that prints the bench line (`roofline.traffic_source.measured = "in this run"`).
+"""
+from __future__ import annotations
+
+import csv
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+MARKER = "k_marker"
+# /opt/skills/guides/MI355X_MICROARCH.md, "HBM": on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced
+# streaming read (16 B per lane; 128-byte requests tallied at 64 B) -- double it; WRITE_SIZE is exact for streaming stores; other
+# access widths are uncalibrated.  k_tick's reads are a mix: 4-byte-per-lane streaming loads of the reference planes (16 of the
+# 56 algorithmic bytes per pixel), 16-byte and 8-byte gathers of the current planes (24), 8-byte-per-lane streaming reads of the
+# spilled residuals (8).  scripts/probes/fetch_calibration.hip measures the factor per access width on this very pattern
+# (profiles/r05_fetch_calibration.txt); without it the bounds are 1 x FETCH (no request is under-counted) and 2 x FETCH (every
+# request is).
+FETCH_FACTOR_BOUNDS = (1.0, 2.0)
+
+
+def _is_tick(name: str) -> bool:
+    # the batch form only ("k_tick<...>"): single match() calls (k_tick_small: the latency probe, the timed-region check) launch
+    # behind the small argument block and are not what the timed region runs
+    return "k_tick<" in name
+
+
+def between_markers(rows, order_key):
+    """rows: dicts with Kernel_Name; order_key: the column that orders dispatches (Dispatch_Id or Start_Timestamp).  Returns the
+    batch-form k_tick rows between the FIRST and the LAST k_marker dispatch, or None when the run carries fewer than two markers."""
+    rows = sorted(rows, key=lambda r: int(r[order_key]))
+    marks = [i for i, r in enumerate(rows) if MARKER in r["Kernel_Name"]]
+    if len(marks) < 2:
+        return None
+    return [r for r in rows[marks[0] + 1: marks[-1]] if _is_tick(r["Kernel_Name"])]
+
+
+def counter_per_launch(csv_path: str, counter: str):
+    """-> (values of `counter` for the k_tick dispatches of the timing pass, values for every k_tick dispatch of the run)"""
+    rows = [r for r in csv.DictReader(open(csv_path)) if r.get("Counter_Name") in (counter, None, "")]
+    every = [float(r["Counter_Value"]) for r in sorted(rows, key=lambda r: int(r["Dispatch_Id"])) if _is_tick(r["Kernel_Name"])]
+    sel = between_markers(rows, "Dispatch_Id")
+    if sel is None:
+        raise RuntimeError(f"{csv_path}: no pair of {MARKER} dispatches (a bench.py older than round 5?)")
+    # a counter is reported once per dispatch and XCC / dimension: sum the rows of a dispatch
+    per = {}
+    for r in sel:
+        per[int(r["Dispatch_Id"])] = per.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
+    return [per[k] for k in sorted(per)], every
+
+
+def traffic_summary(fetch_csv: str, write_csv: str, bench_line: dict, command: str | None = None,
+                    bench_line_write: dict | None = None) -> dict:
+    """HBM-side bytes per k_tick launch of the timing pass of the run that wrote the two counter files (one rocprofv3 --pmc pass
+    each: FETCH_SIZE costs 3 of the 4 TCC slots, WRITE_SIZE 2)."""
+    n_timed = int(bench_line["roofline"]["launches"])
+    alg = float(bench_line["roofline"]["alg_bytes_per_launch"])
+    out = {}
+    for name, path, line in (("FETCH_SIZE", fetch_csv, bench_line), ("WRITE_SIZE", write_csv, bench_line_write or bench_line)):
+        sel, every = counter_per_launch(path, name)
+        if len(sel) != int(line["roofline"]["launches"]) or len(sel) != n_timed:
+            raise RuntimeError(f"{name}: {len(sel)} k_tick dispatches between the markers, bench.py timed "
+                               f"{line['roofline']['launches']} in that pass ({n_timed} in the FETCH_SIZE pass)")
+        out[name + "_kb_avg_per_launch"] = sum(sel) / len(sel)
+        out[name + "_kb_avg_over_every_dispatch_of_the_run"] = sum(every) / max(1, len(every))
+        out[name + "_dispatches"] = len(every)
+    out["launches_averaged"] = n_timed
+    out["selection"] = f"the batch-form k_tick dispatches between the two {MARKER} dispatches that bracket bench.py's timing pass"
+    f_kb, w_kb = out["FETCH_SIZE_kb_avg_per_launch"], out["WRITE_SIZE_kb_avg_per_launch"]
+    lo, hi = FETCH_FACTOR_BOUNDS
+    out["fetch_bytes_per_launch_bounds"] = [lo * f_kb * 1024.0, hi * f_kb * 1024.0]
+    out["write_bytes_per_launch"] = w_kb * 1024.0
+    out["traffic_bytes_per_launch"] = (hi * f_kb + w_kb) * 1024.0            # upper bound: every read request under-counted
+    out["traffic_bytes_per_launch_uncorrected"] = (lo * f_kb + w_kb) * 1024.0  # lower bound: none is
+    out["alg_bytes_per_launch"] = alg
+    # algorithmic split of the 56 B per selected pixel: 40 read (16 reference planes + 24 current planes) + 8
+    # residual spill written + 8 read back by the likelihood pass of the next tick
+    out["alg_write_bytes_per_launch"] = alg * 8.0 / 56.0
+    out["alg_read_bytes_per_launch"] = alg * 48.0 / 56.0
+    out["write_ratio_to_algorithmic"] = out["write_bytes_per_launch"] / out["alg_write_bytes_per_launch"]
+    out["read_ratio_to_algorithmic_bounds"] = [b / out["alg_read_bytes_per_launch"] for b in out["fetch_bytes_per_launch_bounds"]]
+    out["wasted_traffic_ratio_bounds"] = [out["traffic_bytes_per_launch_uncorrected"] / alg, out["traffic_bytes_per_launch"] / alg]
+    out["bench_value_under_pmc"] = bench_line.get("value")
+    if command:
+        out["command"] = command
+    out["note"] = ("Counters of exactly the launches alg_bytes_per_launch describes.  WRITE_SIZE is exact for streaming stores: "
+                   "write_ratio_to_algorithmic is the residual spill (8 B per selected pixel) plus the block records and likelihood "
+                   "partials.  FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read on gfx950 (MI355X_MICROARCH.md), so "
+                   "the read side is bracketed by 1 x and 2 x FETCH_SIZE; wasted_traffic_ratio_bounds = (bounds of FETCH + WRITE) / "
+                   "algorithmic bytes: a ratio well above 1 would mean wasted re-reads, below 1 that part of the algorithmic bytes "
+                   "(neighbouring gathers, the residual re-read) never left L2 / the Infinity Cache.")
+    return out
+
+
+def rocprofv3_path() -> str | None:
+    for cand in (shutil.which("rocprofv3"), "/opt/rocm/bin/rocprofv3"):
+        if cand and os.path.exists(cand):
+            return cand
+    return None
+
+
+def measure_traffic_live(bench_py: str, leg_args: list, timeout_s: float = 150.0) -> dict:
+    """The two counter passes as child processes of the caller: `rocprofv3 --pmc <counter> -- python3 bench.py <leg_args>` each,
+    in a scratch directory (cwd /tmp as the profiler wants), DVO_AMD_LAUNCH_LOCK=1 (rocprofv3's queue interceptor and several
+    host threads: profiles/r03_rocprofv3_sigsegv_root_cause.md).  Returns traffic_summary() of the two; raises on any failure."""
+    prof = rocprofv3_path()
+    if prof is None:
+        raise RuntimeError("rocprofv3 not found")
+    tmp = tempfile.mkdtemp(prefix="dvo_pmc_", dir="/tmp")
+    env = dict(os.environ, DVO_AMD_LAUNCH_LOCK="1", TMPDIR="/tmp")
+    env.pop("DVO_BENCH_MAPS", None)
+    lines, csvs = {}, {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [prof, "--pmc", counter, "-d", d, "-o", "pmc", "--output-format", "csv", "--", sys.executable, bench_py] + leg_args
+            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            if res.returncode != 0:
+                raise RuntimeError(f"{counter} pass failed (rc {res.returncode}): {res.stderr[-600:]}")
+            out_lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+            if not out_lines:
+                raise RuntimeError(f"{counter} pass printed no bench line: {res.stdout[-300:]} {res.stderr[-300:]}")
+            lines[counter] = json.loads(out_lines[-1])
+            found = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith("counter_collection.csv")]
+            if not found:
+                raise RuntimeError(f"{counter} pass left no counter_collection.csv under {d}")
+            csvs[counter] = found[0]
+        summary = traffic_summary(csvs["FETCH_SIZE"], csvs["WRITE_SIZE"], lines["FETCH_SIZE"],
+                                  command="rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (one pass each) -- python3 bench.py " + " ".join(leg_args),
+                                  bench_line_write=lines["WRITE_SIZE"])
+        summary["launches_of_the_write_pass"] = int(lines["WRITE_SIZE"]["roofline"]["launches"])
+        return summary
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)

@@ -92,6 +92,11 @@ int dvo_amd_debug_tick_log(dvo_amd_context *ctx, double *out, int capacity_recor
  * reset, and the number of launches */
 int dvo_amd_kernel_timing(dvo_amd_context *ctx, int enable, double *ms_residual_pass, long long *n_launches, int reset);
 
+/* (profiling aid) one no-op dispatch named `k_marker` on the context's main stream, waited for: bench.py brackets its
+ * single-stream timing pass with two of them so that the summaries of a rocprofv3 run (kernel trace or counter pass) can select
+ * exactly the k_tick dispatches in between (dvo_slam_amd/pmc.py) */
+int dvo_amd_debug_marker(dvo_amd_context *ctx, unsigned tag);
+
 /* (test entry) k_ll_overflow -- the exact answer to "did one of the reference's 50-term likelihood products overflow?"
  * (dense_tracking_impl.cpp:413-419) -- over a residual buffer the CALLER supplies, for one band of it: `residuals` = n_blocks x
  * 4 wave segments x (64 x steps) pixels x 2 floats in scan order, NaN = invalid pixel; the band = wave segments

@@ -475,16 +475,67 @@ def same_path(rg, ro):
                for Lg, Lo in zip(rg.Levels, ro["levels"]))
 
 
+def same_path_beyond_the_bar(orc, synth, ocfg, o_ref, o_cur, rg, ro, err, pose_tol):
+    """A run that took the ORACLE'S iteration path and still ends further than pose_tol from it.  No decision flipped, so there is
+    nothing to re-synchronise: the two runs are the same sequence of Gauss-Newton steps whose increments differ by summation noise.
+    That happens on short, coarse alignments (the validator's level-3-only stage: 4 800 pixels, depth precision 1e9), where the
+    reference's OWN sequential fp32 sums put its increments ~1e-5 from what exact sums give.  Deterministic rule, two parts:
+      1. every iteration of the GPU's run, teacher-forced at the GPU's own pose and previous precision: the reference arithmetic
+         (orc.iteration) must count the GPU's constraints exactly and its increment must be within twice its own summation-noise
+         band of the GPU's (band = |reference increment - increment from exact sums of the same terms|, tests/stage_f64.py);
+      2. the final distance must be accounted for by the oracle's own noise on its own path: err <= pose_tol + 2 * sum over the
+         iterations of the LAST level of |oracle increment - increment from exact sums at the oracle's pose| (earlier levels'
+         noise is corrected by the Gauss-Newton steps of the later ones; the last level's is what the result keeps).
+    Returns report lines; raises AssertionError otherwise."""
+    G, O = gpu_levels(rg), oracle_levels(ro)
+    mu = ocfg.mu
+    sel = (float(ocfg.intensity_derivative_threshold), float(ocfg.depth_derivative_threshold))
+    rcp = ocfg.rcp_mode
+    worst_ratio, n_it = 0.0, 0
+    for Lg in G:
+        for k, ig in enumerate(Lg["iters"]):
+            if not ig["has_inc"]:
+                continue
+            pin = None if k == 0 else Lg["iters"][k - 1]["P"]
+            o2 = orc.iteration(o_ref, o_cur, Lg["id"], ig["T"], pin, rcp, *sel)
+            where = ("same path beyond the bar", "level", Lg["id"], "iteration", k)
+            assert o2["n"] == ig["V"], where + ("the reference counts", o2["n"], "the GPU", ig["V"])
+            prior = mu * np.asarray(orc.se3_log(ig["initial"])) if mu else np.zeros(6)
+            x2 = np.linalg.solve(np.asarray(o2["A"], np.float64) + mu * np.eye(6), np.asarray(o2["b"], np.float64) + prior)
+            _, _, band = _noise_band(orc, o_ref, o_cur, Lg["id"], ig["T"], pin, o2["ll"], x_ref=x2, mu=mu, prior=prior, sel=sel, rcp=rcp)
+            gap = float(np.abs(x2 - ig["inc"]).max())
+            assert gap <= 2 * band + 1e-12, where + ("GPU increment", ig["inc"], "reference arithmetic at the same pose", x2, "band", band)
+            worst_ratio = max(worst_ratio, gap / max(band, 1e-300))
+            n_it += 1
+    budget = 0.0
+    Lo = O[-1]
+    for k, io in enumerate(Lo["iters"]):
+        if not io["has_inc"]:
+            continue
+        pin = None if k == 0 else Lo["iters"][k - 1]["P"]
+        prior = mu * np.asarray(orc.se3_log(io["initial"])) if mu else np.zeros(6)
+        _, _, band = _noise_band(orc, o_ref, o_cur, Lo["id"], io["T"], pin, -io["nll"], x_ref=io["inc"], mu=mu, prior=prior, sel=sel, rcp=rcp)
+        budget += band
+    bar = pose_tol + 2.0 * budget
+    assert err <= bar, ("same path, and further from the oracle than the oracle's own summation noise on its last level accounts for",
+                        err, "bar", bar)
+    return [f"same path as the oracle, {err:.2e} from it: {n_it} iterations teacher-forced at the GPU's own poses, every increment within "
+            f"{worst_ratio:.2f} x the reference's own summation-noise band of the reference arithmetic's (bar 2 x); the oracle's increments "
+            f"on its last level are {budget:.2e} (summed) from the ones exact sums give: bar {bar:.2e}"]
+
+
 def settle(orc, synth, ocfg, o_ref, o_cur, T_init, rg, ro, pose_tol=1e-5, batch_T=None, count_slack=None, increment_band=0.0):
     """For callers that hold a pose from a batched entry point (the validator, the front-end step, the queue): rg is the SAME
     alignment re-run through the single match() with per-iteration statistics -- a pair's result is a function of its inputs
     alone (tests/test_determinism.py), so it must be the batch's result bit for bit (batch_T) -- and is held to the rule of this
-    module: same path -> pose_tol against the free-running oracle, forked -> adjudicate().  Returns (forked, report)."""
+    module: same path -> pose_tol against the free-running oracle (beyond it: same_path_beyond_the_bar), forked -> adjudicate().
+    Returns (forked, report)."""
     if batch_T is not None:
         assert np.array_equal(np.asarray(batch_T), rg.Transformation), "the batched result is not the single match()'s bit for bit"
     err = synth.pose_error(ro["T"], rg.Transformation)
     if same_path(rg, ro):
-        assert err <= pose_tol, ("same path, pose error", err)
-        return False, [f"same path, {err:.2e}"]
+        if err <= pose_tol:
+            return False, [f"same path, {err:.2e}"]
+        return False, same_path_beyond_the_bar(orc, synth, ocfg, o_ref, o_cur, rg, ro, err, pose_tol)
     report, _, _ = adjudicate(orc, synth, ocfg, o_ref, o_cur, T_init, rg, ro, err, pose_tol, count_slack, increment_band)
     return True, report

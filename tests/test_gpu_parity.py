@@ -1170,7 +1170,7 @@ def test_closed_band_never_reads_behind_its_edge(capi):
     res = np.full((n_px, 2), np.nan, np.float32)
     res[:1001] = 1e-6                      # chunk 0 (segments 0..7 = 1024 pixels): terms 1 + 0.2 * 2e-3
     res[1024:1029] = 1e-6                  # chunk 1: five valid pixels, then the hole up to the band edge (pixel 2048)
-    res[2048:] = 1e3                       # behind the band: q = 2e15 per pixel, fifty of them overflow a double
+    res[2048:] = 0.5                       # behind the band: q = 5e8, a term of 1e8 per pixel: forty of them overflow a double
     band_valid = 1006
     kw = dict(n_blocks=n_blocks, steps=steps, seg_first=0, n_segs=16, rank_offset=0, cut_rank=5000, precision=P)
     assert trk.ll_overflow_probe(res, rank_end=band_valid, **kw) is False      # closed: group [1000, 1050) is the host's business
@@ -1178,17 +1178,17 @@ def test_closed_band_never_reads_behind_its_edge(capi):
     # a band that starts inside a group (rank_offset 30): its first complete group is [50, 100) = its pixels 20..69
     assert trk.ll_overflow_probe(res, rank_end=30 + band_valid, **dict(kw, rank_offset=30)) is False
     inside = res.copy()
-    inside[520:570] = 1e3                  # ranks 520..569 of the band: group [550, 600) holds 20 huge terms only ...
+    inside[520:570] = 0.5                  # ranks 520..569: groups [500, 550) and [550, 600) hold 30 and 20 huge terms: 1e240 at most ...
     assert trk.ll_overflow_probe(inside, rank_end=band_valid, **kw) is False
-    inside[500:550] = 1e3                  # ... now group [500, 550) is all huge: overflows inside the band
+    inside[500:550] = 0.5                  # ... now group [500, 550) is all huge (1e400): overflows inside the band
     assert trk.ll_overflow_probe(inside, rank_end=band_valid, **kw) is True
     # the last chunk of a closed band: 60 valid pixels behind the last group boundary, none of them judged
     tail = np.full((n_px, 2), np.nan, np.float32)
     tail[:1000] = 1e-6
-    tail[1024:1084] = 1e3                  # ranks 1000..1059: group [1000, 1050) is complete INSIDE the band: judged, overflows
+    tail[1024:1084] = 0.5                  # ranks 1000..1059: group [1000, 1050) is complete INSIDE the band: judged, overflows
     assert trk.ll_overflow_probe(tail, rank_end=1060, **kw) is True
     tail[1024:1084] = np.nan
-    tail[1024:1064] = 1e3                  # ranks 1000..1039 only: the group is completed by the next rank
+    tail[1024:1064] = 0.5                  # ranks 1000..1039 only (they alone would overflow): completed -- and judged -- by the next rank
     assert trk.ll_overflow_probe(tail, rank_end=1040, **kw) is False
 
 
