@@ -1057,18 +1057,18 @@ __device__ __forceinline__ void tick_body(const TickItem &it, const RcpTable &rc
 // ("compact") grid: lanes 0 .. n_items look at the items' first block groups; the owner is the last item that starts at or
 // before this block's group (every wave finds the same one).
 template <class Args>
-__device__ __forceinline__ int tick_locate(const Args &args, int &bx) {
+__device__ __forceinline__ int tick_locate(const Args &args, int &bx, const unsigned block = blockIdx.x) {
   constexpr int kSlots = (int)(sizeof(args.group_first) / sizeof(args.group_first[0]));
   if (!args.compact) {
     const int rot = args.xcd_rot[blockIdx.y];
-    bx = (int)((blockIdx.x & ~7u) | ((blockIdx.x + rot) & 7u));
+    bx = (int)((block & ~7u) | ((block + rot) & 7u));
     return (int)blockIdx.y;
   }
   const int lane = threadIdx.x & (kWave - 1);
-  const unsigned g = blockIdx.x >> 3;
+  const unsigned g = block >> 3;
   const unsigned first = lane <= args.n_items ? (unsigned)args.group_first[lane < kSlots ? lane : 0] : 0xFFFFFFFFu;
   const int idx = __builtin_amdgcn_readfirstlane(__popcll(__ballot(first <= g)) - 1);
-  bx = (int)blockIdx.x - ((int)args.group_first[idx] << 3);
+  bx = (int)block - ((int)args.group_first[idx] << 3);
   bx = (bx & ~7) | ((bx + (int)args.xcd_rot[idx]) & 7);
   return idx;
 }
@@ -1080,6 +1080,30 @@ __global__ __launch_bounds__(kBlockThreads, ACC == 0 ? 2 : 4) void k_tick(const 
   int bx;
   const int idx = tick_locate(args, bx);
   tick_body<ACC, RCP>(args.items[idx], args.rcp, bx);
+}
+
+// EXPERIMENT (round 5; DVO_AMD_PERSIST=<grid>): a fixed grid of physical blocks, each walking the launch's
+// logical blocks b, b + G, b + 2 G ... of the compact (one-dimensional) layout -- a STATIC partition: no claim counter, no atomics
+// (round 2's dynamic claims lost 4-8 %: the claim's round trip sat between two logical blocks).  G is a multiple of 8, so a logical
+// block keeps the XCD its index maps to.  Same per-pixel code, same records, same summation tree: results are bit-identical to
+// the one-block-per-logical-block launch.  The barrier between two logical blocks protects the LDS staging the tail of a block
+// still reads (the moment gather, the ordered combine of the wave segments).
+template <int ACC, int RCP>
+__global__ __launch_bounds__(kBlockThreads, ACC == 0 ? 2 : 4) void k_tick_persist(const TickArgs args, const int total_blocks) {
+  (void)args;
+#pragma nounroll
+  for (unsigned b = blockIdx.x; b < (unsigned)total_blocks; b += gridDim.x) {
+    // the argument block is re-read through an opaque copy of the kernarg pointer in every trip: hoisted out of the loop its
+    // scalars (descriptor pointers, K T, block ranges of the item) stay live across the whole body and spill (106 SGPRs, 23 VGPRs
+    // in scratch when this loop was written over `args` itself)
+    const DVO_CONST TickArgs *pa = (const DVO_CONST TickArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(pa));
+    const TickArgs &a = *(const TickArgs *)pa;
+    int bx;
+    const int idx = tick_locate(a, bx, b);
+    tick_body<ACC, RCP>(a.items[idx], a.rcp, bx);
+    __syncthreads();
+  }
 }
 
 // the same kernel behind the small argument block of a tick of at most kMaxSmallItems pairs
@@ -1175,7 +1199,11 @@ static int tick_args_layout_impl(Args &args, int max_blocks) {
     const char *e = getenv("DVO_AMD_COMPACT_GRID");
     return e ? (e[0] == '0' ? 0 : 1) : 2;
   }();
-  args.compact = groups > 0 && groups < 65536 && (mode == 1 || (mode == 2 && 2ll * 8 * groups < grid2d)) ? 1 : 0;
+  static const bool persist_on = [] {
+    const char *e = getenv("DVO_AMD_PERSIST");
+    return e && atoi(e) > 0;
+  }();
+  args.compact = groups > 0 && groups < 65536 && (mode == 1 || persist_on || (mode == 2 && 2ll * 8 * groups < grid2d)) ? 1 : 0;
   return (int)(groups * 8);
 }
 int tick_args_layout(TickArgs &args, int max_blocks) { return tick_args_layout_impl(args, max_blocks); }
@@ -1209,6 +1237,20 @@ hipError_t launch_tick(const TickArgs &args, int max_blocks, hipStream_t stream,
   LaunchGuard guard;
   dim3 grid((unsigned)((max_blocks + 7) & ~7), (unsigned)args.n_items, 1);
   if (args.compact) grid = dim3((unsigned)args.group_first[args.n_items] * 8u, 1, 1);
+  static const int persist = [] {  // DVO_AMD_PERSIST=<physical blocks> (a multiple of 8): the static-partition experiment
+    const char *e = getenv("DVO_AMD_PERSIST");
+    const int g = e ? atoi(e) : 0;
+    return g > 0 ? ((g + 7) & ~7) : 0;
+  }();
+  if (persist > 0 && args.compact && acc_mode() == 1 && (int)grid.x > persist) {
+    const int total = (int)grid.x;
+    void *kargs[] = {const_cast<TickArgs *>(&args), const_cast<int *>(&total)};
+    const void *kp = args.rcp.table ? reinterpret_cast<const void *>(&k_tick_persist<1, 1>) : reinterpret_cast<const void *>(&k_tick_persist<1, 0>);
+    const hipError_t e = (t_start && t_stop)
+                             ? hipExtLaunchKernel(kp, dim3((unsigned)persist), dim3(kBlockThreads), kargs, 0, stream, t_start, t_stop, 0)
+                             : hipLaunchKernel(kp, dim3((unsigned)persist), dim3(kBlockThreads), kargs, 0, stream);
+    return e != hipSuccess ? e : hipGetLastError();
+  }
   if (t_start && t_stop) {
     void *kargs[] = {const_cast<TickArgs *>(&args)};
     const hipError_t e = hipExtLaunchKernel(reinterpret_cast<const void *>(kernel), grid, dim3(kBlockThreads), kargs, 0, stream,

@@ -2,7 +2,7 @@
 
 bench.py brackets its single-stream timing pass -- the launches `roofline.launches`, `roofline.avg_launch_us` and
 `roofline.alg_bytes_per_launch` describe -- with two no-op dispatches named `k_marker` (dvo_amd_debug_marker).  Everything
-here selects the batch-form k_tick dispatches BETWEEN the two markers, so a figure quoted per launch is a figure of exactly
+here selects the k_tick dispatches BETWEEN the two markers, so a figure quoted per launch is a figure of exactly
 those launches (until round 4 the counter summary took "the last N k_tick dispatches of the run", and 21 launches of an
 isolated level-0 micro-benchmark that ran behind the timing pass were averaged in: VERDICT round 4).
 
@@ -38,12 +38,14 @@ def _is_tick(name: str) -> bool:
 
 def between_markers(rows, order_key):
     """rows: dicts with Kernel_Name; order_key: the column that orders dispatches (Dispatch_Id or Start_Timestamp).  Returns the
-    batch-form k_tick rows between the FIRST and the LAST k_marker dispatch, or None when the run carries fewer than two markers."""
+    k_tick rows between the FIRST and the LAST k_marker dispatch, or None when the run carries fewer than two markers."""
     rows = sorted(rows, key=lambda r: int(r[order_key]))
     marks = [i for i, r in enumerate(rows) if MARKER in r["Kernel_Name"]]
     if len(marks) < 2:
         return None
-    return [r for r in rows[marks[0] + 1: marks[-1]] if _is_tick(r["Kernel_Name"])]
+    # (every form of the kernel: the tail of the timing pass drains through ticks of at most eight pairs, which go out as
+    #  k_tick_small; bench.py's launch count and algorithmic bytes include them)
+    return [r for r in rows[marks[0] + 1: marks[-1]] if "k_tick" in r["Kernel_Name"]]
 
 
 def counter_per_launch(csv_path: str, counter: str):
@@ -76,7 +78,7 @@ def traffic_summary(fetch_csv: str, write_csv: str, bench_line: dict, command: s
         out[name + "_kb_avg_over_every_dispatch_of_the_run"] = sum(every) / max(1, len(every))
         out[name + "_dispatches"] = len(every)
     out["launches_averaged"] = n_timed
-    out["selection"] = f"the batch-form k_tick dispatches between the two {MARKER} dispatches that bracket bench.py's timing pass"
+    out["selection"] = f"the k_tick dispatches (batch and small-argument form) between the two {MARKER} dispatches that bracket bench.py's timing pass"
     f_kb, w_kb = out["FETCH_SIZE_kb_avg_per_launch"], out["WRITE_SIZE_kb_avg_per_launch"]
     lo, hi = FETCH_FACTOR_BOUNDS
     out["fetch_bytes_per_launch_bounds"] = [lo * f_kb * 1024.0, hi * f_kb * 1024.0]
