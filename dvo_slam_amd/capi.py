@@ -42,7 +42,11 @@ EXPORTS = [
 class CConfig(C.Structure):
     _fields_ = [("first_level", C.c_int), ("last_level", C.c_int), ("max_iterations_per_level", C.c_int),
                 ("precision", C.c_double), ("mu", C.c_double), ("use_initial_estimate", C.c_int),
-                ("intensity_derivative_threshold", C.c_float), ("depth_derivative_threshold", C.c_float)]
+                ("intensity_derivative_threshold", C.c_float), ("depth_derivative_threshold", C.c_float),
+                ("segment_geometry", C.c_int), ("reserved", C.c_int)]
+
+
+GEOMETRY_THROUGHPUT, GEOMETRY_LATENCY = 0, 1
 
 
 class CIterationStats(C.Structure):
@@ -229,6 +233,9 @@ class Config:
         self.UseInitialEstimate = bool(c.use_initial_estimate)
         self.IntensityDerivativeThreshold = c.intensity_derivative_threshold
         self.DepthDerivativeThreshold = c.depth_derivative_threshold
+        # not a field of the reference: how a level is cut into wave segments (dvo_amd.h: dvo_amd_config::segment_geometry);
+        # GEOMETRY_THROUGHPUT (default) or GEOMETRY_LATENCY (the shortest single match())
+        self.SegmentGeometry = c.segment_geometry
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise AttributeError(k)
@@ -242,7 +249,8 @@ class Config:
 
     def _c(self) -> CConfig:
         return CConfig(self.FirstLevel, self.LastLevel, self.MaxIterationsPerLevel, self.Precision, self.Mu,
-                       int(self.UseInitialEstimate), self.IntensityDerivativeThreshold, self.DepthDerivativeThreshold)
+                       int(self.UseInitialEstimate), self.IntensityDerivativeThreshold, self.DepthDerivativeThreshold,
+                       int(self.SegmentGeometry), 0)
 
 
 class RgbdImagePyramid:

@@ -284,7 +284,7 @@ def createConstraintProposalValidator(frontend_cfg: capi.Config | None = None, m
             FirstLevel=t.first_level, LastLevel=t.last_level, MaxIterationsPerLevel=t.max_iterations_per_level,
             Precision=t.precision, Mu=t.mu, UseInitialEstimate=bool(t.use_initial_estimate),
             IntensityDerivativeThreshold=t.intensity_derivative_threshold,
-            DepthDerivativeThreshold=t.depth_derivative_threshold))
+            DepthDerivativeThreshold=t.depth_derivative_threshold, SegmentGeometry=t.segment_geometry))
         st.OnlyKeepBest = bool(s.only_keep_best)
         for k in range(s.n_voters):
             st.addVoter(kinds[s.voters[k].kind](s.voters[k].threshold))

@@ -494,6 +494,10 @@ struct dvo_amd_context {
   // 4/8/8/8 46.6 k | 0.83 ms; 8/8/8/8 45.9 k | 0.84; 2/4/8/8 46.2 k | 0.76; 2/4/4/8 45.2 k | 0.72; 1/2/4/8 44.5 k | 0.70;
   // 8/8/8/16 46.1 k | 0.84; 1/1/1/4 (what a single pair got until round 3) 35.8 k | 0.71.
   long long level_steps_at[4] = {70, 250, 1000, 9600};
+  // dvo_amd_config::segment_geometry = DVO_AMD_GEOMETRY_LATENCY: 640x480 levels 3..0 take 1 / 2 / 4 / 8 steps per wave (1280x960
+  // levels 4..0: 1 / 2 / 4 / 8 / 8): what a single match() got until round 3, as a configuration of the tracker -- honoured by
+  // match(), the batched forms, the queue, the validator's stages and the band pipeline alike (round 5)
+  long long level_steps_at_latency[4] = {250, 1000, 4000, 38400};
   int fault_slot_alloc = -1;           // DVO_AMD_FAULT_SLOT_ALLOC: fail the allocation of this slot once (tests of the error path)
   bool fin_stamps = false;             // DVO_AMD_FIN_STAMPS=1: k_finalize records phase stamps (diagnostic)
   bool sort_items = true;              // longest-lived blocks first inside a launch (DVO_AMD_SORT_ITEMS=0: slot order)
@@ -920,7 +924,7 @@ int ensure_slots(dvo_amd_context *ctx, int n_jobs, int n_pad) {
 // epilogue (descriptors, seven wave reductions, the Gram tile, the block record) are amortised over long ones.
 int level_steps(const dvo_amd_context *ctx, int n_px) {
   const long long waves = n_px / kStepPx;
-  const long long *t = ctx->level_steps_at;
+  const long long *t = ctx->cfg.segment_geometry == DVO_AMD_GEOMETRY_LATENCY ? ctx->level_steps_at_latency : ctx->level_steps_at;
   int steps = waves >= t[3] ? 16 : waves >= t[2] ? 8 : waves >= t[1] ? 4 : waves >= t[0] ? 2 : 1;
   while (steps < kMaxSteps && (n_px + kStepPx * kWavesPerBlock * steps - 1) / (kStepPx * kWavesPerBlock * steps) > 2048) steps *= 2;
   return steps;
@@ -1543,6 +1547,8 @@ int check_config(const dvo_amd_config *c) {
   if (c->first_level < c->last_level) return DVO_AMD_ERR_INSANE_CONFIG;  // Config::IsSane
   if (c->last_level < 0 || c->first_level >= DVO_AMD_MAX_LEVELS || c->max_iterations_per_level < 1)
     return DVO_AMD_ERR_INVALID_ARGUMENT;
+  if (c->segment_geometry != DVO_AMD_GEOMETRY_THROUGHPUT && c->segment_geometry != DVO_AMD_GEOMETRY_LATENCY)
+    return DVO_AMD_ERR_INVALID_ARGUMENT;
   return DVO_AMD_OK;
 }
 
@@ -2080,6 +2086,8 @@ void dvo_amd_default_config(dvo_amd_config *c) {
   c->use_initial_estimate = 0;
   c->intensity_derivative_threshold = 0.0f;
   c->depth_derivative_threshold = 0.0f;
+  c->segment_geometry = DVO_AMD_GEOMETRY_THROUGHPUT;
+  c->reserved = 0;
 }
 
 int dvo_amd_context_create(int device, const dvo_amd_config *cfg, dvo_amd_context **out) {

@@ -173,6 +173,7 @@ void dvo_amd_default_validator_stages(const dvo_amd_config *frontend_cfg, double
       c.precision = frontend_cfg->precision, c.mu = frontend_cfg->mu;
       c.intensity_derivative_threshold = frontend_cfg->intensity_derivative_threshold;
       c.depth_derivative_threshold = frontend_cfg->depth_derivative_threshold;
+      c.segment_geometry = frontend_cfg->segment_geometry;  // (not a reference field: the tracker's wave-segment geometry)
     }
     stages[s].tracking_config = c;
   }

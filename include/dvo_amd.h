@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define DVO_AMD_MAX_LEVELS 8
-#define DVO_AMD_ABI_VERSION 2
+#define DVO_AMD_ABI_VERSION 3
 
 typedef enum {
   DVO_AMD_OK = 0,
@@ -66,7 +66,20 @@ typedef struct {
   int use_initial_estimate;       /* UseInitialEstimate, default 0 */
   float intensity_derivative_threshold; /* IntensityDerivativeThreshold, default 0 */
   float depth_derivative_threshold;     /* DepthDerivativeThreshold, default 0 */
+  /* NOT a field of the reference (ABI version 3): how a pyramid level is cut into wave segments -- where the fp32 sums of a
+   * residual pass are cut.  Like every other field of this struct it is part of what a result is a function of: two trackers
+   * with different values agree to summation noise, not bit for bit; under ONE value match(), the batched forms, the queue, the
+   * validator's workers and every band count agree bit for bit (tests/test_determinism.py runs under both).
+   *   DVO_AMD_GEOMETRY_THROUGHPUT (default): 640x480 levels 3..0 run 2 / 4 / 8 / 8 steps of 64 pixels per wave (a 1280x960
+   *     level 0: 16) -- long segments amortise a block's prologue and epilogue: the most pairs per second;
+   *   DVO_AMD_GEOMETRY_LATENCY: 1 / 2 / 4 / 8 -- short segments spread a coarse level over more waves: the shortest single
+   *     match() (the reference's default deployment is one match() per frame, dvo_ros/src/camera_dense_tracking.cpp:269), a few
+   *     per cent fewer pairs per second in large batches. */
+  int segment_geometry;
+  int reserved;
 } dvo_amd_config;
+#define DVO_AMD_GEOMETRY_THROUGHPUT 0
+#define DVO_AMD_GEOMETRY_LATENCY 1
 
 /* DenseTracker::IterationStats, dense_tracking.h:83-100 */
 typedef struct {

@@ -300,6 +300,7 @@ class ConstraintProposalValidator {
     o.precision = c.Precision, o.mu = c.Mu, o.use_initial_estimate = c.UseInitialEstimate ? 1 : 0;
     o.intensity_derivative_threshold = c.IntensityDerivativeThreshold;
     o.depth_derivative_threshold = c.DepthDerivativeThreshold;
+    o.segment_geometry = c.SegmentGeometry, o.reserved = 0;
     return o;
   }
   dvo::DenseTracker tracker_;

@@ -555,6 +555,9 @@ class DenseTracker {
     float ScaleEstimatorParam;
     float IntensityDerivativeThreshold;
     float DepthDerivativeThreshold;
+    // NOT a field of the reference: dvo_amd_config::segment_geometry (DVO_AMD_GEOMETRY_THROUGHPUT, the default, or
+    // DVO_AMD_GEOMETRY_LATENCY for the shortest single match()); callers of the reference never touch it
+    int SegmentGeometry;
 
     Config() {  // dense_tracking_config.cpp:27-42
       dvo_amd_config c;
@@ -566,6 +569,7 @@ class DenseTracker {
       ScaleEstimatorType = core::ScaleEstimators::TDistribution, ScaleEstimatorParam = core::kTDistributionDefaultDof;
       IntensityDerivativeThreshold = c.intensity_derivative_threshold;
       DepthDerivativeThreshold = c.depth_derivative_threshold;
+      SegmentGeometry = c.segment_geometry;
     }
     size_t getNumLevels() const { return (size_t)FirstLevel + 1; }
     bool UseEstimateSmoothing() const { return Mu > 1e-6; }
@@ -804,6 +808,7 @@ class DenseTracker {
     o.precision = c.Precision, o.mu = c.Mu, o.use_initial_estimate = c.UseInitialEstimate ? 1 : 0;
     o.intensity_derivative_threshold = c.IntensityDerivativeThreshold;
     o.depth_derivative_threshold = c.DepthDerivativeThreshold;
+    o.segment_geometry = c.SegmentGeometry, o.reserved = 0;
     return o;
   }
 

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(capi):
     missing = [name for name in declared if not hasattr(L, name)]
     assert not missing, missing
     assert sorted(capi.EXPORTS) == declared  # the Python binding covers the whole header
-    assert L.dvo_amd_abi_version() == 2
+    assert L.dvo_amd_abi_version() == 3
 
 
 def test_default_config_matches_reference_defaults(capi):

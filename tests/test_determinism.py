@@ -175,3 +175,37 @@ def test_stage_probe_runs_the_geometry_match_runs(capi, synth, frames, singles):
                 checked += 1
             prev_P = it["TDistributionPrecision"]
     assert checked >= 10
+
+
+def test_the_latency_geometry_is_a_configuration_like_any_other(capi, synth, frames, singles):
+    """dvo_amd_config::segment_geometry = DVO_AMD_GEOMETRY_LATENCY (round 5; 640x480 levels 3..0 in 1 / 2 / 4 / 8 steps per wave:
+    the shortest single match()).  It is part of what a result is a function of, like every other field of the configuration:
+    under it match() == batch at any residency == the queue == every band count, bit for bit -- and it is NOT the default
+    geometry's result bit for bit (another summation order: agreement to summation noise, the same path or a fork)."""
+    cfg = capi.Config(FirstLevel=3, LastLevel=0, SegmentGeometry=capi.GEOMETRY_LATENCY)
+    single = capi.DenseTracker(cfg)
+    pairs = _pairs(frames, 30)
+    want = {ij: single.match(frames[ij[0]], frames[ij[1]]) for ij in pairs}
+    trk = capi.DenseTracker(cfg)
+    many = _pairs(frames, 130)
+    for residency in (8, 62, 124):
+        out = trk.match_batch([frames[i] for i, _ in many], [frames[j] for _, j in many], in_flight=residency)
+        for ij, r in zip(many, out):
+            assert_same_result(want[ij], r, f"latency geometry: pair {ij} at residency {residency}")
+    subs = [trk.submit([frames[i] for i, _ in p], [frames[j] for _, j in p], in_flight=40) for p in (pairs, pairs[::-1][:7])]
+    for p, s in zip((pairs, pairs[::-1][:7]), subs):
+        for ij, r in zip(p, trk.wait(s)):
+            assert_same_result(want[ij], r, f"latency geometry: pair {ij} through the queue")
+    for n_bands in (1, 2, 8, 16):
+        for ij in pairs[:4]:
+            assert_same_result(want[ij], trk.match_banded(frames[ij[0]], frames[ij[1]], n_bands), f"latency geometry, {n_bands} bands")
+    # another configuration, another summation order: close, not identical
+    differs = 0
+    for ij in pairs:
+        d = synth.pose_error(singles[ij].Transformation, want[ij].Transformation)
+        assert d < 3e-4, (ij, d)
+        differs += not np.array_equal(singles[ij].Transformation, want[ij].Transformation)
+    assert differs > 0
+    # an unknown geometry is refused like any insane configuration
+    with pytest.raises(capi.DvoAmdError):
+        capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0, SegmentGeometry=7))
