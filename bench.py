@@ -309,14 +309,24 @@ def main():
         with open(os.environ["DVO_BENCH_MAPS"], "w") as fh:
             fh.write(open("/proc/self/maps").read())
     # single-pair latency (informational)
+    # One match() per frame is the reference's default deployment (dvo_ros/src/camera_dense_tracking.cpp:269): a tracker configured
+    # for it (dvo_amd_config::segment_geometry = DVO_AMD_GEOMETRY_LATENCY, round 5) next to the batch's own configuration.
     n_lat = 10
-    lat_rounds = []
-    for _ in range(0 if args.counter_leg else 3):  # the median of three rounds of ten: one round is at the mercy of whatever the box does in those 7 ms
-        t0 = time.perf_counter()
-        for i in range(n_lat):
-            r1 = trk.match(ref, curs[i % len(curs)])
-        lat_rounds.append((time.perf_counter() - t0) * 1e3 / n_lat)
-    single_ms = sorted(lat_rounds)[1] if lat_rounds else None
+
+    def latency_of(tracker):
+        rounds = []
+        for _ in range(0 if args.counter_leg else 3):  # the median of three rounds of ten: one round is at the mercy of whatever the box does in those 7 ms
+            t0 = time.perf_counter()
+            for i in range(n_lat):
+                tracker.match(ref, curs[i % len(curs)])
+            rounds.append((time.perf_counter() - t0) * 1e3 / n_lat)
+        return sorted(rounds)[1] if rounds else None
+    trk_latency = capi.DenseTracker(capi.Config(FirstLevel=first_level, LastLevel=0, SegmentGeometry=capi.GEOMETRY_LATENCY), device=device)
+    if not args.counter_leg:
+        trk_latency.match(ref, curs[0])  # (its scratch and streams exist before the clock starts)
+    single_ms = latency_of(trk_latency)
+    single_ms_batch_geometry = latency_of(trk)
+    del trk_latency
 
     # With one host thread the HIP events around every k_tick launch are taken inside the timed region.  With several
     # threads kernels of different streams overlap on the GPU, so the per-launch durations are measured in a second,
@@ -442,6 +452,12 @@ def main():
             "timed_region_check": region_check,
             "max_deviation_from_single_match": region_check["max_deviation_from_single_match"] if region_check else None,
             "single_pair_latency_ms": single_ms,
+            "single_pair_latency": {
+                "ms": single_ms, "configuration": "segment_geometry = DVO_AMD_GEOMETRY_LATENCY (levels 3..0 in 1/2/4/8 steps per wave)",
+                "ms_with_the_batch_configuration": single_ms_batch_geometry,
+                "batch_configuration": "segment_geometry = DVO_AMD_GEOMETRY_THROUGHPUT (4/4/8/8), what the timed region runs",
+                "what": "one dvo_amd_match() at a time through the Python binding, median of three rounds of ten pairs; the geometry "
+                        "is a field of the tracker's configuration and part of what a result is a function of"},
             "prep_ms_per_frame": prep_ms,
             "prep_ms_per_frame_first_use": prep_first_ms,
             # build the new frame's pyramid from host planes + one match()

@@ -35,7 +35,7 @@ EXPORTS = [
     "dvo_amd_exchange_create", "dvo_amd_exchange_attach", "dvo_amd_exchange_destroy",
     "dvo_amd_match_submit", "dvo_amd_match_wait", "dvo_amd_match_poll", "dvo_amd_debug_next_seq",
     "dvo_amd_set_reciprocal_mode", "dvo_amd_get_reciprocal_mode", "dvo_amd_debug_rcp", "dvo_amd_debug_block_trace",
-    "dvo_amd_debug_ll_overflow", "dvo_amd_debug_marker",
+    "dvo_amd_debug_ll_overflow", "dvo_amd_debug_marker", "dvo_amd_debug_rcp_form",
 ]
 
 
@@ -141,6 +141,7 @@ def lib():
     L.dvo_amd_get_reciprocal_mode.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.dvo_amd_debug_rcp.argtypes = [vp, C.c_int, fp, fp]
     L.dvo_amd_debug_marker.argtypes = [vp, C.c_uint]
+    L.dvo_amd_debug_rcp_form.argtypes = [vp, C.POINTER(C.c_int), C.c_char_p, C.c_int]
     L.dvo_amd_debug_ll_overflow.argtypes = [vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp,
                                             C.POINTER(C.c_int)]
     L.dvo_amd_pyramid_create.argtypes = [C.c_int, fp, fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
@@ -433,6 +434,12 @@ class DenseTracker:
         m, k = C.c_int(), C.c_int()
         _check(lib().dvo_amd_get_reciprocal_mode(self._h, C.byref(m), C.byref(k)), "dvo_amd_get_reciprocal_mode")
         return ("host_sse" if m.value else "exact"), k.value
+
+    def reciprocal_form(self):
+        """(diagnostic) ("off" | "table" | "nibbles", why the nibble form is not in use)"""
+        form, note = C.c_int(), C.create_string_buffer(256)
+        _check(lib().dvo_amd_debug_rcp_form(self._h, C.byref(form), note, 256), "dvo_amd_debug_rcp_form")
+        return ("off", "table", "nibbles")[form.value], note.value.decode()
 
     def table_rcp(self, x) -> np.ndarray:
         """the table reciprocal of every element as the kernels compute it (test entry; needs the host_sse mode)"""

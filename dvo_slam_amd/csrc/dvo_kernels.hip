@@ -118,6 +118,27 @@ __device__ __forceinline__ float rcp_host_table(float z, const RcpTable &rcp) {
   return u2f(r | (u & 0x80000000u));
 }
 
+// The nibble form (RcpTable::nibbles, round 5): no global-memory gather.  rcpps(1.m) is rebuilt from the device's own reciprocal of
+// the midpoint of m's cell -- its top bits, a pure function of the cell index -- plus a signed 4-bit correction from a table
+// in LDS (lds_nib: eight cells to a word); exponent and special cases as above.  Bit-identical to rcp_host_table by construction:
+// the corrections are (table entry - that very expression) evaluated on this device when the mode is switched on, and the
+// switch refuses the form if the expression differs between the two rounding modes the kernel uses it in.
+__device__ __forceinline__ unsigned rcp_midpoint_bits(unsigned cell, int shift) {
+  return f2u(__builtin_amdgcn_rcpf(u2f(0x3f800000u | (cell << shift) | (1u << (shift - 1)))));
+}
+__device__ __forceinline__ float rcp_host_nibbles(float z, const unsigned *lds_nib, int shift, int unit) {
+  const unsigned u = f2u(z), au = u & 0x7fffffffu, e = au >> 23, m = au & 0x7fffffu;
+  const unsigned cell = m >> shift;
+  const unsigned word = lds_nib[cell >> 3];
+  const int corr = (int)(((word >> ((cell & 7u) * 4u)) & 15u) ^ 8u) - 8;  // signed nibble
+  const unsigned t = (rcp_midpoint_bits(cell, shift) & ~((1u << unit) - 1u)) + (unsigned)(corr << unit);
+  const int re = (int)(t >> 23) - ((int)e - 127);
+  unsigned r = re >= 1 ? (((unsigned)re << 23) | (t & 0x7fffffu)) : 0u;
+  r = e == 0u ? 0x7f800000u : r;
+  r = e == 255u ? (m ? (au | 0x00400000u) : 0u) : r;
+  return u2f(r | (u & 0x80000000u));
+}
+
 // Pointers read from a descriptor in memory are generic ("flat") to the compiler; flat loads are slower and cannot be
 // counted separately from LDS traffic.  Everything the kernels touch lives in device global memory: say so.
 #define DVO_GLOBAL __attribute__((address_space(1)))
@@ -146,7 +167,8 @@ struct LevelPairDesc {
   int *seg_prefix[2];
   int w, h;
   float wc[6], wr[4], ub_x, ub_y;
-  RcpTable rcp;  // (only read by the RCP = 1 kernels)
+  RcpTable rcp;  // (only read by the RCP >= 1 kernels)
+  const unsigned *rcp_lds;  // (RCP = 2) the block's LDS copy of rcp.nibbles
 };
 
 // Block-level trace (builds with -DDVO_TRACE_BLOCKS only: scripts/variant.sh trace -DDVO_TRACE_BLOCKS; never in the shipped
@@ -190,7 +212,9 @@ __device__ __forceinline__ Proj project_pixel_rtz(const float *kt, const LevelPa
   const float sy = (kt[4] * x + kt[5] * y) + (kt[6] * z + kt[7]);
   Proj p;
   p.sz = (kt[8] * x + kt[9] * y) + (kt[10] * z + kt[11]);
-  const float rz = RCP ? rcp_host_table(p.sz, d.rcp) : rcp_toward_zero(p.sz);  // :192 (_mm_rcp_ps) / the exact quotient
+  const float rz = RCP == 2   ? rcp_host_nibbles(p.sz, d.rcp_lds, d.rcp.shift, d.rcp.unit)  // :192 (_mm_rcp_ps) ...
+                   : RCP == 1 ? rcp_host_table(p.sz, d.rcp)
+                              : rcp_toward_zero(p.sz);                                        // ... / the exact quotient
   p.u = sx * rz, p.v = sy * rz;
   // 0 <= u <= w-2 and 0 <= v <= h-2 (:160-161,203); NaN compares false.  (Bitwise and: four compares and three scalar ands;
   // the short-circuit form compiles to an exec-masked region.)
@@ -294,9 +318,19 @@ __host__ __device__ constexpr int gram_pair(int ci, int cj) { return ci == 0 ? c
 // (Measured and removed in round 3, DESIGN.md section 10: a five-waves-per-SIMD build, physical blocks walking several logical
 // ones, item tables in device memory.)
 // RCP 0 (default): 1 / z of the projection is the exactly truncated quotient, the t-distribution weight 7 v_rcp_f32(5 + d).
-// RCP 1 (dvo_amd_set_reciprocal_mode): both reciprocals are the host's _mm_rcp_ps, bit for bit (dense_tracking_impl.cpp:192,700).
+// RCP 1 (dvo_amd_set_reciprocal_mode): both reciprocals are the host's _mm_rcp_ps, bit for bit (dense_tracking_impl.cpp:192,700),
+//       from a table in global memory; RCP 2: the same function from a 2 KiB correction table in LDS (rcp_host_nibbles).
 template <int ACC, int RCP>
-__device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const int lb) {
+__device__ void residual_pass(const TickItem &it, const LevelPairDesc &d_in, const int lb) {
+  LevelPairDesc d = d_in;
+  __shared__ unsigned rcp_lds[RCP == 2 ? kRcpNibbleWordsMax : 1];
+  if (RCP == 2) {
+    // every block copies the corrections (L2-resident, 2 KiB) next to its staging area; the first projection waits for them
+    const int words = (1 << (23 - d.rcp.shift)) >> 3;
+    for (int i = threadIdx.x; i < words; i += kBlockThreads) rcp_lds[i] = ((const DVO_GLOBAL unsigned *)d.rcp.nibbles)[i];
+    __syncthreads();
+    d.rcp_lds = rcp_lds;
+  }
   constexpr int kBufs = 2;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
@@ -474,7 +508,9 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d, const 
       const float t0 = __builtin_fmaf(r0, P0, r1 * P1);
       const float t1 = __builtin_fmaf(r0, P2, r1 * P3);
       const float dd = __builtin_fmaf(t0, r0, t1 * r1);
-      wgt = 7.0f * (RCP ? rcp_host_table(5.0f + dd, d.rcp) : __builtin_amdgcn_rcpf(5.0f + dd));
+      wgt = 7.0f * (RCP == 2   ? rcp_host_nibbles(5.0f + dd, d.rcp_lds, d.rcp.shift, d.rcp.unit)
+                    : RCP == 1 ? rcp_host_table(5.0f + dd, d.rcp)
+                               : __builtin_amdgcn_rcpf(5.0f + dd));
     }
     wgt = ok ? wgt : 0.0f;
 
@@ -1022,6 +1058,7 @@ __device__ __forceinline__ void tick_body(const TickItem &it, const RcpTable &rc
   }
 #endif
   d.rcp = rcp;
+  d.rcp_lds = nullptr;
   if (bx < rb)
     residual_pass<ACC, RCP>(it, d, it.res_first + xcd_contiguous_block(bx, rb));
   else
@@ -1092,7 +1129,11 @@ template <int ACC, int RCP>
 __global__ __launch_bounds__(kBlockThreads, ACC == 0 ? 2 : 4) void k_tick_persist(const TickArgs args, const int total_blocks) {
   (void)args;
 #pragma nounroll
-  for (unsigned b = blockIdx.x; b < (unsigned)total_blocks; b += gridDim.x) {
+  for (unsigned base = 0, odd = 0; base < (unsigned)total_blocks; base += gridDim.x, odd ^= 1u) {
+    // boustrophedon: the items are sorted longest blocks first, so plain striding would hand physical block 0 the longest block
+    // of EVERY round; on odd rounds the order is reversed (the pieces of a sorted list dealt like this add up evenly)
+    const unsigned b = base + (odd ? gridDim.x - 1u - blockIdx.x : blockIdx.x);
+    if (b >= (unsigned)total_blocks) continue;
     // the argument block is re-read through an opaque copy of the kernarg pointer in every trip: hoisted out of the loop its
     // scalars (descriptor pointers, K T, block ranges of the item) stay live across the whole body and spill (106 SGPRs, 23 VGPRs
     // in scratch when this loop was written over `args` itself)
@@ -1115,8 +1156,30 @@ __global__ __launch_bounds__(kBlockThreads, 4) void k_tick_small(const TickArgsS
 }
 
 __global__ void k_rcp_table_probe(const RcpTable rcp, const float *__restrict__ in, float *__restrict__ out, int n) {
+  __shared__ unsigned nib[kRcpNibbleWordsMax];
+  if (rcp.nibbles) {
+    for (int i = threadIdx.x; i < ((1 << (23 - rcp.shift)) >> 3); i += blockDim.x) nib[i] = rcp.nibbles[i];
+    __syncthreads();
+  }
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = rcp_host_table(in[i], rcp);
+  if (i < n) out[i] = rcp.nibbles ? rcp_host_nibbles(in[i], nib, rcp.shift, rcp.unit) : rcp_host_table(in[i], rcp);
+}
+// v_rcp_f32 of every cell midpoint under both rounding modes the residual pass uses it in (the host builds the corrections of the
+// nibble form from the round-to-nearest column and refuses the form if the columns differ)
+__global__ void k_rcp_midpoint_probe(int k, unsigned *__restrict__ out_rn, unsigned *__restrict__ out_rtz) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (1u << k)) return;
+  unsigned cell = i;
+  asm volatile("" : "+v"(cell));
+  const unsigned a = rcp_midpoint_bits(cell, 23 - k);
+  unsigned keep = a;
+  asm volatile("" : "+v"(keep));
+  round_toward_zero();
+  asm volatile("" : "+v"(cell));
+  unsigned b = rcp_midpoint_bits(cell, 23 - k);
+  asm volatile("" : "+v"(b));
+  round_to_nearest();
+  out_rn[i] = keep, out_rtz[i] = b;
 }
 
 // DVO_AMD_LAUNCH_LOCK=1: a process-wide mutex around every kernel launch.  Only for profiled multi-thread runs: rocprofv3's
@@ -1152,7 +1215,9 @@ int acc_mode() {
 
 typedef void (*TickKernel)(const TickArgs);
 // (the host-rcpps mode exists for the default accumulator only)
-static TickKernel pick_tick_kernel(bool rcp_table) { return rcp_table ? k_tick<1, 1> : acc_mode() == 0 ? k_tick<0, 0> : k_tick<1, 0>; }
+static TickKernel pick_tick_kernel(const RcpTable &rcp) {
+  return rcp.nibbles ? k_tick<1, 2> : rcp.table ? k_tick<1, 1> : acc_mode() == 0 ? k_tick<0, 0> : k_tick<1, 0>;
+}
 
 // A tick's items are at different pyramid levels: the two-dimensional grid (blocks of the largest item x items) launches
 // mostly blocks that return at once, and the dispatcher starts only ~4 of them per nanosecond.  When more than half of the
@@ -1201,7 +1266,7 @@ static int tick_args_layout_impl(Args &args, int max_blocks) {
   }();
   static const bool persist_on = [] {
     const char *e = getenv("DVO_AMD_PERSIST");
-    return e && atoi(e) > 0;
+    return e && (atoi(e) > 0 || e[0] == 'a' || e[0] == 'A');
   }();
   args.compact = groups > 0 && groups < 65536 && (mode == 1 || persist_on || (mode == 2 && 2ll * 8 * groups < grid2d)) ? 1 : 0;
   return (int)(groups * 8);
@@ -1217,9 +1282,13 @@ hipError_t launch_tick_small(const TickArgsSmall &args, int max_blocks, hipStrea
   if (args.compact) grid = dim3((unsigned)args.group_first[args.n_items] * 8u, 1, 1);
   if (t_start && t_stop) {
     void *kargs[] = {const_cast<TickArgsSmall *>(&args)};
-    const void *kernel = args.rcp.table ? reinterpret_cast<const void *>(&k_tick_small<1>) : reinterpret_cast<const void *>(&k_tick_small<0>);
+    const void *kernel = args.rcp.nibbles ? reinterpret_cast<const void *>(&k_tick_small<2>)
+                         : args.rcp.table ? reinterpret_cast<const void *>(&k_tick_small<1>)
+                                          : reinterpret_cast<const void *>(&k_tick_small<0>);
     const hipError_t e = hipExtLaunchKernel(kernel, grid, dim3(kBlockThreads), kargs, 0, stream, t_start, t_stop, 0);
     if (e != hipSuccess) return e;
+  } else if (args.rcp.nibbles) {
+    hipLaunchKernelGGL(k_tick_small<2>, grid, dim3(kBlockThreads), 0, stream, args);
   } else if (args.rcp.table) {
     hipLaunchKernelGGL(k_tick_small<1>, grid, dim3(kBlockThreads), 0, stream, args);
   } else {
@@ -1232,20 +1301,31 @@ hipError_t launch_tick(const TickArgs &args, int max_blocks, hipStream_t stream,
   // the host-rcpps mode is built for the default accumulator only: under DVO_AMD_ACCUM=valu (the cross-check of the summation) it
   // is refused rather than silently run on the matrix pipe (dvo_amd_set_reciprocal_mode refuses first, with the reason)
   if (args.rcp.table && acc_mode() == 0) return hipErrorNotSupported;
-  TickKernel kernel = pick_tick_kernel(args.rcp.table != nullptr);
+  TickKernel kernel = pick_tick_kernel(args.rcp);
   if (args.n_items <= 0 || max_blocks <= 0) return hipSuccess;
   LaunchGuard guard;
   dim3 grid((unsigned)((max_blocks + 7) & ~7), (unsigned)args.n_items, 1);
   if (args.compact) grid = dim3((unsigned)args.group_first[args.n_items] * 8u, 1, 1);
-  static const int persist = [] {  // DVO_AMD_PERSIST=<physical blocks> (a multiple of 8): the static-partition experiment
+  // DVO_AMD_PERSIST=<physical blocks> (a multiple of 8): the static-partition experiment; "auto": as many physical blocks as give
+  // every one of them the same number of logical blocks, ceil(total / ceil(total / 1024)) -- a launch of 1 500 blocks then runs as
+  // 752 physical blocks of two logical blocks each instead of one full round of 1 024 and a round of 476, and leaves the other
+  // 272 block slots to the kernels of other streams
+  static const int persist_env = [] {
     const char *e = getenv("DVO_AMD_PERSIST");
+    if (e && (e[0] == 'a' || e[0] == 'A')) return -1;
     const int g = e ? atoi(e) : 0;
     return g > 0 ? ((g + 7) & ~7) : 0;
   }();
+  int persist = persist_env;
+  if (persist < 0) {
+    const int total = (int)grid.x, rounds = (total + 1023) / 1024;
+    persist = rounds > 1 ? ((((total + rounds - 1) / rounds) + 7) & ~7) : 0;
+  }
   if (persist > 0 && args.compact && acc_mode() == 1 && (int)grid.x > persist) {
     const int total = (int)grid.x;
     void *kargs[] = {const_cast<TickArgs *>(&args), const_cast<int *>(&total)};
-    const void *kp = args.rcp.table ? reinterpret_cast<const void *>(&k_tick_persist<1, 1>) : reinterpret_cast<const void *>(&k_tick_persist<1, 0>);
+    const void *kp = reinterpret_cast<const void *>(&k_tick_persist<1, 0>);
+    if (args.rcp.table) return hipErrorNotSupported;  // (the experiment exists for the default reciprocal only)
     const hipError_t e = (t_start && t_stop)
                              ? hipExtLaunchKernel(kp, dim3((unsigned)persist), dim3(kBlockThreads), kargs, 0, stream, t_start, t_stop, 0)
                              : hipLaunchKernel(kp, dim3((unsigned)persist), dim3(kBlockThreads), kargs, 0, stream);
@@ -1652,6 +1732,12 @@ __global__ void k_marker(unsigned *sink, unsigned tag) {
 hipError_t launch_marker(unsigned tag, hipStream_t stream) {
   LaunchGuard guard;
   hipLaunchKernelGGL(k_marker, dim3(1), dim3(64), 0, stream, (unsigned *)nullptr, tag & 0x7FFFFFFFu);
+  return hipGetLastError();
+}
+
+hipError_t launch_rcp_midpoint_probe(int k, unsigned *out_rn, unsigned *out_rtz, hipStream_t stream) {
+  LaunchGuard guard;
+  hipLaunchKernelGGL(k_rcp_midpoint_probe, dim3((unsigned)(((1 << k) + 255) / 256)), dim3(256), 0, stream, k, out_rn, out_rtz);
   return hipGetLastError();
 }
 

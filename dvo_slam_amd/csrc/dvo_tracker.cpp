@@ -481,19 +481,25 @@ struct dvo_amd_context {
   ncclResult_t (*p_allgather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*p_comm_destroy)(ncclComm_t) = nullptr;
   unsigned tick_seq = 0;
-  RcpTable rcp = {nullptr, 0, 0};     // opt-in: the host's _mm_rcp_ps from a table (dvo_amd_set_reciprocal_mode); null = exact
-  unsigned *rcp_table_dev = nullptr;  // the device copy of the table (kept once built)
+  RcpTable rcp = {nullptr, 0, 0, nullptr};  // opt-in: the host's _mm_rcp_ps from a table (dvo_amd_set_reciprocal_mode); null = exact
+  unsigned *rcp_table_dev = nullptr;    // the device copy of the table (kept once built)
+  unsigned *rcp_nibbles_dev = nullptr;  // ... and of the packed corrections of the nibble form (null: they do not fit four bits)
+  int rcp_unit = 0;
+  std::string rcp_form_note;            // why the nibble form is not in use (diagnostic)
   unsigned *ovf_host = nullptr, *ovf_dev = nullptr;  // pinned word for the verdict of k_ll_overflow (rare path)
   long long ovf_checks = 0, ovf_hits = 0;            // how often the exact overflow check ran / said yes (diagnostic)
   // Wave-step counts OF A LEVEL (its pixels / 64) from which its wave segments take 2 / 4 / 8 / 16 steps: the geometry of a
   // residual pass -- and with it the order every fp32 sum of the pass is taken in -- is a function of the level alone, never
   // of what else is resident in the tick (level_steps below).  DVO_AMD_LEVEL_STEPS_AT="a,b,c,d", read when the context is
   // created (a tuning knob: it changes results in the last bits like any other summation order would).
-  // Default: 640x480 levels 3..0 (75 / 300 / 1 200 / 4 800 wave steps) take 2 / 4 / 8 / 8 steps per wave, a 1280x960 level 0
-  // (19 200) takes 16.  Interleaved runs of the streaming bench (gpurun_out/r4b, r4c; pairs/s | single-pair latency):
-  // 4/8/8/8 46.6 k | 0.83 ms; 8/8/8/8 45.9 k | 0.84; 2/4/8/8 46.2 k | 0.76; 2/4/4/8 45.2 k | 0.72; 1/2/4/8 44.5 k | 0.70;
-  // 8/8/8/16 46.1 k | 0.84; 1/1/1/4 (what a single pair got until round 3) 35.8 k | 0.71.
-  long long level_steps_at[4] = {70, 250, 1000, 9600};
+  // Default (DVO_AMD_GEOMETRY_THROUGHPUT) since round 5: 640x480 levels 3..0 (75 / 300 / 1 200 / 4 800 wave steps) take 4 / 4 / 8 / 8
+  // steps per wave, a 1280x960 level 0 (19 200) takes 16.  Until round 4 the table was 2 / 4 / 8 / 8 (thresholds 70, 250, 1000,
+  // 9600): one table had to serve the batch and the single match(); now the latency-first table is a configuration of its own
+  // (segment_geometry) and this one is the fastest for batches: interleaved runs of the streaming bench in round 5
+  // (profiles/r05_geometry_ab.txt; pairs/s): 2/4/8/8 52.1 / 51.7 k, 4/4/8/8 52.8 / 53.4 k, 4/8/8/8 53.0 / 53.0 k.  Round 4's runs
+  // (gpurun_out/r4b, r4c; pairs/s | single-pair latency): 4/8/8/8 46.6 k | 0.83 ms; 8/8/8/8 45.9 k | 0.84; 2/4/8/8 46.2 k | 0.76;
+  // 2/4/4/8 45.2 k | 0.72; 1/2/4/8 44.5 k | 0.70; 8/8/8/16 46.1 k | 0.84; 1/1/1/4 (a single pair until round 3) 35.8 k | 0.71.
+  long long level_steps_at[4] = {18, 70, 1000, 9600};
   // dvo_amd_config::segment_geometry = DVO_AMD_GEOMETRY_LATENCY: 640x480 levels 3..0 take 1 / 2 / 4 / 8 steps per wave (1280x960
   // levels 4..0: 1 / 2 / 4 / 8 / 8): what a single match() got until round 3, as a configuration of the tracker -- honoured by
   // match(), the batched forms, the queue, the validator's stages and the band pipeline alike (round 5)
@@ -2176,6 +2182,7 @@ void dvo_amd_context_destroy(dvo_amd_context *ctx) {
   if (ctx->out_wire) (void)hipHostFree(ctx->out_wire);
   if (ctx->ovf_host) (void)hipHostFree(ctx->ovf_host);
   if (ctx->rcp_table_dev) (void)hipFree(ctx->rcp_table_dev);
+  if (ctx->rcp_nibbles_dev) (void)hipFree(ctx->rcp_nibbles_dev);
   for (auto &ev : ctx->events) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
@@ -2201,7 +2208,7 @@ int dvo_amd_set_reciprocal_mode(dvo_amd_context *ctx, int mode) {
   int rc = queue_must_be_idle(ctx, "dvo_amd_set_reciprocal_mode");
   if (rc) return rc;
   if (mode == DVO_AMD_RCP_EXACT) {
-    ctx->rcp = RcpTable{nullptr, 0, 0};
+    ctx->rcp = RcpTable{nullptr, 0, 0, nullptr};
     return DVO_AMD_OK;
   }
   if (acc_mode() == 0) {  // (the mode used to run the matrix-pipe accumulator silently under the switch)
@@ -2218,7 +2225,53 @@ int dvo_amd_set_reciprocal_mode(dvo_amd_context *ctx, int mode) {
     HIP_TRY(hipMalloc((void **)&ctx->rcp_table_dev, sizeof(uint32_t) * h.table.size()));
     HIP_TRY(hipMemcpy(ctx->rcp_table_dev, h.table.data(), sizeof(uint32_t) * h.table.size(), hipMemcpyHostToDevice));
   }
-  ctx->rcp = RcpTable{ctx->rcp_table_dev, 23 - h.k, 0};
+  // The nibble form (round 5): rcpps(1.m) = (the device's v_rcp_f32 of the cell's midpoint, bits below `unit` cleared) +
+  // correction << unit, the corrections in LDS instead of a gather from global memory in the dependent chain of every step.  The
+  // corrections are formed here against the device's OWN reciprocal, evaluated by a probe kernel in both rounding modes the residual
+  // pass uses it in; if the two differ, a correction leaves [-8, 7], or the table has more than 2^12 cells, the table form stays.
+  if (!ctx->rcp_nibbles_dev && ctx->rcp_form_note.empty()) {
+    const char *form = getenv("DVO_AMD_RCP_FORM");  // "table": keep the global-memory table (A/B)
+    const int n = 1 << h.k;
+    if (form && (form[0] == 't' || form[0] == 'T')) {
+      ctx->rcp_form_note = "DVO_AMD_RCP_FORM=table";
+    } else if (h.k > 12 || h.k < 4) {
+      ctx->rcp_form_note = "rcpps depends on more than 12 mantissa bits on this host";
+    } else {
+      unsigned *probe = nullptr;
+      HIP_TRY(hipMalloc((void **)&probe, sizeof(unsigned) * 2 * (size_t)n));
+      std::vector<unsigned> mid(2 * (size_t)n);
+      hipError_t e = launch_rcp_midpoint_probe(h.k, probe, probe + n, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e == hipSuccess) e = hipMemcpy(mid.data(), probe, sizeof(unsigned) * mid.size(), hipMemcpyDeviceToHost);
+      (void)hipFree(probe);
+      if (e != hipSuccess) return fail_hip("rcp midpoint probe", e);
+      uint32_t low = 0;
+      for (uint32_t t : h.table) low |= t & 0x7fffffu;
+      int unit = 0;
+      while (unit < 22 && !((low >> unit) & 1u)) ++unit;  // (every entry a power of two: unit stops at 22)
+      std::vector<unsigned> words((size_t)std::max(n / 8, 1), 0u);
+      for (int i = 0; i < n && ctx->rcp_form_note.empty(); ++i) {
+        if (mid[(size_t)i] != mid[(size_t)n + i]) {
+          ctx->rcp_form_note = "v_rcp_f32 depends on the rounding mode";
+          break;
+        }
+        const int64_t base = (int64_t)(mid[(size_t)i] & ~((1u << unit) - 1u));
+        const int64_t diff = (int64_t)h.table[(size_t)i] - base;
+        if (diff % (1ll << unit) != 0 || diff / (1ll << unit) < -8 || diff / (1ll << unit) > 7) {
+          ctx->rcp_form_note = "a correction does not fit four bits";
+          break;
+        }
+        const unsigned nib = (unsigned)((diff / (1ll << unit)) & 15);
+        words[(size_t)(i >> 3)] |= nib << ((i & 7) * 4);
+      }
+      if (ctx->rcp_form_note.empty()) {
+        HIP_TRY(hipMalloc((void **)&ctx->rcp_nibbles_dev, sizeof(unsigned) * words.size()));
+        HIP_TRY(hipMemcpy(ctx->rcp_nibbles_dev, words.data(), sizeof(unsigned) * words.size(), hipMemcpyHostToDevice));
+        ctx->rcp_unit = unit;
+      }
+    }
+  }
+  ctx->rcp = RcpTable{ctx->rcp_table_dev, 23 - h.k, ctx->rcp_unit, ctx->rcp_nibbles_dev};
   return DVO_AMD_OK;
 }
 
@@ -2226,6 +2279,13 @@ int dvo_amd_get_reciprocal_mode(const dvo_amd_context *ctx, int *mode, int *tabl
   if (!ctx) return DVO_AMD_ERR_INVALID_ARGUMENT;
   if (mode) *mode = ctx->rcp.table ? DVO_AMD_RCP_HOST_SSE : DVO_AMD_RCP_EXACT;
   if (table_mantissa_bits) *table_mantissa_bits = ctx->rcp.table ? 23 - ctx->rcp.shift : 0;
+  return DVO_AMD_OK;
+}
+
+int dvo_amd_debug_rcp_form(const dvo_amd_context *ctx, int *form, char *note, int note_capacity) {
+  if (!ctx || !form) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  *form = ctx->rcp.nibbles ? 2 : ctx->rcp.table ? 1 : 0;
+  if (note && note_capacity > 0) std::snprintf(note, (size_t)note_capacity, "%s", ctx->rcp_form_note.c_str());
   return DVO_AMD_OK;
 }
 

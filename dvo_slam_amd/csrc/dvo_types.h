@@ -158,8 +158,15 @@ constexpr int kMaxItemsPerLaunch = 62;  // (tick_locate: lanes 0 .. n_items of o
 struct RcpTable {
   const unsigned *table;  // device memory: bits of rcpps(1.m) for m = index << shift
   int shift;              // 23 - (mantissa bits rcpps depends on)
-  int pad;
+  int unit;               // (nibble form) the lowest mantissa bit any table entry sets: the corrections are in units of 1 << unit
+  // The same function without a global-memory gather in the dependent chain of every step (round 5): rcpps(1.m) =
+  // (v_rcp_f32(midpoint of m's cell) with the bits below `unit` cleared) + correction << unit, the corrections -- signed 4-bit,
+  // one per cell, 0 or 1 on the hosts seen so far -- packed eight to a word: 2 KiB for 2^12 cells, copied into LDS by every
+  // block.  Built on the DEVICE from the table above and the device's own v_rcp_f32 when the mode is switched on; null when a
+  // correction does not fit four bits (then the table form above runs).
+  const unsigned *nibbles;
 };
+constexpr int kRcpNibbleWordsMax = 512;  // 2^12 cells: what fits beside four blocks' staging areas in a CU's LDS
 struct TickArgs {
   int n_items;
   int compact;  // 0: grid (blocks of the largest item, n_items); 1: one-dimensional grid without the blocks no item owns
@@ -302,8 +309,11 @@ hipError_t launch_exchange_record(const FinOut *rec_dev, const struct ExchangeAr
 constexpr float kLlOverflowScreen = 7.0e6f;
 hipError_t read_finalize_stamps(unsigned long long out[8]);
 long long read_block_trace(unsigned long long *out, long long capacity);  // -1: not a trace build (see dvo_kernels.hip)
-// out[i] = the table reciprocal of in[i] (device pointers): the unit test of the opt-in host-rcpps mode
+// out[i] = the table reciprocal of in[i] (device pointers): the unit test of the opt-in host-rcpps mode (the nibble form when
+// rcp.nibbles is set, else the table form)
 hipError_t launch_rcp_table_probe(const RcpTable &rcp, const float *in, float *out, int n, hipStream_t stream);
+// out_rn[i] / out_rtz[i] = bits of v_rcp_f32(midpoint of cell i of [1, 2)) under round-to-nearest / round-toward-zero, i < 1 << k
+hipError_t launch_rcp_midpoint_probe(int k, unsigned *out_rn, unsigned *out_rtz, hipStream_t stream);
 
 hipError_t launch_marker(unsigned tag, hipStream_t stream);  // a no-op dispatch named k_marker (profile bracketing)
 int acc_mode();  // 1: Gram matrix on the matrix pipe (default); 0: DVO_AMD_ACCUM=valu, the 87-register cross-check form

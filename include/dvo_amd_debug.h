@@ -92,6 +92,11 @@ int dvo_amd_debug_tick_log(dvo_amd_context *ctx, double *out, int capacity_recor
  * reset, and the number of launches */
 int dvo_amd_kernel_timing(dvo_amd_context *ctx, int enable, double *ms_residual_pass, long long *n_launches, int reset);
 
+/* (diagnostic) which form of the host-rcpps mode the context's kernels run: 0 the mode is off, 1 a table in global memory (a gather
+ * in the dependent chain of every step), 2 the device's own reciprocal of the cell midpoint plus 4-bit corrections from LDS (round
+ * 5; bit-identical to form 1 by construction).  note: why form 2 is not in use ("" if it is or the mode is off). */
+int dvo_amd_debug_rcp_form(const dvo_amd_context *ctx, int *form, char *note, int note_capacity);
+
 /* (profiling aid) one no-op dispatch named `k_marker` on the context's main stream, waited for: bench.py brackets its
  * single-stream timing pass with two of them so that the summaries of a rocprofv3 run (kernel trace or counter pass) can select
  * exactly the k_tick dispatches in between (dvo_slam_amd/pmc.py) */

@@ -75,6 +75,38 @@ def _oracle_residual_image(orc, orr, occ, level, T, shape, mode):
     return img.reshape(shape[0], shape[1], 2), len(r)
 
 
+def test_the_two_forms_of_the_mode_are_the_same_function(capi, orc, synth, pair, monkeypatch, capsys):
+    """Round 5: the mode's reciprocal without a global-memory gather -- the device's own v_rcp_f32 of the midpoint of the input's
+    table cell plus a signed 4-bit correction from a 2 KiB table in LDS (dvo_kernels.hip: rcp_host_nibbles), the corrections formed
+    on the device when the mode is switched on.  Same function as the table form by construction: the instruction bit for bit
+    (the test above runs on whichever form the tracker picked), and a whole match() -- every statistic -- identical to the table
+    form's (DVO_AMD_RCP_FORM=table keeps the round-4 form)."""
+    nib = _tracker(capi, FirstLevel=3, LastLevel=0)
+    form, why = nib.reciprocal_form()
+    with capsys.disabled():
+        print(f"\n[rcpps] form in use: {form}" + (f" ({why})" if why else ""))
+    monkeypatch.setenv("DVO_AMD_RCP_FORM", "table")
+    tab = _tracker(capi, FirstLevel=3, LastLevel=0)
+    assert tab.reciprocal_form()[0] == "table"
+    monkeypatch.delenv("DVO_AMD_RCP_FORM")
+    if form != "nibbles":
+        pytest.skip("the nibble form is not available on this host: " + why)
+    rng = np.random.default_rng(7)
+    x = rng.integers(0, 2**32, size=500_000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    a, b = nib.table_rcp(x).view(np.uint32), tab.table_rcp(x).view(np.uint32)
+    ok = ~np.isnan(x)
+    assert np.array_equal(a[ok], b[ok])
+    for gr, gc in ((pair["gr"], pair["gc"]), (pair["gc"], pair["gr"])):
+        ra, rb = nib.match(gr, gc), tab.match(gr, gc)
+        assert np.array_equal(ra.Transformation, rb.Transformation) and np.array_equal(ra.Information, rb.Information)
+        assert ra.LogLikelihood == rb.LogLikelihood
+        assert [[it["ValidConstraints"] for it in L["Iterations"]] for L in ra.Levels] == \
+               [[it["ValidConstraints"] for it in L["Iterations"]] for L in rb.Levels]
+    out = nib.match_batch([pair["gr"]] * 20, [pair["gc"]] * 20, in_flight=12)
+    want = tab.match(pair["gr"], pair["gc"])
+    assert all(np.array_equal(want.Transformation, r.Transformation) for r in out)
+
+
 @pytest.mark.parametrize("level", [3, 2, 1, 0])
 def test_residuals_bit_exact_against_the_oracles_rcpps_mode(capi, orc, synth, pair, level):
     trk = _tracker(capi, FirstLevel=3, LastLevel=0)
