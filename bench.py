@@ -591,7 +591,7 @@ def main():
                              ("ingest", lambda: ingest_timing(capi, synth, cur_frames, K, levels, device)),
                              ("loop_closure_validator", lambda: validator_timing(capi, synth, W, H, device)),
                              ("dual_match_front_end", lambda: dual_match_timing(capi, ref, curs, levels, first_level, device)),
-                             ("cpu_baseline_all_cores", lambda: None if args.no_cpu_baseline else
+                             ("cpu_baseline_many_threads", lambda: None if args.no_cpu_baseline else
                               cpu_baseline_threads(args, ref_frame, cur_frames[:8], K, levels, first_level))):
                 try:
                     line[name] = fn()
@@ -844,8 +844,9 @@ def profiled_workload(args):
 def roofline_traffic(args, world, line):
     """HBM-side bytes per k_tick launch of the timing pass: (traffic, traffic_source).
 
-    A property of THIS run when it can be: on rank 0 of a one-GPU run bench.py starts the two rocprofv3 counter passes itself
-    (--pmc FETCH_SIZE and --pmc WRITE_SIZE, one pass each: they do not fit one) as child processes running the same workload
+    A property of THIS run when it can be: on rank 0 of a one-GPU run bench.py starts the rocprofv3 counter passes itself
+    (--pmc FETCH_SIZE and --pmc WRITE_SIZE, one pass each: they do not fit one; a third pass with SQ_INSTS_VALU + SQ_INSTS_MFMA
+    replaces roofline.issue's per-step model by the instruction counts of the launches themselves) as child processes running the same workload
     in its short form (--counter-leg), and summarises the k_tick dispatches between the two k_marker dispatches that bracket
     the timing pass (dvo_slam_amd/pmc.py; corrected as MI355X_MICROARCH.md prescribes for gfx950).  `traffic` is the upper
     bound (2 x FETCH_SIZE + WRITE_SIZE); the bounds, the write ratio and the wasted-traffic ratio are in traffic_source.
@@ -863,10 +864,22 @@ def roofline_traffic(args, world, line):
         leg += ["--drain-between-steps"] if args.drain_between_steps else []
         try:
             t0 = time.perf_counter()
-            d = pmc.measure_traffic_live(os.path.abspath(__file__), leg)
+            live = pmc.measure_live(os.path.abspath(__file__), leg)
+            d = live["traffic"]
             d["measured"] = "in this run"
-            d["seconds_spent_on_the_two_counter_passes"] = time.perf_counter() - t0
+            d["seconds_spent_on_the_counter_passes"] = time.perf_counter() - t0
             d["alg_bytes_per_launch_of_this_runs_timing_pass"] = line["roofline"]["alg_bytes_per_launch"]
+            iss = live.get("issue")
+            if iss and "issue_cycles" in iss and line["roofline"].get("avg_launch_us"):
+                # the issue roofline from the instruction counts of these very launches (the per-step model from a committed
+                # profile stays beside it as `issue_model`)
+                k_s = line["roofline"]["avg_launch_us"] * 1e-6 * line["roofline"]["launches"]
+                iss["peak_cycles"] = iss["simds"] * iss["peak_clock_hz"] * k_s
+                iss["frac"] = iss["issue_cycles"] / iss["peak_cycles"]
+                line["roofline"]["issue_model"] = line["roofline"].get("issue")
+                line["roofline"]["issue"] = iss
+            elif iss:
+                line["roofline"]["issue_live_pass"] = iss
             return d["traffic_bytes_per_launch"], d
         except Exception as exc:  # the bench line never depends on the profiler
             why_not = repr(exc)[:400]
@@ -1004,42 +1017,30 @@ def dual_match_timing(capi, keyframe, frames, levels, first_level, device):
 
 
 def cpu_baseline_threads(args, ref_frame, cur_frames, K, levels, first_level):
-    """SURVEY.md 8d (ii): one oracle tracker per hardware thread over independent pairs (the shape of tbb::parallel_reduce
-    over proposals); ctypes releases the GIL inside orc_match."""
-    import threading
-
+    """SURVEY.md 8d (ii): one oracle tracker per host thread over independent pairs (the shape of tbb::parallel_reduce over
+    proposals, keyframe_graph.cpp:587-590), the threads driven from C (orc_bench_threads).  Threads = the CPUs of this process's
+    affinity mask, at most 64: a bounded side measurement on a host that other jobs share -- named for what it is, not "all
+    cores" (round 4 ran the same 64 threads from Python and scaled 10.6x: most of a call was the binding's result marshalling
+    under the interpreter lock, not the alignment)."""
     from oracle import oracle as orc
 
     orc.select_build("native")  # -O3 -march=native, the reference's flags (dvo_core/CMakeLists.txt:38-40)
-    n_threads = min(os.cpu_count() or 1, 64)
     try:
-        n_threads = min(n_threads, len(os.sched_getaffinity(0)))
+        avail = len(os.sched_getaffinity(0))
     except AttributeError:
-        pass
+        avail = os.cpu_count() or 1
+    n_threads = max(1, min(avail, 64))
     pr = orc.Pyramid(ref_frame[0], ref_frame[1], K, levels)
     pcs = [orc.Pyramid(f[0], f[1], K, levels) for f in cur_frames]
     cfg = orc.default_config(first_level=first_level, last_level=0, rcp_mode=orc.RCP_SSE)
     budget = min(args.cpu_seconds, 8.0)
-    counts = [0] * n_threads
-    t0 = time.perf_counter()
-
-    def worker(t):
-        k = t
-        while time.perf_counter() - t0 < budget:
-            orc.match(cfg, pr, pcs[k % len(pcs)])
-            k += 1
-            counts[t] += 1
-
-    th = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
-    for x in th:
-        x.start()
-    for x in th:
-        x.join()
-    dt = time.perf_counter() - t0
+    n, dt = orc.bench_threads(cfg, pr, pcs, n_threads, budget)
     del pr, pcs
     orc.select_build("parity")
-    return {"value": sum(counts) / dt, "unit": "frame-pairs/s", "cores": n_threads, "kind": "port",
-            "sample": f"{sum(counts)} match() calls in {dt:.1f} s, {n_threads} threads, one oracle tracker each, shared pyramids"}
+    return {"value": n / dt, "unit": "frame-pairs/s", "cores": n_threads, "kind": "port", "cpus_in_the_affinity_mask": avail,
+            "host_hardware_threads": os.cpu_count(),
+            "sample": f"{n} match() calls in {dt:.1f} s on {n_threads} threads (C threads, one oracle tracker each, shared pyramids); "
+                      f"the cap of 64 threads is this bench's, not the host's"}
 
 
 def cpu_baseline(args, ref_frame, cur_frames, K, levels, first_level):

@@ -126,16 +126,25 @@ __device__ __forceinline__ float rcp_host_table(float z, const RcpTable &rcp) {
 __device__ __forceinline__ unsigned rcp_midpoint_bits(unsigned cell, int shift) {
   return f2u(__builtin_amdgcn_rcpf(u2f(0x3f800000u | (cell << shift) | (1u << (shift - 1)))));
 }
+// NAN_ANY: a NaN input may give ANY result (the residual pass: a NaN depth makes sx, sy NaN as well, so u, v are NaN and the pixel
+// invalid whatever 1 / z is; most wave steps hold such lanes -- unselected pixels -- and must not send the wave down the rare path).
+template <bool NAN_ANY>
 __device__ __forceinline__ float rcp_host_nibbles(float z, const unsigned *lds_nib, int shift, int unit) {
   const unsigned u = f2u(z), au = u & 0x7fffffffu, e = au >> 23, m = au & 0x7fffffu;
   const unsigned cell = m >> shift;
   const unsigned word = lds_nib[cell >> 3];
   const int corr = (int)(((word >> ((cell & 7u) * 4u)) & 15u) ^ 8u) - 8;  // signed nibble
   const unsigned t = (rcp_midpoint_bits(cell, shift) & ~((1u << unit) - 1u)) + (unsigned)(corr << unit);
-  const int re = (int)(t >> 23) - ((int)e - 127);
-  unsigned r = re >= 1 ? (((unsigned)re << 23) | (t & 0x7fffffu)) : 0u;
-  r = e == 0u ? 0x7f800000u : r;
-  r = e == 255u ? (m ? (au | 0x00400000u) : 0u) : r;
+  // Common case, branch free: t's exponent field is 126 or 127, so for 1 <= e <= 252 the result's exponent stays a normal one and
+  // scaling by 2^-(e - 127) is an integer subtraction on the bit pattern.  Zero / denormal inputs, results that would leave the
+  // normal range and infinities / NaNs (e = 0 or e >= 253) take the full rule; the wave branches only if one of its lanes has one.
+  unsigned r = t - ((e - 127u) << 23);
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(e - 1u >= 252u && !(NAN_ANY && au > 0x7f800000u)) != 0ull, 0)) {
+    const int re = (int)(t >> 23) - ((int)e - 127);
+    r = re >= 1 ? (((unsigned)re << 23) | (t & 0x7fffffu)) : 0u;
+    r = e == 0u ? 0x7f800000u : r;
+    r = e == 255u ? (m ? (au | 0x00400000u) : 0u) : r;
+  }
   return u2f(r | (u & 0x80000000u));
 }
 
@@ -212,7 +221,7 @@ __device__ __forceinline__ Proj project_pixel_rtz(const float *kt, const LevelPa
   const float sy = (kt[4] * x + kt[5] * y) + (kt[6] * z + kt[7]);
   Proj p;
   p.sz = (kt[8] * x + kt[9] * y) + (kt[10] * z + kt[11]);
-  const float rz = RCP == 2   ? rcp_host_nibbles(p.sz, d.rcp_lds, d.rcp.shift, d.rcp.unit)  // :192 (_mm_rcp_ps) ...
+  const float rz = RCP == 2   ? rcp_host_nibbles<true>(p.sz, d.rcp_lds, d.rcp.shift, d.rcp.unit)  // :192 (_mm_rcp_ps) ...
                    : RCP == 1 ? rcp_host_table(p.sz, d.rcp)
                               : rcp_toward_zero(p.sz);                                        // ... / the exact quotient
   p.u = sx * rz, p.v = sy * rz;
@@ -508,7 +517,7 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d_in, con
       const float t0 = __builtin_fmaf(r0, P0, r1 * P1);
       const float t1 = __builtin_fmaf(r0, P2, r1 * P3);
       const float dd = __builtin_fmaf(t0, r0, t1 * r1);
-      wgt = 7.0f * (RCP == 2   ? rcp_host_nibbles(5.0f + dd, d.rcp_lds, d.rcp.shift, d.rcp.unit)
+      wgt = 7.0f * (RCP == 2   ? rcp_host_nibbles<true>(5.0f + dd, d.rcp_lds, d.rcp.shift, d.rcp.unit)
                     : RCP == 1 ? rcp_host_table(5.0f + dd, d.rcp)
                                : __builtin_amdgcn_rcpf(5.0f + dd));
     }
@@ -1162,7 +1171,7 @@ __global__ void k_rcp_table_probe(const RcpTable rcp, const float *__restrict__ 
     __syncthreads();
   }
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = rcp.nibbles ? rcp_host_nibbles(in[i], nib, rcp.shift, rcp.unit) : rcp_host_table(in[i], rcp);
+  if (i < n) out[i] = rcp.nibbles ? rcp_host_nibbles<false>(in[i], nib, rcp.shift, rcp.unit) : rcp_host_table(in[i], rcp);
 }
 // v_rcp_f32 of every cell midpoint under both rounding modes the residual pass uses it in (the host builds the corrections of the
 // nibble form from the round-to-nearest column and refuses the form if the columns differ)

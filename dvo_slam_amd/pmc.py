@@ -24,10 +24,28 @@ MARKER = "k_marker"
 # streaming read (16 B per lane; 128-byte requests tallied at 64 B) -- double it; WRITE_SIZE is exact for streaming stores; other
 # access widths are uncalibrated.  k_tick's reads are a mix: 4-byte-per-lane streaming loads of the reference planes (16 of the
 # 56 algorithmic bytes per pixel), 16-byte and 8-byte gathers of the current planes (24), 8-byte-per-lane streaming reads of the
-# spilled residuals (8).  scripts/probes/fetch_calibration.hip measures the factor per access width on this very pattern
-# (profiles/r05_fetch_calibration.txt); without it the bounds are 1 x FETCH (no request is under-counted) and 2 x FETCH (every
-# request is).
+# spilled residuals (8).  scripts/probes/fetch_calibration.hip measured the factors on this part (profiles/r05_fetch_calibration.txt):
+# exactly 2.00 for 4-, 8- and 16-byte-per-lane STREAMING reads alike; >= 1.30 for k_tick's GATHER pattern (a mix of 128-byte and
+# 64-byte requests).  The raw bounds stay 1 x FETCH (no request under-counted) and 2 x FETCH (every request is: the guide's
+# correction, what `roofline.traffic` reports); fetch_model() below splits the counter into its streaming and gather parts.
 FETCH_FACTOR_BOUNDS = (1.0, 2.0)
+STREAMING_FACTOR = 2.0
+GATHER_FACTOR_CALIBRATED = 1.30
+# of the 56 algorithmic bytes per selected pixel: 16 reference planes + 8 residual re-read are streaming reads, 24 are gathers
+ALG_STREAMING_READ, ALG_GATHER_READ, ALG_WRITE, ALG_TOTAL = 24.0, 24.0, 8.0, 56.0
+
+
+def fetch_model(fetch_counted_bytes: float, alg_bytes: float) -> dict:
+    """true fetch bytes = S + g (C - S / 2): S the streaming bytes of the launch (every one read exactly once, counted at half),
+    C the counter, g in [1, 2] the true / counted ratio of the gathers (1.30 for the calibrated pattern)"""
+    S = alg_bytes * ALG_STREAMING_READ / ALG_TOTAL
+    gathers_counted = max(0.0, fetch_counted_bytes - S / STREAMING_FACTOR)
+    return {"streaming_bytes_assumed": S, "gather_bytes_counted": gathers_counted,
+            "fetch_bytes_bounds": [S + 1.0 * gathers_counted, S + 2.0 * gathers_counted],
+            "fetch_bytes_calibrated": S + GATHER_FACTOR_CALIBRATED * gathers_counted,
+            "alg_gather_bytes": alg_bytes * ALG_GATHER_READ / ALG_TOTAL,
+            "calibration": "profiles/r05_fetch_calibration.txt: streaming reads of 4 / 8 / 16 B per lane are counted at exactly 1/2, "
+                           "k_tick's gather pattern at 1/1.30 or less"}
 
 
 def _is_tick(name: str) -> bool:
@@ -93,6 +111,11 @@ def traffic_summary(fetch_csv: str, write_csv: str, bench_line: dict, command: s
     out["write_ratio_to_algorithmic"] = out["write_bytes_per_launch"] / out["alg_write_bytes_per_launch"]
     out["read_ratio_to_algorithmic_bounds"] = [b / out["alg_read_bytes_per_launch"] for b in out["fetch_bytes_per_launch_bounds"]]
     out["wasted_traffic_ratio_bounds"] = [out["traffic_bytes_per_launch_uncorrected"] / alg, out["traffic_bytes_per_launch"] / alg]
+    fm = fetch_model(f_kb * 1024.0, alg)
+    out["fetch_model"] = fm
+    out["traffic_bytes_per_launch_calibrated"] = fm["fetch_bytes_calibrated"] + out["write_bytes_per_launch"]
+    out["wasted_traffic_ratio_calibrated"] = out["traffic_bytes_per_launch_calibrated"] / alg
+    out["wasted_traffic_ratio_bounds_calibrated"] = [(b + out["write_bytes_per_launch"]) / alg for b in fm["fetch_bytes_bounds"]]
     out["bench_value_under_pmc"] = bench_line.get("value")
     if command:
         out["command"] = command
@@ -101,7 +124,11 @@ def traffic_summary(fetch_csv: str, write_csv: str, bench_line: dict, command: s
                    "partials.  FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read on gfx950 (MI355X_MICROARCH.md), so "
                    "the read side is bracketed by 1 x and 2 x FETCH_SIZE; wasted_traffic_ratio_bounds = (bounds of FETCH + WRITE) / "
                    "algorithmic bytes: a ratio well above 1 would mean wasted re-reads, below 1 that part of the algorithmic bytes "
-                   "(neighbouring gathers, the residual re-read) never left L2 / the Infinity Cache.")
+                   "(neighbouring gathers, the residual re-read) never left L2 / the Infinity Cache.  fetch_model splits the counter "
+                   "with the calibrated factors (streaming reads exactly 2, the gather pattern >= 1.30): "
+                   "wasted_traffic_ratio_calibrated is the best estimate, wasted_traffic_ratio_bounds_calibrated its bounds for gather "
+                   "factors of 1 and 2.  The writes exceed the algorithmic 8 B per SELECTED pixel because the spill covers every pixel "
+                   "of the level (NaN marks the ~10 % unselected ones) and every block adds a 416-byte record.")
     return out
 
 
@@ -112,36 +139,66 @@ def rocprofv3_path() -> str | None:
     return None
 
 
-def measure_traffic_live(bench_py: str, leg_args: list, timeout_s: float = 150.0) -> dict:
-    """The two counter passes as child processes of the caller: `rocprofv3 --pmc <counter> -- python3 bench.py <leg_args>` each,
-    in a scratch directory (cwd /tmp as the profiler wants), DVO_AMD_LAUNCH_LOCK=1 (rocprofv3's queue interceptor and several
-    host threads: profiles/r03_rocprofv3_sigsegv_root_cause.md).  Returns traffic_summary() of the two; raises on any failure."""
+def _counter_pass(prof, counters, bench_py, leg_args, tmp, env, timeout_s):
+    """one `rocprofv3 --pmc <counters> -- python3 bench.py <leg_args>` child: (bench line it printed, counter csv path)"""
+    d = os.path.join(tmp, "_".join(counters))
+    cmd = [prof, "--pmc"] + list(counters) + ["-d", d, "-o", "pmc", "--output-format", "csv", "--", sys.executable, bench_py] + leg_args
+    res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+    if res.returncode != 0:
+        raise RuntimeError(f"{counters} pass failed (rc {res.returncode}): {res.stderr[-600:]}")
+    out_lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    if not out_lines:
+        raise RuntimeError(f"{counters} pass printed no bench line: {res.stdout[-300:]} {res.stderr[-300:]}")
+    found = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith("counter_collection.csv")]
+    if not found:
+        raise RuntimeError(f"{counters} pass left no counter_collection.csv under {d}")
+    return json.loads(out_lines[-1]), found[0]
+
+
+def issue_summary(csv_path: str, bench_line: dict, valu_issue_cycles=4, mfma_issue_cycles=8, simds=1024, clock_hz=2.4e9) -> dict:
+    """VALU + MFMA issue cycles of the timing pass's k_tick launches from SQ_INSTS_VALU / SQ_INSTS_MFMA of those very dispatches
+    (wave instructions; SQ_INSTS_VALU counts the MFMA instructions too), against every SIMD issuing every cycle for the launches'
+    own duration as the UN-profiled run measured it (the caller passes its k_tick milliseconds: counters slow the kernels down)."""
+    valu, _ = counter_per_launch(csv_path, "SQ_INSTS_VALU")
+    mfma, _ = counter_per_launch(csv_path, "SQ_INSTS_MFMA")
+    n = int(bench_line["roofline"]["launches"])
+    if len(valu) != n or len(mfma) != n:
+        raise RuntimeError(f"issue counters: {len(valu)} / {len(mfma)} k_tick dispatches between the markers, bench.py timed {n}")
+    plain = sum(valu) - sum(mfma)
+    cyc = plain * valu_issue_cycles + sum(mfma) * mfma_issue_cycles
+    return {"bound": "VALU+MFMA issue", "valu_wave_instructions": plain, "mfma_wave_instructions": sum(mfma), "launches": n,
+            "valu_issue_cycles": valu_issue_cycles, "mfma_issue_cycles": mfma_issue_cycles, "issue_cycles": cyc,
+            "simds": simds, "peak_clock_hz": clock_hz,
+            "measured": "SQ_INSTS_VALU / SQ_INSTS_MFMA of the timing pass's own k_tick dispatches, one rocprofv3 --pmc pass run by "
+                        "this bench (the launch time is the un-profiled run's)"}
+
+
+def measure_live(bench_py: str, leg_args: list, timeout_s: float = 150.0, with_issue: bool = True) -> dict:
+    """The counter passes as child processes of the caller: `rocprofv3 --pmc <counters> -- python3 bench.py <leg_args>` each (FETCH_SIZE
+    and WRITE_SIZE do not fit one pass; SQ_INSTS_VALU + SQ_INSTS_MFMA do), in a scratch directory (cwd /tmp as the profiler
+    wants), DVO_AMD_LAUNCH_LOCK=1 (rocprofv3's queue interceptor and several host threads:
+    profiles/r03_rocprofv3_sigsegv_root_cause.md).  Returns {"traffic": traffic_summary(), "issue": issue_summary() or an error
+    string}; raises if a traffic pass fails."""
     prof = rocprofv3_path()
     if prof is None:
         raise RuntimeError("rocprofv3 not found")
     tmp = tempfile.mkdtemp(prefix="dvo_pmc_", dir="/tmp")
     env = dict(os.environ, DVO_AMD_LAUNCH_LOCK="1", TMPDIR="/tmp")
     env.pop("DVO_BENCH_MAPS", None)
-    lines, csvs = {}, {}
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, counter)
-            cmd = [prof, "--pmc", counter, "-d", d, "-o", "pmc", "--output-format", "csv", "--", sys.executable, bench_py] + leg_args
-            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
-            if res.returncode != 0:
-                raise RuntimeError(f"{counter} pass failed (rc {res.returncode}): {res.stderr[-600:]}")
-            out_lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
-            if not out_lines:
-                raise RuntimeError(f"{counter} pass printed no bench line: {res.stdout[-300:]} {res.stderr[-300:]}")
-            lines[counter] = json.loads(out_lines[-1])
-            found = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith("counter_collection.csv")]
-            if not found:
-                raise RuntimeError(f"{counter} pass left no counter_collection.csv under {d}")
-            csvs[counter] = found[0]
-        summary = traffic_summary(csvs["FETCH_SIZE"], csvs["WRITE_SIZE"], lines["FETCH_SIZE"],
+        line_f, csv_f = _counter_pass(prof, ("FETCH_SIZE",), bench_py, leg_args, tmp, env, timeout_s)
+        line_w, csv_w = _counter_pass(prof, ("WRITE_SIZE",), bench_py, leg_args, tmp, env, timeout_s)
+        summary = traffic_summary(csv_f, csv_w, line_f,
                                   command="rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (one pass each) -- python3 bench.py " + " ".join(leg_args),
-                                  bench_line_write=lines["WRITE_SIZE"])
-        summary["launches_of_the_write_pass"] = int(lines["WRITE_SIZE"]["roofline"]["launches"])
-        return summary
+                                  bench_line_write=line_w)
+        summary["launches_of_the_write_pass"] = int(line_w["roofline"]["launches"])
+        out = {"traffic": summary, "issue": None}
+        if with_issue:
+            try:
+                line_i, csv_i = _counter_pass(prof, ("SQ_INSTS_VALU", "SQ_INSTS_MFMA"), bench_py, leg_args, tmp, env, timeout_s)
+                out["issue"] = issue_summary(csv_i, line_i)
+            except Exception as exc:  # the traffic figure does not depend on the third pass
+                out["issue"] = {"error": repr(exc)[:300]}
+        return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

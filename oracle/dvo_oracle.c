@@ -1242,6 +1242,62 @@ int orc_iteration(orc_pyramid *ref, orc_pyramid *cur, int level, float ti, float
 }
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * throughput of the restated path on many host threads (bench.py's cpu_baseline_many_threads leg): one tracker per thread over
+ * independent pairs -- the shape of tbb::parallel_reduce over proposals (keyframe_graph.cpp:587-590) -- driven from C so that no
+ * interpreter lock sits between two match() calls (round 4's Python-threaded leg scaled 10.6x on 64 threads: most of a call was
+ * the binding's own result marshalling under the GIL).  The pyramids are shared read-only (the reference selection of `ref` must
+ * have been built: run one orc_match first).
+ * ------------------------------------------------------------------------------------------------------------------ */
+#include <pthread.h>
+#include <time.h>
+typedef struct {
+  const orc_config *cfg;
+  orc_pyramid *ref;
+  orc_pyramid *const *curs;
+  int n_curs, index;
+  double seconds;
+  long long done;
+} bench_arg;
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+static void *bench_worker(void *p) {
+  bench_arg *a = (bench_arg *)p;
+  const double t0 = now_s();
+  int k = a->index;
+  while (now_s() - t0 < a->seconds) {
+    orc_result res;
+    res.iterations = NULL, res.iterations_capacity = 0;
+    if (orc_match(a->cfg, a->ref, a->curs[k % a->n_curs], NULL, &res) != 0) break;
+    ++k, ++a->done;
+  }
+  return NULL;
+}
+long long orc_bench_threads(const orc_config *cfg, orc_pyramid *ref, orc_pyramid *const *curs, int n_curs, int n_threads,
+                            double seconds, double *elapsed_s) {
+  if (n_threads < 1 || n_threads > 1024 || n_curs < 1) return -1;
+  pthread_t th[1024];
+  static bench_arg args[1024];
+  const double t0 = now_s();
+  int started = 0;
+  for (int t = 0; t < n_threads; ++t) {
+    args[t].cfg = cfg, args[t].ref = ref, args[t].curs = curs, args[t].n_curs = n_curs, args[t].index = t, args[t].seconds = seconds;
+    args[t].done = 0;
+    if (pthread_create(&th[t], NULL, bench_worker, &args[t]) != 0) break;
+    ++started;
+  }
+  long long total = 0;
+  for (int t = 0; t < started; ++t) {
+    pthread_join(th[t], NULL);
+    total += args[t].done;
+  }
+  if (elapsed_s) *elapsed_s = now_s() - t0;
+  return started == n_threads ? total : -2;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
  * frame ingest
  * ------------------------------------------------------------------------------------------------------------------ */
 

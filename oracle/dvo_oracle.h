@@ -172,6 +172,12 @@ typedef struct {
 /* res->levels[0] is from->level and counts only the iterations run here (their ids continue at from->iteration).  -4: bad state */
 int orc_match_from(const orc_config *cfg, orc_pyramid *ref, orc_pyramid *cur, const orc_match_state *from, orc_result *res);
 
+/* bench.py's many-thread CPU baseline: n_threads threads, each calling orc_match(cfg, ref, curs[k % n_curs]) for `seconds`;
+ * returns the number of alignments finished (all threads), *elapsed_s the wall time.  `ref`'s selection must exist already (run
+ * one orc_match before): the pyramids are shared read-only. */
+long long orc_bench_threads(const orc_config *cfg, orc_pyramid *ref, orc_pyramid *const *curs, int n_curs, int n_threads,
+                            double seconds, double *elapsed_s);
+
 /* Frame ingest.
  * depth: SurfacePyramid::convertRawDepthImage / ...Sse (surface_pyramid.cpp:44-105): 0 -> NaN, else (float)raw * scale
  * (one fp32 multiply); callers use scale 1/5000 (benchmark_slam.cpp:77) or 0.001 (camera_dense_tracking.cpp:234).

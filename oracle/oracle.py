@@ -51,7 +51,7 @@ def build_native() -> str:
     if not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in src):
         os.makedirs(os.path.dirname(path), exist_ok=True)
         subprocess.run([os.environ.get("CC", "gcc"), "-O3", "-march=native", "-msse3", "-fPIC", "-std=gnu11", "-shared", "-o",
-                        path + ".tmp", src[0], "-lm"], check=True)
+                        path + ".tmp", src[0], "-lm", "-lpthread"], check=True)
         os.replace(path + ".tmp", path)
     return path
 
@@ -125,6 +125,9 @@ def lib():
                                             C.POINTER(C.c_ubyte)]
         L.orc_match.argtypes = [C.POINTER(Config), C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(Result)]
         L.orc_match_from.argtypes = [C.POINTER(Config), C.c_void_p, C.c_void_p, C.POINTER(MatchState), C.POINTER(Result)]
+        L.orc_bench_threads.restype = C.c_longlong
+        L.orc_bench_threads.argtypes = [C.POINTER(Config), C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_double,
+                                        C.POINTER(C.c_double)]
         L.orc_ingest_depth_u16.argtypes = [C.POINTER(C.c_ushort), C.c_int, C.c_int, C.c_int, C.c_float, fp]
         L.orc_ingest_gray_from_bgr8.argtypes = [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, fp]
         L.orc_ingest_gray_from_gray8.argtypes = [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, fp]
@@ -289,6 +292,17 @@ def _run_match(cfg, ref, cur, T_init, state):
         out["levels"].append({"id": L.id, "max_valid_pixels": L.max_valid_pixels, "valid_pixels": L.valid_pixels,
                               "termination": L.termination, "iterations": iters})
     return out
+
+
+def bench_threads(cfg: Config, ref: Pyramid, curs, n_threads: int, seconds: float):
+    """orc_bench_threads: (alignments finished by all threads, wall seconds); the threads run in C, no interpreter in the loop"""
+    match(cfg, ref, curs[0])  # builds ref's selection before the threads share it
+    arr = (C.c_void_p * len(curs))(*[c.h for c in curs])
+    dt = C.c_double()
+    n = lib().orc_bench_threads(C.byref(cfg), ref.h, arr, len(curs), int(n_threads), float(seconds), C.byref(dt))
+    if n < 0:
+        raise RuntimeError(f"orc_bench_threads failed: {n}")
+    return int(n), dt.value
 
 
 def se3_exp(xi):

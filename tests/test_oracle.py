@@ -605,3 +605,40 @@ def test_fork_criterion_resynchronises_a_stand_in(orc, synth, capsys):
         print()
         for ln in lines:
             print(ln)
+
+
+def test_q7_tail_weights_are_below_every_sums_rounding(orc, synth, capsys):
+    """Q7: computeWeightsSse forms the first 4 * floor(V / 4) weights with rcpps and the last V mod 4 with an exact division
+    (dense_tracking_impl.cpp:667-706).  The HIP path's host-rcpps mode takes EVERY weight from the rcpps table -- a stated deviation
+    (include/dvo_amd.h, DVO_AMD_RCP_HOST_SSE).  Its size, measured on the reference's own arithmetic: the at most three tail weights
+    change by <= 2^-12 relative, i.e. the weighted sums a weight enters (scale, A, b) by <= 3 / V * 2^-12 ~ 4e-9 of their size at
+    V = 2e5 -- two orders of magnitude below the fp32 rounding of a single term and five below the 2e-4 by which the reference's own
+    sequential fp32 sums miss the exact ones.  No test at the level of a sum, an increment or a pose can see it."""
+    import ctypes as C
+
+    (Ir, Zr), (Ic, Zc), Tgt = synth.make_pair(640, 480)
+    K = synth.intrinsics_for(640, 480)
+    pr, pc = orc.Pyramid(Ir, Zr, K, 1), orc.Pyramid(Ic, Zc, K, 1)
+    pe, res, _ = orc.compute_residuals(pr, pc, 0, Tgt, orc.RCP_SSE)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+    worst = 0.0
+    for tail in range(4):  # V mod 4 = 0 .. 3
+        r = np.ascontiguousarray(res[: len(res) - ((len(res) - tail) % 4)], np.float32)
+        n = len(r)
+        assert n % 4 == tail
+        P0 = np.array([1e-3, 0, 0, 1e5], np.float32)  # a previous precision of the size the level-0 iterations see
+        w_ref, cov, P = np.zeros(n, np.float32), np.zeros(4, np.float32), np.zeros(4, np.float32)
+        orc.lib().orc_weights_scale_loglik(fp(r), n, fp(P0), 0, orc.RCP_SSE, fp(w_ref), fp(cov), fp(P))
+        d = (r[:, 0] * P0[0] + r[:, 1] * P0[1]) * r[:, 0] + (r[:, 0] * P0[2] + r[:, 1] * P0[3]) * r[:, 1]
+        w_all = (np.float32(7.0) * orc.host_rcp((np.float32(5.0) + d).astype(np.float32))).astype(np.float32)
+        n4 = n - n % 4
+        assert np.array_equal(w_all[:n4], w_ref[:n4])            # the body: the very rcpps weights
+        tail_rel = np.abs(w_all[n4:].astype(np.float64) - w_ref[n4:]) / w_ref[n4:] if n % 4 else np.zeros(1)
+        assert tail_rel.max() <= 2.0 ** -11
+        # what that does to a weighted sum of the pass (float64, so that nothing else is in the difference)
+        rr = (r[:, 0].astype(np.float64) ** 2)
+        s_ref, s_all = (w_ref.astype(np.float64) * rr).sum(), (w_all.astype(np.float64) * rr).sum()
+        worst = max(worst, abs(s_all - s_ref) / abs(s_ref))
+    with capsys.disabled():
+        print(f"\n[Q7 tail] all-table weights vs the reference's exact-division tail: a weighted sum of the pass moves by at most {worst:.1e} relative")
+    assert worst < 1e-7
