@@ -574,9 +574,17 @@ def main():
                     t0 = time.perf_counter()
                     run_steps(n, tally)
                     dt = time.perf_counter() - t0
+                    mb_pair = sum(c[0] - c[4] for c in tally) / (B * n) / 1e6
+                    conc = sum(c[0] - c[4] for c in tally) / dt / 1e9 / HBM_PEAK_GBS
                     return {"value": B * n / dt, "unit": "frame-pairs/s", "steps": n,
                             "relative_to_the_default_mode": (B * n / dt) / value,
                             "iterations_per_pair": sum(c[3] for c in tally) / (B * n),
+                            "useful_algorithmic_mb_per_pair": mb_pair,
+                            "concurrent_frac_of_hbm_peak": conc,
+                            # the same work per second?  rcpps arithmetic converges differently (more iterations, more of them on
+                            # the fine levels): pairs/s compares two different amounts of work, bytes/s does not
+                            "relative_to_the_default_mode_at_equal_work": conc / (useful / elapsed_local / 1e9 / HBM_PEAK_GBS),
+                            "form": trackers[0].reciprocal_form()[0],
                             "table_mantissa_bits": trackers[0].reciprocal_mode()[1],
                             "what": "dvo_amd_set_reciprocal_mode(DVO_AMD_RCP_HOST_SSE): 1 / z of the projection and the reciprocal of "
                                     "the t-distribution weights are this host's _mm_rcp_ps from a device-resident table"}
@@ -1037,8 +1045,18 @@ def cpu_baseline_threads(args, ref_frame, cur_frames, K, levels, first_level):
     n, dt = orc.bench_threads(cfg, pr, pcs, n_threads, budget)
     del pr, pcs
     orc.select_build("parity")
+    quota = None  # the CPU time this container may use, in cores (cgroup v2 cpu.max / v1 cfs quota): what the threads really share
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()) if q > 0 else None
+        except Exception:
+            pass
     return {"value": n / dt, "unit": "frame-pairs/s", "cores": n_threads, "kind": "port", "cpus_in_the_affinity_mask": avail,
-            "host_hardware_threads": os.cpu_count(),
+            "host_hardware_threads": os.cpu_count(), "container_cpu_quota_cores": quota,
             "sample": f"{n} match() calls in {dt:.1f} s on {n_threads} threads (C threads, one oracle tracker each, shared pyramids); "
                       f"the cap of 64 threads is this bench's, not the host's"}
 
