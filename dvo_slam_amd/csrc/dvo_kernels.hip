@@ -1128,34 +1128,6 @@ __global__ __launch_bounds__(kBlockThreads, ACC == 0 ? 2 : 4) void k_tick(const 
   tick_body<ACC, RCP>(args.items[idx], args.rcp, bx);
 }
 
-// EXPERIMENT (round 5; DVO_AMD_PERSIST=<grid>): a fixed grid of physical blocks, each walking the launch's
-// logical blocks b, b + G, b + 2 G ... of the compact (one-dimensional) layout -- a STATIC partition: no claim counter, no atomics
-// (round 2's dynamic claims lost 4-8 %: the claim's round trip sat between two logical blocks).  G is a multiple of 8, so a logical
-// block keeps the XCD its index maps to.  Same per-pixel code, same records, same summation tree: results are bit-identical to
-// the one-block-per-logical-block launch.  The barrier between two logical blocks protects the LDS staging the tail of a block
-// still reads (the moment gather, the ordered combine of the wave segments).
-template <int ACC, int RCP>
-__global__ __launch_bounds__(kBlockThreads, ACC == 0 ? 2 : 4) void k_tick_persist(const TickArgs args, const int total_blocks) {
-  (void)args;
-#pragma nounroll
-  for (unsigned base = 0, odd = 0; base < (unsigned)total_blocks; base += gridDim.x, odd ^= 1u) {
-    // boustrophedon: the items are sorted longest blocks first, so plain striding would hand physical block 0 the longest block
-    // of EVERY round; on odd rounds the order is reversed (the pieces of a sorted list dealt like this add up evenly)
-    const unsigned b = base + (odd ? gridDim.x - 1u - blockIdx.x : blockIdx.x);
-    if (b >= (unsigned)total_blocks) continue;
-    // the argument block is re-read through an opaque copy of the kernarg pointer in every trip: hoisted out of the loop its
-    // scalars (descriptor pointers, K T, block ranges of the item) stay live across the whole body and spill (106 SGPRs, 23 VGPRs
-    // in scratch when this loop was written over `args` itself)
-    const DVO_CONST TickArgs *pa = (const DVO_CONST TickArgs *)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(pa));
-    const TickArgs &a = *(const TickArgs *)pa;
-    int bx;
-    const int idx = tick_locate(a, bx, b);
-    tick_body<ACC, RCP>(a.items[idx], a.rcp, bx);
-    __syncthreads();
-  }
-}
-
 // the same kernel behind the small argument block of a tick of at most kMaxSmallItems pairs
 template <int RCP>
 __global__ __launch_bounds__(kBlockThreads, 4) void k_tick_small(const TickArgsSmall args) {
@@ -1273,11 +1245,7 @@ static int tick_args_layout_impl(Args &args, int max_blocks) {
     const char *e = getenv("DVO_AMD_COMPACT_GRID");
     return e ? (e[0] == '0' ? 0 : 1) : 2;
   }();
-  static const bool persist_on = [] {
-    const char *e = getenv("DVO_AMD_PERSIST");
-    return e && (atoi(e) > 0 || e[0] == 'a' || e[0] == 'A');
-  }();
-  args.compact = groups > 0 && groups < 65536 && (mode == 1 || persist_on || (mode == 2 && 2ll * 8 * groups < grid2d)) ? 1 : 0;
+  args.compact = groups > 0 && groups < 65536 && (mode == 1 || (mode == 2 && 2ll * 8 * groups < grid2d)) ? 1 : 0;
   return (int)(groups * 8);
 }
 int tick_args_layout(TickArgs &args, int max_blocks) { return tick_args_layout_impl(args, max_blocks); }
@@ -1315,31 +1283,6 @@ hipError_t launch_tick(const TickArgs &args, int max_blocks, hipStream_t stream,
   LaunchGuard guard;
   dim3 grid((unsigned)((max_blocks + 7) & ~7), (unsigned)args.n_items, 1);
   if (args.compact) grid = dim3((unsigned)args.group_first[args.n_items] * 8u, 1, 1);
-  // DVO_AMD_PERSIST=<physical blocks> (a multiple of 8): the static-partition experiment; "auto": as many physical blocks as give
-  // every one of them the same number of logical blocks, ceil(total / ceil(total / 1024)) -- a launch of 1 500 blocks then runs as
-  // 752 physical blocks of two logical blocks each instead of one full round of 1 024 and a round of 476, and leaves the other
-  // 272 block slots to the kernels of other streams
-  static const int persist_env = [] {
-    const char *e = getenv("DVO_AMD_PERSIST");
-    if (e && (e[0] == 'a' || e[0] == 'A')) return -1;
-    const int g = e ? atoi(e) : 0;
-    return g > 0 ? ((g + 7) & ~7) : 0;
-  }();
-  int persist = persist_env;
-  if (persist < 0) {
-    const int total = (int)grid.x, rounds = (total + 1023) / 1024;
-    persist = rounds > 1 ? ((((total + rounds - 1) / rounds) + 7) & ~7) : 0;
-  }
-  if (persist > 0 && args.compact && acc_mode() == 1 && (int)grid.x > persist) {
-    const int total = (int)grid.x;
-    void *kargs[] = {const_cast<TickArgs *>(&args), const_cast<int *>(&total)};
-    const void *kp = reinterpret_cast<const void *>(&k_tick_persist<1, 0>);
-    if (args.rcp.table) return hipErrorNotSupported;  // (the experiment exists for the default reciprocal only)
-    const hipError_t e = (t_start && t_stop)
-                             ? hipExtLaunchKernel(kp, dim3((unsigned)persist), dim3(kBlockThreads), kargs, 0, stream, t_start, t_stop, 0)
-                             : hipLaunchKernel(kp, dim3((unsigned)persist), dim3(kBlockThreads), kargs, 0, stream);
-    return e != hipSuccess ? e : hipGetLastError();
-  }
   if (t_start && t_stop) {
     void *kargs[] = {const_cast<TickArgs *>(&args)};
     const hipError_t e = hipExtLaunchKernel(reinterpret_cast<const void *>(kernel), grid, dim3(kBlockThreads), kargs, 0, stream,
