@@ -7,10 +7,11 @@ BUILD_ID := $(shell python3 dvo_slam_amd/_build.py --print-id)
 
 all: $(LIB)
 
-$(LIB): $(SRC)/dvo_kernels.hip $(SRC)/dvo_tracker.cpp $(SRC)/dvo_validator.cpp $(SRC)/dvo_frontend.cpp $(SRC)/dvo_tum.cpp \
-        $(SRC)/dvo_types.h $(SRC)/se3.h include/dvo_amd.h include/dvo_amd_debug.h
-	$(HIPCC) $(FLAGS) '-DDVO_AMD_BUILD_ID="$(BUILD_ID)"' -x hip $(SRC)/dvo_kernels.hip $(SRC)/dvo_tracker.cpp $(SRC)/dvo_validator.cpp $(SRC)/dvo_frontend.cpp \
-	    $(SRC)/dvo_tum.cpp -lz -o $@
+CPP := $(SRC)/dvo_kernels.hip $(SRC)/dvo_pyramid.cpp $(SRC)/dvo_tracker.cpp $(SRC)/dvo_sharded.cpp $(SRC)/dvo_probes.cpp \
+       $(SRC)/dvo_validator.cpp $(SRC)/dvo_frontend.cpp $(SRC)/dvo_tum.cpp
+
+$(LIB): $(CPP) $(SRC)/dvo_types.h $(SRC)/dvo_internal.h $(SRC)/se3.h include/dvo_amd.h include/dvo_amd_debug.h
+	$(HIPCC) $(FLAGS) '-DDVO_AMD_BUILD_ID="$(BUILD_ID)"' -x hip $(CPP) -lz -o $@
 
 oracle:
 	$(MAKE) -C oracle

@@ -16,8 +16,9 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("DVO_AMD_LIB") or os.path.join(_HERE, "libdvo_amd.so")
-SOURCES = ["dvo_kernels.hip", "dvo_tracker.cpp", "dvo_validator.cpp", "dvo_frontend.cpp", "dvo_tum.cpp"]
-HEADERS = ["dvo_types.h", "se3.h", os.path.join("..", "..", "include", "dvo_amd.h"),
+SOURCES = ["dvo_kernels.hip", "dvo_pyramid.cpp", "dvo_tracker.cpp", "dvo_sharded.cpp", "dvo_probes.cpp", "dvo_validator.cpp",
+           "dvo_frontend.cpp", "dvo_tum.cpp"]
+HEADERS = ["dvo_types.h", "dvo_internal.h", "se3.h", os.path.join("..", "..", "include", "dvo_amd.h"),
            os.path.join("..", "..", "include", "dvo_amd_debug.h")]
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",

@@ -967,7 +967,7 @@ __global__ __launch_bounds__(kWave) void k_ll_overflow(const float2 *__restrict_
   // rank of the first valid pixel BEHIND the chunk (only the chunk's own segments are known to hold this pass's residuals)
   // rank_end >= 0: the band is CLOSED -- the residuals behind it live on another GPU -- and rank_end is the rank of the first
   // valid pixel behind it: the band's last chunk then stops at the last group that ends inside the band (the group that
-  // straddles the edge is settled by the host from the ranks' edge records, dvo_tracker.cpp: sharded_overflow)
+  // straddles the edge is settled by the host from the ranks' edge records, dvo_sharded.cpp: sharded_overflow)
   const bool last_chunk = s1 >= seg_first + n_segs;
   const int e = !last_chunk ? rank_offset + seg_prefix[s1] : (rank_end >= 0 ? rank_end : 0x7fffffff);
   const int first = a + (50 - a % 50) % 50;                          // first group that starts in the chunk
@@ -1654,7 +1654,7 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize_small(const FinArgsSma
 }
 
 // The one-hop exchange of a ready-made record (device memory): the rare second exchange of a tick of a tile-sharded pair -- the
-// band-edge terms of the reference's 50-term likelihood products (dvo_tracker.cpp: sharded_overflow) travel as a FinOut-shaped
+// band-edge terms of the reference's 50-term likelihood products (dvo_sharded.cpp: sharded_overflow) travel as a FinOut-shaped
 // record through the same mapped buffers, tags and generations as the tick records do.
 __global__ __launch_bounds__(kFinThreadsBatch) void k_exchange_record(const FinOut *__restrict__ rec, const ExchangeArgs *exchange, unsigned xseq) {
   __shared__ __attribute__((aligned(16))) FinOut sh_out;

@@ -37,7 +37,7 @@ One artefact of the reference is worth a note when it occurs (overflow_note): co
 Mahalanobis distance above ~7e6 that product overflows, the reference's likelihood is -inf and it rejects the iteration.  This
 needs precisions of 1e9 and more, which only noise-free synthetic depth produces (2 of the 64 alignments of BASELINE config 5's
 scenario; never on sensor data, where the depth precision is ~1e4).  The GPU path reproduces it, tile-sharded pairs included
-(csrc/dvo_tracker.cpp: ll_overflowed, sharded_overflow).  The oracle's `ll_guard` mode -- the same sum without the overflow --
+(csrc/dvo_tracker.cpp: ll_overflowed; csrc/dvo_sharded.cpp: sharded_overflow).  The oracle's `ll_guard` mode -- the same sum without the overflow --
 shows how far the artefact moves the answer (tests/test_gpu_parity.py::test_overflowing_likelihood_is_reproduced).
 """
 import numpy as np
