@@ -453,7 +453,7 @@ def main():
             "max_deviation_from_single_match": region_check["max_deviation_from_single_match"] if region_check else None,
             "single_pair_latency_ms": single_ms,
             "single_pair_latency": {
-                "ms": single_ms, "configuration": "segment_geometry = DVO_AMD_GEOMETRY_LATENCY (levels 3..0 in 1/2/4/8 steps per wave)",
+                "ms": single_ms, "configuration": "segment_geometry = DVO_AMD_GEOMETRY_LATENCY (levels 3..0 in 1/2/2/4 steps per wave)",
                 "ms_with_the_batch_configuration": single_ms_batch_geometry,
                 "batch_configuration": "segment_geometry = DVO_AMD_GEOMETRY_THROUGHPUT (4/4/8/8), what the timed region runs",
                 "what": "one dvo_amd_match() at a time through the Python binding, median of three rounds of ten pairs; the geometry "

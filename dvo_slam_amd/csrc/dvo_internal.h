@@ -174,10 +174,12 @@ struct dvo_amd_context {
   // (gpurun_out/r4b, r4c; pairs/s | single-pair latency): 4/8/8/8 46.6 k | 0.83 ms; 8/8/8/8 45.9 k | 0.84; 2/4/8/8 46.2 k | 0.76;
   // 2/4/4/8 45.2 k | 0.72; 1/2/4/8 44.5 k | 0.70; 8/8/8/16 46.1 k | 0.84; 1/1/1/4 (a single pair until round 3) 35.8 k | 0.71.
   long long level_steps_at[4] = {18, 70, 1000, 9600};
-  // dvo_amd_config::segment_geometry = DVO_AMD_GEOMETRY_LATENCY: 640x480 levels 3..0 take 1 / 2 / 4 / 8 steps per wave (1280x960
-  // levels 4..0: 1 / 2 / 4 / 8 / 8): what a single match() got until round 3, as a configuration of the tracker -- honoured by
-  // match(), the batched forms, the queue, the validator's stages and the band pipeline alike (round 5)
-  long long level_steps_at_latency[4] = {250, 1000, 4000, 38400};
+  // dvo_amd_config::segment_geometry = DVO_AMD_GEOMETRY_LATENCY: 640x480 levels 3..0 take 1 / 2 / 2 / 4 steps per wave (1280x960
+  // levels 4..0: 1 / 2 / 2 / 4 / 4): short segments spread a level over more waves -- the shortest single match() of the tables
+  // measured (profiles/r05_latency_geometries.txt: 0.60 ms against 0.63 for 1/2/4/8 and 0.66 for the batch's 4/4/8/8) --, a
+  // configuration of the tracker honoured by match(), the batched forms, the queue, the validator's stages and the band pipeline
+  // alike (round 5)
+  long long level_steps_at_latency[4] = {250, 4000, 38400, 999999};
   int fault_slot_alloc = -1;           // DVO_AMD_FAULT_SLOT_ALLOC: fail the allocation of this slot once (tests of the error path)
   bool fin_stamps = false;             // DVO_AMD_FIN_STAMPS=1: k_finalize records phase stamps (diagnostic)
   bool sort_items = true;              // longest-lived blocks first inside a launch (DVO_AMD_SORT_ITEMS=0: slot order)

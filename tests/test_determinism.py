@@ -178,7 +178,7 @@ def test_stage_probe_runs_the_geometry_match_runs(capi, synth, frames, singles):
 
 
 def test_the_latency_geometry_is_a_configuration_like_any_other(capi, synth, frames, singles):
-    """dvo_amd_config::segment_geometry = DVO_AMD_GEOMETRY_LATENCY (round 5; 640x480 levels 3..0 in 1 / 2 / 4 / 8 steps per wave:
+    """dvo_amd_config::segment_geometry = DVO_AMD_GEOMETRY_LATENCY (round 5; 640x480 levels 3..0 in 1 / 2 / 2 / 4 steps per wave:
     the shortest single match()).  It is part of what a result is a function of, like every other field of the configuration:
     under it match() == batch at any residency == the queue == every band count, bit for bit -- and it is NOT the default
     geometry's result bit for bit (another summation order: agreement to summation noise, the same path or a fork)."""
