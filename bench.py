@@ -168,6 +168,24 @@ def pair_index(i, n_refs, n_curs):
     return i % n_refs, (i // n_refs) % n_curs
 
 
+def workload_cur_pose(synth, i):
+    """camera pose of current frame i of the synthetic workload (hashed: every frame a different motion of 0.5 .. 1.4 x the headline
+    pair's, alternating sign, plus a small second component)"""
+    return synth.se3_exp(synth.XI_GT_PAIR * (0.5 + 0.9 * ((i * 7) % 13) / 13.0) * (1 if i % 2 == 0 else -1)
+                         + synth.XI_GT_PAIR[::-1] * 0.03 * ((i * 5) % 11 - 5))
+
+
+def workload_ref_frame(synth, W, H, rank, k):
+    """keyframe k of the synthetic workload (k = 0: the scene's reference view)"""
+    if k == 0:
+        return synth.render(W, H, None, frame_id=2 * rank)
+    return synth.render(W, H, synth.se3_exp(synth.XI_GT_PAIR * 0.05 * k), frame_id=1000 + 2 * rank + k)
+
+
+def workload_cur_frame(synth, W, H, rank, i):
+    return synth.render(W, H, workload_cur_pose(synth, i), frame_id=2 * rank + 1 + 2 * i)
+
+
 def main():
     args = parse()
     maybe_spawn_ranks(args)
@@ -201,13 +219,13 @@ def main():
     n_curs, n_refs = max(1, args.distinct), max(1, args.distinct_refs)
 
     # ---- synthetic frames (seeded, rank-dependent): `distinct` current frames and `distinct-refs` keyframes at hashed poses
+    # (tests/test_bench_workload.py checks a sample of exactly these pairs against the oracle)
     def cur_pose(i):
-        return synth.se3_exp(synth.XI_GT_PAIR * (0.5 + 0.9 * ((i * 7) % 13) / 13.0) * (1 if i % 2 == 0 else -1)
-                             + synth.XI_GT_PAIR[::-1] * 0.03 * ((i * 5) % 11 - 5))
+        return workload_cur_pose(synth, i)
 
     t0 = time.perf_counter()
-    ref_frame = synth.render(W, H, None, frame_id=2 * rank)
-    cur_frames = [synth.render(W, H, cur_pose(i), frame_id=2 * rank + 1 + 2 * i) for i in range(n_curs)]
+    ref_frame = workload_ref_frame(synth, W, H, rank, 0)
+    cur_frames = [workload_cur_frame(synth, W, H, rank, i) for i in range(n_curs)]
     t_render = time.perf_counter() - t0
 
     # ---- pyramids (prep): built once, resident in HBM
@@ -234,7 +252,7 @@ def main():
     ref_pyrs = [ref]
     ref_frames_extra = []
     for i in range(1, n_refs):
-        fr = synth.render(W, H, synth.se3_exp(synth.XI_GT_PAIR * 0.05 * i), frame_id=1000 + 2 * rank + i)
+        fr = workload_ref_frame(synth, W, H, rank, i)
         ref_frames_extra.append(fr)
         ref_pyrs.append(capi.RgbdImagePyramid(fr[0], fr[1], K, levels, device=device))
     n_pyramids = len(ref_pyrs) + len(curs)
