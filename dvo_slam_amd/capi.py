@@ -35,7 +35,7 @@ EXPORTS = [
     "dvo_amd_exchange_create", "dvo_amd_exchange_attach", "dvo_amd_exchange_destroy",
     "dvo_amd_match_submit", "dvo_amd_match_wait", "dvo_amd_match_poll", "dvo_amd_debug_next_seq",
     "dvo_amd_set_reciprocal_mode", "dvo_amd_get_reciprocal_mode", "dvo_amd_debug_rcp", "dvo_amd_debug_block_trace",
-    "dvo_amd_debug_ll_overflow", "dvo_amd_debug_marker", "dvo_amd_debug_rcp_form",
+    "dvo_amd_debug_ll_overflow", "dvo_amd_debug_marker", "dvo_amd_debug_rcp_form", "dvo_amd_debug_weights",
 ]
 
 
@@ -81,6 +81,12 @@ class CIterationProbe(C.Structure):
                 ("scale", C.c_float * 4), ("precision", C.c_float * 4), ("moments", C.c_double * 87),
                 ("information", C.c_double * 36), ("rhs", C.c_double * 6), ("loglik_sum", C.c_double),
                 ("loglik", C.c_float), ("reserved_f", C.c_float)]
+
+
+class CQ7Probe(C.Structure):
+    _fields_ = [("n_tail", C.c_int), ("valid_constraints", C.c_int), ("valid_counted", C.c_int), ("recomputed_equal", C.c_int),
+                ("pixel", C.c_int * 3), ("weight_table", C.c_float * 3), ("weight_exact", C.c_float * 3),
+                ("scale_sums_delta", C.c_double * 3), ("moments_delta", C.c_double * 87)]
 
 
 class DvoAmdError(RuntimeError):
@@ -173,6 +179,7 @@ def lib():
     L.dvo_amd_residuals.argtypes = [vp, vp, vp, C.c_int, fp, fp, C.POINTER(C.c_int)]
     L.dvo_amd_error_image.argtypes = [vp, vp, vp, dp, C.c_int, fp]
     L.dvo_amd_debug_iteration.argtypes = [vp, vp, vp, C.c_int, fp, fp, fp, C.POINTER(CIterationProbe)]
+    L.dvo_amd_debug_weights.argtypes = [vp, vp, vp, C.c_int, fp, fp, fp, C.POINTER(CQ7Probe)]
     L.dvo_amd_kernel_timing.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_longlong), C.c_int]
     L.dvo_amd_bench_residual_pass.argtypes = [vp, vp, vp, C.c_int, fp, C.c_int, C.c_int, C.c_int, dp, dp,
                                               C.POINTER(C.c_int)]
@@ -637,6 +644,23 @@ class DenseTracker:
                 "precision": np.array(pr.precision[:], np.float32).reshape(2, 2).T.copy(), "ll": float(pr.loglik),
                 "A": np.array(pr.information[:]).reshape(6, 6).T.copy(), "b": np.array(pr.rhs[:]),
                 "moments": np.array(pr.moments[:]), "scale_sums": np.array(pr.scale_sums[:]), "ll_sum": pr.loglik_sum}
+
+    def weights_probe(self, reference: RgbdImagePyramid, current: RgbdImagePyramid, level: int, T, precision_in):
+        """(test entry, dvo_amd_debug.h; host-rcpps mode only) the t-distribution weights of one residual pass at T under the 2x2
+        precision_in as the product kernel formed them -- [h, w], NaN where the pixel is no constraint -- and what k_q7_tail did
+        about the last V mod 4 of them (Q7): dict(n_tail, n, n_counted, recomputed_equal, pixel, w_table, w_exact, scale_sums_delta,
+        moments_delta)"""
+        w, h, _ = reference.level_info(level)
+        out = np.empty((h, w), np.float32)
+        Tf = np.ascontiguousarray(np.asarray(T, dtype=np.float64).astype(np.float32).T)
+        pin = np.ascontiguousarray(np.asarray(precision_in, np.float32).T).ravel()
+        q = CQ7Probe()
+        _check(lib().dvo_amd_debug_weights(self._h, reference._h, current._h, level, _fp(Tf), _fp(pin), _fp(out), C.byref(q)),
+               "dvo_amd_debug_weights")
+        return out, {"n_tail": q.n_tail, "n": q.valid_constraints, "n_counted": q.valid_counted,
+                     "recomputed_equal": bool(q.recomputed_equal), "pixel": list(q.pixel[:]),
+                     "w_table": np.array(q.weight_table[:], np.float32), "w_exact": np.array(q.weight_exact[:], np.float32),
+                     "scale_sums_delta": np.array(q.scale_sums_delta[:]), "moments_delta": np.array(q.moments_delta[:])}
 
     def ll_overflow_probe(self, residuals, n_blocks: int, steps: int, seg_first: int, n_segs: int, rank_offset: int, rank_end: int,
                           cut_rank: int, precision) -> bool:

@@ -105,6 +105,7 @@ struct JobSlot {
   double *ll_partials = nullptr;
   float *ll_qmax = nullptr;   // per likelihood block: the largest Mahalanobis distance it took (behind ll_partials)
   unsigned ll_qmax_off = 0;   // ... its distance from ll_partials in doubles
+  Q7Rec *q7 = nullptr;        // (host-rcpps mode) what k_q7_tail leaves for k_finalize, behind ll_qmax
   int *seg_prefix[2] = {nullptr, nullptr};
   FinWire *out = nullptr;     // pinned host memory as the device sees it: the record arrives here as tagged pieces
   FinOut *out_dev = nullptr;  // device staging of the record
@@ -160,6 +161,9 @@ struct dvo_amd_context {
   unsigned *rcp_nibbles_dev = nullptr;  // ... and of the packed corrections of the nibble form (null: they do not fit four bits)
   int rcp_unit = 0;
   std::string rcp_form_note;            // why the nibble form is not in use (diagnostic)
+  int q7_off256 = 0;                    // a slot's Q7Rec lives 256 * q7_off256 bytes behind its ll_partials (ensure_slots)
+  float *dbg_w_dev = nullptr;           // dvo_amd_debug_weights: per-pixel weights of slot 0's residual pass
+  size_t dbg_w_capacity = 0;
   unsigned *ovf_host = nullptr, *ovf_dev = nullptr;  // pinned word for the verdict of k_ll_overflow (rare path)
   long long ovf_checks = 0, ovf_hits = 0;            // how often the exact overflow check ran / said yes (diagnostic)
   // Wave-step counts OF A LEVEL (its pixels / 64) from which its wave segments take 2 / 4 / 8 / 16 steps: the geometry of a

@@ -178,6 +178,7 @@ struct LevelPairDesc {
   float wc[6], wr[4], ub_x, ub_y;
   RcpTable rcp;  // (only read by the RCP >= 1 kernels)
   const unsigned *rcp_lds;  // (RCP = 2) the block's LDS copy of rcp.nibbles
+  float *dbg_w;  // (RCP >= 1 kernels, test instrumentation) SlotDesc::dbg_w
 };
 
 // Block-level trace (builds with -DDVO_TRACE_BLOCKS only: scripts/variant.sh trace -DDVO_TRACE_BLOCKS; never in the shipped
@@ -513,15 +514,18 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d_in, con
     // computeWeightsSse / computeWeight: w = (2+5)/(5 + r^T P r), mean 0 (dense_tracking_impl.cpp:640-707)
     float wgt = 1.0f;
     if (!unit_w) {
-      // (round-to-nearest section: fused multiply-adds are fine here, only the toward-zero stage is bit-matched)
-      const float t0 = __builtin_fmaf(r0, P0, r1 * P1);
-      const float t1 = __builtin_fmaf(r0, P2, r1 * P3);
-      const float dd = __builtin_fmaf(t0, r0, t1 * r1);
+      // (round-to-nearest section: in the default mode fused multiply-adds are fine here, only the toward-zero stage is
+      //  bit-matched; the host-rcpps kernels form the distance as computeWeightsSse does, product by product (:669-697), so that
+      //  every weight is the reference's bit for bit)
+      const float t0 = RCP ? r0 * P0 + r1 * P1 : __builtin_fmaf(r0, P0, r1 * P1);
+      const float t1 = RCP ? r0 * P2 + r1 * P3 : __builtin_fmaf(r0, P2, r1 * P3);
+      const float dd = RCP ? t0 * r0 + t1 * r1 : __builtin_fmaf(t0, r0, t1 * r1);
       wgt = 7.0f * (RCP == 2   ? rcp_host_nibbles<true>(5.0f + dd, d.rcp_lds, d.rcp.shift, d.rcp.unit)
                     : RCP == 1 ? rcp_host_table(5.0f + dd, d.rcp)
                                : __builtin_amdgcn_rcpf(5.0f + dd));
     }
     wgt = ok ? wgt : 0.0f;
+    if (RCP && d.dbg_w) ((DVO_GLOBAL float *)d.dbg_w)[cur_idx] = ok ? wgt : u2f(0x7fc00000u);  // (dvo_amd_debug_weights only)
 
     // Jacobians at the untransformed reference point (dense_tracking.cpp:333-339,448-476)
     // (Formed from the pixel's ray instead -- x / z is tx, y / z is ty: five instructions fewer, same Jacobian to an ulp -- the
@@ -1068,6 +1072,7 @@ __device__ __forceinline__ void tick_body(const TickItem &it, const RcpTable &rc
 #endif
   d.rcp = rcp;
   d.rcp_lds = nullptr;
+  d.dbg_w = RCP ? ((const DVO_CONST SlotDesc *)it.slot)->dbg_w : nullptr;
   if (bx < rb)
     residual_pass<ACC, RCP>(it, d, it.res_first + xcd_contiguous_block(bx, rb));
   else
@@ -1135,6 +1140,155 @@ __global__ __launch_bounds__(kBlockThreads, 4) void k_tick_small(const TickArgsS
   const int idx = tick_locate(args, bx);
   tick_body<1, RCP>(args.items[idx], args.rcp, bx);
 }
+
+// ---- Q7 in the host-rcpps mode (dense_tracking_impl.cpp:702-706; Q7Rec in dvo_types.h) -------------------------------------------
+// One wave per residual pass of a tick launch, after k_tick and before k_finalize on the same stream: V from the pass's block
+// records, the last V mod 4 valid pixels from the per-wave counts and the spilled residuals (walked backwards), then those <= 3
+// pixels once more through the residual pass's own functions -- lane j takes tail pixel j -- for their Jacobians, and what
+// (w_exact - w_table) adds to the pair sums (Q5: an odd rank weights its partner's residual; the tail starts on a multiple of
+// four, so the partner is in the tail) and to the 87 moments, in double.  Costs one small dispatch per tick, in this mode only.
+template <class Args>
+__device__ __forceinline__ void q7_tail_wave(const Args &args) {
+  const TickItem &it = args.items[blockIdx.x];
+  const int lane = threadIdx.x;
+  LevelPairDesc d = load_desc(it);
+  d.rcp = args.rcp;
+  d.rcp_lds = nullptr, d.dbg_w = nullptr;
+  DVO_GLOBAL Q7Rec *const rec = (DVO_GLOBAL Q7Rec *)((DVO_GLOBAL char *)d.ll_partials + 256u * (unsigned)args.q7_off256);
+  const gcf recs = (gcf)d.records;
+  const int nb = it.res_blocks, steps = item_res_steps(it), seg_px = kStepPx * steps;
+  int v = 0;
+  for (int b = lane; b < nb; b += kWave) v += (int)f2u(recs[(size_t)b * kRecStride + kRecCount]);
+  for (int o = kWave / 2; o; o >>= 1) v += __shfl_xor(v, o);
+  const int n_tail = (it.flags & kItemUnitWeights) ? 0 : (v & 3);
+  __shared__ double sh_delta[3][3 + kNumAcc];
+  __shared__ int sh_idx[3];
+  __shared__ float sh_r0[3], sh_r1[3];
+  if (lane < 3) {
+    sh_idx[lane] = 0, sh_r0[lane] = sh_r1[lane] = 0.0f;
+    for (int i = 0; i < 3 + kNumAcc; ++i) sh_delta[lane][i] = 0.0;
+  }
+  __syncthreads();
+  int found = 0;  // wave uniform; tail pixels are found last first
+  if (n_tail) {
+    const DVO_GLOBAL v2f *const res = (const DVO_GLOBAL v2f *)((it.flags & kItemResBuf) ? d.res[1] : d.res[0]);
+    for (int sg = nb * kWavesPerBlock - 1; sg >= 0 && found < n_tail; --sg) {
+      const int c = __builtin_amdgcn_readfirstlane((int)f2u(recs[(size_t)(sg >> 2) * kRecStride + kRecWaveCnt + (sg & 3)]));
+      if (c == 0) continue;
+      for (int st = steps - 1; st >= 0 && found < n_tail; --st) {
+        const int first = sg * seg_px + st * kStepPx;
+        const v2f r = res[first + lane];
+        unsigned long long m = __ballot(r.x == r.x);  // NaN marks an invalid pixel
+        while (m && found < n_tail) {
+          const int hi = 63 - __builtin_clzll(m);
+          const float r0 = __shfl(r.x, hi), r1 = __shfl(r.y, hi);
+          if (lane == 0) sh_idx[found] = first + hi, sh_r0[found] = r0, sh_r1[found] = r1;
+          m &= ~(1ull << hi);
+          ++found;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const bool mine = lane < n_tail && found == n_tail;
+  float w_table = 0.0f, w_exact = 0.0f;
+  bool equal = true;
+  int my_idx = 0;
+  if (n_tail && found == n_tail) {  // (wave uniform; every lane walks a real pixel, lanes past the tail walk tail pixel 0 for nothing)
+    const int j = lane < n_tail ? lane : 0;  // ascending rank: tail pixel j was found (n_tail - 1 - j)-th
+    const int k = n_tail - 1 - j;
+    const unsigned idx = (unsigned)sh_idx[k];
+    my_idx = (int)idx;
+    const unsigned prow = idx / (unsigned)d.w, pcol = idx - prow * (unsigned)d.w;
+    float z = ((gcf)d.r_zsel)[idx], ri = ((gcf)d.r_i)[idx], rix = ((gcf)d.r_ix)[idx], riy = ((gcf)d.r_iy)[idx];
+    float x = ((gcf)d.tx)[pcol] * z, y = ((gcf)d.ty)[prow] * z;
+    float kt[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) kt[i] = it.kt[i];
+    DVO_OPAQUE(x); DVO_OPAQUE(y); DVO_OPAQUE(z); DVO_OPAQUE(ri); DVO_OPAQUE(rix); DVO_OPAQUE(riy);
+    round_toward_zero();
+    DVO_OPAQUE(x); DVO_OPAQUE(y); DVO_OPAQUE(z); DVO_OPAQUE(ri); DVO_OPAQUE(rix); DVO_OPAQUE(riy);
+    float r0, r1, e2, e3, e4, e5;
+    bool ok;
+    {
+      const Proj p = project_pixel_rtz<1>(kt, d, x, y, z);
+      const Gathered g = gather_pixel(d, p.base);
+      finish_pixel_rtz<true>(d, p, g, z, ri, rix, riy, r0, r1, e2, e3, e4, e5, ok);
+    }
+    DVO_OPAQUE(r0); DVO_OPAQUE(r1); DVO_OPAQUE(e2); DVO_OPAQUE(e3); DVO_OPAQUE(e4); DVO_OPAQUE(e5);
+    DVO_OPAQUE(x); DVO_OPAQUE(y); DVO_OPAQUE(z);
+    round_to_nearest();
+    DVO_OPAQUE(r0); DVO_OPAQUE(r1); DVO_OPAQUE(e2); DVO_OPAQUE(e3); DVO_OPAQUE(e4); DVO_OPAQUE(e5);
+    DVO_OPAQUE(x); DVO_OPAQUE(y); DVO_OPAQUE(z);
+    equal = ok && f2u(r0) == f2u(sh_r0[k]) && f2u(r1) == f2u(sh_r1[k]);
+    // the two weights (the distance as computeWeightsSse / computeWeight form it: product by product)
+    const float t0 = r0 * it.P[0] + r1 * it.P[1];
+    const float t1 = r0 * it.P[2] + r1 * it.P[3];
+    const float dd = t0 * r0 + t1 * r1;
+    w_table = 7.0f * rcp_host_table(5.0f + dd, d.rcp);
+    w_exact = (float)((2.0 + 5.0f) / (5.0f + dd));  // :643, the division in double
+    const double dw = mine ? (double)w_exact - (double)w_table : 0.0;
+    // Jacobian rows as the residual pass forms them (without the sqrt(w) of the staged form)
+    const float iz = __builtin_amdgcn_rcpf(z);
+    const float iz2 = iz * iz;
+    const float j02 = -x * iz2, j12 = -y * iz2;
+    const float j03 = j02 * y, j13 = __builtin_fmaf(j12, y, -1.0f);
+    const float j04 = __builtin_fmaf(-j02, x, 1.0f), j14 = -j03;
+    const float j05 = -y * iz, j15 = x * iz;
+    float Ja[6], Jb[6];
+    Ja[0] = e2 * iz;
+    Ja[1] = e3 * iz;
+    Ja[2] = __builtin_fmaf(e2, j02, e3 * j12);
+    Ja[3] = __builtin_fmaf(e2, j03, e3 * j13);
+    Ja[4] = __builtin_fmaf(e2, j04, e3 * j14);
+    Ja[5] = __builtin_fmaf(e2, j05, e3 * j15);
+    Jb[0] = e4 * iz;
+    Jb[1] = e5 * iz;
+    Jb[2] = __builtin_fmaf(e4, j02, __builtin_fmaf(e5, j12, -1.0f));
+    Jb[3] = __builtin_fmaf(e4, j03, __builtin_fmaf(e5, j13, -y));
+    Jb[4] = __builtin_fmaf(e4, j04, __builtin_fmaf(e5, j14, x));
+    Jb[5] = __builtin_fmaf(e4, j05, e5 * j15);
+    if (lane < 3) {
+      double *o = sh_delta[lane];
+      // pair sums: an even rank weights its own residual, an odd one its partner's (tail pixel 0: the tail starts on a multiple of 4)
+      const float a0 = (j & 1) ? sh_r0[n_tail - 1] : r0, a1 = (j & 1) ? sh_r1[n_tail - 1] : r1;
+      o[0] = dw * (double)(a0 * a0), o[1] = dw * (double)(a0 * a1), o[2] = dw * (double)(a1 * a1);
+      double *acc = o + 3;
+      int t = 0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int c = i; c < 6; ++c, ++t) {
+          acc[kAccAA + t] = dw * ((double)Ja[i] * (double)Ja[c]);
+          acc[kAccAB + t] = dw * ((double)Ja[i] * (double)Jb[c] + (double)Jb[i] * (double)Ja[c]);
+          acc[kAccBB + t] = dw * ((double)Jb[i] * (double)Jb[c]);
+        }
+        acc[kAccAR0 + i] = dw * ((double)Ja[i] * (double)r0);
+        acc[kAccAR1 + i] = dw * ((double)Ja[i] * (double)r1);
+        acc[kAccBR0 + i] = dw * ((double)Jb[i] * (double)r0);
+        acc[kAccBR1 + i] = dw * ((double)Jb[i] * (double)r1);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = lane; i < 3 + kNumAcc; i += kWave) {
+    const double sum = (sh_delta[0][i] + sh_delta[1][i]) + sh_delta[2][i];
+    if (i < 3) rec->S[i] = sum; else rec->acc[i - 3] = sum;
+  }
+  const unsigned long long all_equal = __ballot(!mine || equal);
+  if (lane < 3) {
+    rec->idx[lane] = mine ? my_idx : -1;
+    rec->w_table[lane] = mine ? w_table : 0.0f;
+    rec->w_exact[lane] = mine ? w_exact : 0.0f;
+  }
+  if (lane == 0) {
+    rec->n_tail = found == n_tail ? n_tail : -1;  // (-1: the counts and the residual buffer disagree -- cannot happen)
+    rec->valid = v;
+    rec->recomputed_equal = all_equal == ~0ull ? 1 : 0;
+  }
+}
+__global__ __launch_bounds__(kWave) void k_q7_tail(const Q7Args args) { q7_tail_wave(args); }
+__global__ __launch_bounds__(kWave) void k_q7_tail_small(const Q7ArgsSmall args) { q7_tail_wave(args); }
 
 __global__ void k_rcp_table_probe(const RcpTable rcp, const float *__restrict__ in, float *__restrict__ out, int n) {
   __shared__ unsigned nib[kRcpNibbleWordsMax];
@@ -1437,6 +1591,8 @@ __device__ __forceinline__ void finalize_block(const FinItem &it, const bool sta
   const int nb = it.records ? (int)it.n_blocks : 0;
   const int band_lo = (int)it.block_first, band_hi = band_lo + nb;  // the blocks this item reduces
   const int level_nb = (int)it.level_blocks;                        // the blocks the level's chunks partition
+  const DVO_GLOBAL Q7Rec *const q7 =
+      it.q7_off256 ? (const DVO_GLOBAL Q7Rec *)((const DVO_GLOBAL char *)it.ll_partials + 256u * (unsigned)it.q7_off256) : nullptr;
   if (t < kFinSegThreads) {
     // Wave 0: the ordered part.  Lane 4 c + q owns quarter q of chunk c (what of it lies in the band), folds its records in
     // ascending order, and the 64 lane records are folded by a binary tree -- chunk subtrees first, then the tree over chunks.
@@ -1497,7 +1653,8 @@ __device__ __forceinline__ void finalize_block(const FinItem &it, const bool sta
         const SegRec &a = sh_seg[0];
         sh_out.valid = a.c;
         sh_out.has_res = 1;
-        for (int i = 0; i < 3; ++i) sh_out.S[i] = a.s0[i], sh_out.S_odd[i] = a.s1[i];
+        // (host-rcpps mode, whole levels only: what the exact weights of the pass's last V mod 4 pixels add -- k_q7_tail)
+        for (int i = 0; i < 3; ++i) sh_out.S[i] = a.s0[i] + (q7 ? q7->S[i] : 0.0), sh_out.S_odd[i] = a.s1[i];
         sh_out.first_w = a.first_w, sh_out.last_r0 = a.l0, sh_out.last_r1 = a.l1;
       }
       // exclusive scan of the valid counts over the band's wave segments: the log-likelihood pass needs each pixel's
@@ -1601,7 +1758,8 @@ __device__ __forceinline__ void finalize_block(const FinItem &it, const bool sta
     for (int k = 0; k < kLevelChunksMax / 2; ++k) p[k] = kPaired ? sh_acc[k][col] : sh_acc[kPaired ? k : 2 * k][col] + sh_acc[kPaired ? k : 2 * k + 1][col];
     return ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
   };
-  if (t >= kFinAccFirst && t < kFinAccFirst + kNumAcc) sh_out.acc[t - kFinAccFirst] = tree(t - kFinAccFirst);
+  if (t >= kFinAccFirst && t < kFinAccFirst + kNumAcc)
+    sh_out.acc[t - kFinAccFirst] = tree(t - kFinAccFirst) + (q7 ? q7->acc[t - kFinAccFirst] : 0.0);
   if (t == kFinAccFirst + kNumAcc) {
     double qm = 0.0;
     for (int c = 0; c < kFinChunks; ++c) qm = sh_acc[c][89] > qm ? sh_acc[c][89] : qm;
@@ -1727,6 +1885,19 @@ long long read_block_trace(unsigned long long *out, long long capacity) {
 
 hipError_t read_finalize_stamps(unsigned long long out[8]) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fin_stamps), sizeof(unsigned long long) * 8);
+}
+
+hipError_t launch_q7_tail(const Q7Args &args, hipStream_t stream) {
+  if (args.n_items <= 0) return hipSuccess;
+  LaunchGuard guard;
+  hipLaunchKernelGGL(k_q7_tail, dim3((unsigned)args.n_items), dim3(kWave), 0, stream, args);
+  return hipGetLastError();
+}
+hipError_t launch_q7_tail_small(const Q7ArgsSmall &args, hipStream_t stream) {
+  if (args.n_items <= 0) return hipSuccess;
+  LaunchGuard guard;
+  hipLaunchKernelGGL(k_q7_tail_small, dim3((unsigned)args.n_items), dim3(kWave), 0, stream, args);
+  return hipGetLastError();
 }
 
 hipError_t launch_finalize_small(const FinArgsSmall &args, hipStream_t stream) {

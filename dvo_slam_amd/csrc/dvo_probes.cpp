@@ -118,6 +118,14 @@ int single_tick(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyrami
   }
   hipError_t e = launch_tick(ta, (int)w.res_blocks + (int)w.ll_blocks, ctx->stream);
   if (e != hipSuccess) return fail_hip("launch_tick", e);
+  if (ctx->rcp.table && residual_pass && !unit_weights) {  // host-rcpps mode: the Q7 tail, as submit_tick runs it
+    Q7ArgsSmall qs;
+    qs.n_items = 1, qs.q7_off256 = ctx->q7_off256, qs.rcp = ctx->rcp;
+    for (int i = 0; i < kMaxSmallItems; ++i) qs.items[i] = w;
+    e = launch_q7_tail_small(qs, ctx->stream);
+    if (e != hipSuccess) return fail_hip("launch_q7_tail", e);
+    f.q7_off256 = (uint16_t)ctx->q7_off256;
+  }
   e = launch_finalize(fa, ctx->stream);
   if (e != hipSuccess) return fail_hip("launch_finalize", e);
   return DVO_AMD_OK;
@@ -212,6 +220,54 @@ int dvo_amd_debug_iteration(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dv
     if (rc) return rc;
   }
   out->loglik = loglik_from_sum(o.valid, P, out->loglik_sum, overflowed);
+  return DVO_AMD_OK;
+}
+
+int dvo_amd_debug_weights(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, int level, const float *T,
+                          const float *precision_in, float *weights, dvo_amd_q7_probe *tail) {
+  if (!ctx || !reference || !current || !T || !precision_in || !weights || !tail || level < 0) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  if (!ctx->rcp.table) {
+    g_last_error = "dvo_amd_debug_weights: only the host-rcpps kernels can store their weights (dvo_amd_set_reciprocal_mode)";
+    return DVO_AMD_ERR_INVALID_ARGUMENT;
+  }
+  int rc = check_level_pair(ctx, reference, current, level);
+  if (rc) return rc;
+  rc = queue_must_be_idle(ctx, "dvo_amd_debug_weights");
+  if (rc) return rc;
+  const LevelData &R = reference->lv[level];
+  HIP_TRY(hipSetDevice(ctx->device));
+  const Selection *sel = nullptr;
+  rc = pyramid_selection(reference, ctx->cfg.intensity_derivative_threshold, ctx->cfg.depth_derivative_threshold, &sel);
+  if (rc) return rc;
+  rc = ensure_slots(ctx, 1, R.n_pad);
+  if (rc) return rc;
+  if (ctx->dbg_w_capacity < (size_t)R.n_pad) {
+    if (ctx->dbg_w_dev) (void)hipFree(ctx->dbg_w_dev);
+    ctx->dbg_w_dev = nullptr, ctx->dbg_w_capacity = 0;
+    HIP_TRY(hipMalloc((void **)&ctx->dbg_w_dev, sizeof(float) * (size_t)R.n_pad));
+    ctx->dbg_w_capacity = (size_t)R.n_pad;
+  }
+  // slot 0's descriptor points the residual pass at the buffer for this one tick
+  char *field = reinterpret_cast<char *>(ctx->slot_desc) + offsetof(SlotDesc, dbg_w);
+  float *on = ctx->dbg_w_dev, *off = nullptr;
+  HIP_TRY(hipMemcpy(field, &on, sizeof(on), hipMemcpyHostToDevice));
+  rc = single_tick(ctx, reference, current, level, sel, T, precision_in, false, true, false, 0);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  const hipError_t e_off = hipMemcpy(field, &off, sizeof(off), hipMemcpyHostToDevice);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail_hip("dvo_amd_debug_weights", e);
+  if (e_off != hipSuccess) return fail_hip("dvo_amd_debug_weights", e_off);
+  rc = take_record_synced(ctx, 0, ctx->tick_seq);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(weights, ctx->dbg_w_dev, sizeof(float) * (size_t)R.n, hipMemcpyDeviceToHost));
+  Q7Rec q;
+  HIP_TRY(hipMemcpy(&q, ctx->slots[0].q7, sizeof(q), hipMemcpyDeviceToHost));
+  std::memset(tail, 0, sizeof(*tail));
+  tail->n_tail = q.n_tail, tail->valid_constraints = ctx->out_host[0].valid, tail->recomputed_equal = q.recomputed_equal;
+  for (int i = 0; i < 3; ++i)
+    tail->pixel[i] = q.idx[i], tail->weight_table[i] = q.w_table[i], tail->weight_exact[i] = q.w_exact[i], tail->scale_sums_delta[i] = q.S[i];
+  for (int i = 0; i < kNumAcc; ++i) tail->moments_delta[i] = q.acc[i];
+  tail->valid_counted = q.valid;
   return DVO_AMD_OK;
 }
 

@@ -323,6 +323,21 @@ int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, i
   if (exchange && ctx->x_ranks > 0) fa.exchange = ctx->x_args_dev, fa.xseq = ctx->x_seq = next_seq(ctx->x_seq);  // the tail of k_finalize exchanges
   hipError_t e = launch_tick(ta, std::max(max_blocks, 1), ctx->stream);
   if (e != hipSuccess) return fail_hip("launch_tick", e);
+  // Host-rcpps mode, Q7 (k_q7_tail): which pixels are a pass's last V mod 4 is a property of the whole level.  With every band on
+  // this GPU the level's block records all stand in slot 0: one whole-level item, and the host adds what it leaves to the combined
+  // record -- the addition k_finalize makes at the root of the same tree for an unsharded pair, so banded == unsharded holds in
+  // this mode too.  A pair sharded over several GPUs has only its own band's records: its tail weights stay the table's (stated in
+  // include/dvo_amd.h).
+  const bool q7 = ctx->rcp.table && j.have_b && j.b.k != 0 && !exchange && band_first == 0 && n_local == n_bands;
+  if (q7) {
+    Q7ArgsSmall qs;
+    qs.n_items = 1, qs.q7_off256 = ctx->q7_off256, qs.rcp = ctx->rcp;
+    TickItem whole = ta.items[0];
+    whole.res_first = 0, whole.res_blocks = (uint16_t)nb_level;
+    for (int i = 0; i < kMaxSmallItems; ++i) qs.items[i] = whole;
+    e = launch_q7_tail_small(qs, ctx->stream);
+    if (e != hipSuccess) return fail_hip("launch_q7_tail", e);
+  }
   e = launch_finalize(fa, ctx->stream);
   if (e != hipSuccess) return fail_hip("launch_finalize", e);
 
@@ -340,6 +355,12 @@ int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, i
   }
   FinOut comb;
   combine_bands(recs, n_bands, comb);
+  if (q7) {
+    Q7Rec q;
+    HIP_TRY(hipMemcpy(&q, ctx->slots[0].q7, sizeof(q), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 3; ++i) comb.S[i] = comb.S[i] + q.S[i];
+    for (int i = 0; i < kNumAcc; ++i) comb.acc[i] = comb.acc[i] + q.acc[i];
+  }
   if (j.sub_res)
     for (int b = 0; b < n_bands; ++b) j.b.band_valid[b] = recs[b]->valid;
   if (j.sub_ll) {

@@ -329,7 +329,10 @@ int ensure_slots_impl(dvo_amd_context *ctx, int n_jobs, int n_pad) {
   const size_t b_ll = align_up(sizeof(double) * max_blocks, 256), b_lq = align_up(sizeof(float) * max_blocks, 256);
   const size_t b_sp = align_up(sizeof(int) * kWavesPerBlock * max_blocks, 256);
   const size_t b_out = align_up(sizeof(FinOut), 256);
-  const size_t total = 2 * b_res + b_rec + b_ll + b_lq + 2 * b_sp + b_out;
+  const size_t b_q7 = align_up(sizeof(Q7Rec), 256);  // behind ll_qmax: k_finalize finds it from ll_partials (FinItem::q7_off256)
+  const size_t total = 2 * b_res + b_rec + b_ll + b_lq + b_q7 + 2 * b_sp + b_out;
+  if ((b_ll + b_lq) / 256 > 0xFFFFu) return fail_hip("level too large for the slot layout", hipErrorInvalidValue);
+  ctx->q7_off256 = (int)((b_ll + b_lq) / 256);
   ctx->slots.resize(n_slots);
   for (int i = 0; i < n_slots; ++i) {
     JobSlot &s = ctx->slots[i];
@@ -345,6 +348,7 @@ int ensure_slots_impl(dvo_amd_context *ctx, int n_jobs, int n_pad) {
     s.ll_partials = (double *)p, p += b_ll;
     s.ll_qmax = (float *)p, p += b_lq;
     s.ll_qmax_off = (unsigned)(b_ll / sizeof(double));
+    s.q7 = (Q7Rec *)p, p += b_q7;
     s.seg_prefix[0] = (int *)p, p += b_sp;
     s.seg_prefix[1] = (int *)p, p += b_sp;
     s.out_dev = (FinOut *)p, p += b_out;
@@ -355,6 +359,7 @@ int ensure_slots_impl(dvo_amd_context *ctx, int n_jobs, int n_pad) {
     sd.res[0] = s.res[0], sd.res[1] = s.res[1];
     sd.records = s.records, sd.ll_partials = s.ll_partials, sd.ll_qmax = s.ll_qmax;
     sd.seg_prefix[0] = s.seg_prefix[0], sd.seg_prefix[1] = s.seg_prefix[1];
+    sd.dbg_w = nullptr;
   }
   HIP_TRY(hipMemcpy(ctx->slot_desc, slot_host.data(), sizeof(SlotDesc) * n_slots, hipMemcpyHostToDevice));
   ctx->tick_seq = 0;
@@ -574,6 +579,8 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
       f.records = j.slot->records;
       f.n_blocks = w.res_blocks, f.level_blocks = w.res_blocks;
       f.seg_prefix_out = j.slot->seg_prefix[j.b.buf];
+      // host-rcpps mode: the pass's last V mod 4 weights are exact divisions (Q7): k_q7_tail leaves the difference, k_finalize adds it
+      if (ctx->rcp.table && j.b.k != 0) f.q7_off256 = (uint16_t)ctx->q7_off256;
       j.sub_res = true;
       j.sub_px = (double)j.sel->count[j.level];
       j.result->n_residual_passes++;
@@ -671,6 +678,15 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
       (void)tick_args_layout(ts, max_blocks);
       const hipError_t es = launch_tick_small(ts, max_blocks, st, t0, t1);
       if (es == hipSuccess) {
+        if (ctx->rcp.table) {
+          Q7ArgsSmall qs;
+          qs.n_items = 0, qs.q7_off256 = ctx->q7_off256, qs.rcp = ctx->rcp;
+          for (int i = 0; i < n_here; ++i)
+            if (fin_items[first + (size_t)order[i]].q7_off256) qs.items[qs.n_items++] = ta.items[i];
+          for (int i = qs.n_items; i < kMaxSmallItems; ++i) qs.items[i] = ta.items[0];
+          const hipError_t eq = launch_q7_tail_small(qs, st);
+          if (eq != hipSuccess) return fail_hip("launch_q7_tail", eq);
+        }
         FinArgsSmall fs;
         fs.n_items = n_here, fs.pad = ctx->fin_stamps ? 0x57A3 : 0;
         for (int i = 0; i < kMaxSmallItems; ++i) fs.items[i] = fin_items[first + (size_t)order[i < n_here ? i : 0]];
@@ -685,6 +701,15 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
     hipError_t e = launch_tick(ta, max_blocks, st, t0, t1);
     if (e != hipSuccess) return fail_hip("launch_tick", e);
     static_assert(kMaxFinItems >= kMaxItemsPerLaunch, "one reduce launch per tick launch");
+    if (ctx->rcp.table) {
+      Q7Args qa;
+      qa.n_items = 0, qa.q7_off256 = ctx->q7_off256, qa.rcp = ctx->rcp;
+      for (int i = 0; i < n_here; ++i)
+        if (fin_items[first + (size_t)order[i]].q7_off256) qa.items[qa.n_items++] = ta.items[i];
+      for (int i = qa.n_items; i < kMaxItemsPerLaunch; ++i) qa.items[i] = ta.items[0];
+      e = launch_q7_tail(qa, st);
+      if (e != hipSuccess) return fail_hip("launch_q7_tail", e);
+    }
     FinArgs fa;
     fa.n_items = n_here;
     fa.pad = ctx->fin_stamps ? 0x57A3 : 0;
@@ -1196,6 +1221,7 @@ void dvo_amd_context_destroy(dvo_amd_context *ctx) {
   if (ctx->ovf_host) (void)hipHostFree(ctx->ovf_host);
   if (ctx->rcp_table_dev) (void)hipFree(ctx->rcp_table_dev);
   if (ctx->rcp_nibbles_dev) (void)hipFree(ctx->rcp_nibbles_dev);
+  if (ctx->dbg_w_dev) (void)hipFree(ctx->dbg_w_dev);
   for (auto &ev : ctx->events) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);

@@ -111,6 +111,8 @@ struct SlotDesc {  // one per job slot of a context: scratch of the pair being a
   double *ll_partials;  // log-likelihood pass: one double per block
   float *ll_qmax;       // ... and the largest Mahalanobis distance the block took (see loglik_pass)
   int *seg_prefix[2];   // per wave segment: valid pixels before it within its band, for the pass that filled res[i]
+  float *dbg_w;         // test instrumentation (dvo_amd_debug_weights): when set, the residual pass of the host-rcpps kernels also
+                        // stores every pixel's t-distribution weight here; null in every product path
 };
 
 // One job's device work of a tick, passed by value in the kernel arguments (no H2D copy per iteration):
@@ -166,6 +168,21 @@ struct RcpTable {
   // correction does not fit four bits (then the table form above runs).
   const unsigned *nibbles;
 };
+// Q7 (dense_tracking_impl.cpp:702-706) in the host-rcpps mode: computeWeightsSse forms the first 4 floor(V / 4) weights of a pass
+// with rcpps and the last V mod 4 by an exact division in double.  Which pixels those are is only known once the pass has counted
+// its valid pixels, so the residual pass weights every pixel with the table and k_q7_tail -- one wave per residual pass, between
+// k_tick and k_finalize on the same stream -- finds the <= 3 tail pixels, recomputes them and leaves what their exact weights add
+// to the pair sums and the 87 moments; k_finalize adds it at the root of its tree.
+struct Q7Rec {
+  double S[3];          // added to FinOut::S
+  double acc[87];       // added to FinOut::acc (kNumAcc)
+  int n_tail, valid;    // V mod 4 (0 for a pass with unit weights), V
+  int idx[3];           // the tail pixels (index in the level's scan order), ascending
+  float w_table[3];     // the weight the residual pass gave them: 7 rcpps(5 + d)
+  float w_exact[3];     // computeWeight's: (float)((2.0 + 5.0f) / (5.0f + d))
+  int recomputed_equal; // the recomputed residuals of the tail pixels are the spilled ones, bit for bit (always; checked by the tests)
+};
+static_assert(sizeof(Q7Rec) == 768, "Q7Rec: three 256-byte lines of the slot's block");
 constexpr int kRcpNibbleWordsMax = 512;  // 2^12 cells: what fits beside four blocks' staging areas in a CU's LDS
 struct TickArgs {
   int n_items;
@@ -238,7 +255,8 @@ struct FinItem {
   uint16_t level_blocks;               // residual blocks of the whole level in this tick's residual pass (the chunk structure)
   uint16_t ll_level_blocks;            // ... in the pass whose likelihood is summed
   uint16_t ll_merge_log2;              // log2 of the residual blocks per merged likelihood block
-  uint16_t pad;
+  uint16_t q7_off256;                  // host-rcpps mode: the pass's Q7Rec lives 256 * q7_off256 bytes behind ll_partials and its
+                                       // S / acc are added to the record's (0: nothing to add)
   const double *ll_partials;
   int *seg_prefix_out;    // per wave segment of the band: valid pixels before it (exclusive scan from the band start)
   FinWire *out;           // host (pinned, device-visible): where the record is published, as tagged pieces
@@ -258,6 +276,16 @@ struct FinArgs {
   FinItem items[kMaxFinItems];
 };
 static_assert(sizeof(FinArgs) <= 4096, "kernel argument block too large");
+
+// k_q7_tail's arguments: the residual-pass items of a tick launch (a TickItem each: level descriptors, slot, geometry, K T, P)
+template <int N>
+struct Q7ArgsT {
+  int n_items;
+  int q7_off256;  // where a slot's Q7Rec lives: 256 * q7_off256 bytes behind its ll_partials (the same for every slot of a context)
+  RcpTable rcp;
+  TickItem items[N];
+};
+typedef Q7ArgsT<kMaxItemsPerLaunch> Q7Args;
 
 // A tick of at most eight pairs (a single match(), the two-pair front-end step, small batches) goes out with argument blocks a tenth the size:
 // the runtime copies the kernel arguments into device-visible memory at every launch, and both launches sit on the critical
@@ -293,6 +321,10 @@ int tick_args_layout(TickArgsSmall &args, int max_blocks);
 hipError_t launch_tick_small(const TickArgsSmall &args, int max_blocks, hipStream_t stream, hipEvent_t t_start = nullptr,
                              hipEvent_t t_stop = nullptr);
 hipError_t launch_finalize_small(const FinArgsSmall &args, hipStream_t stream);
+// (host-rcpps mode) the Q7 tail of every residual pass of a tick launch: between launch_tick and launch_finalize, same stream
+typedef Q7ArgsT<kMaxSmallItems> Q7ArgsSmall;
+hipError_t launch_q7_tail(const Q7Args &args, hipStream_t stream);
+hipError_t launch_q7_tail_small(const Q7ArgsSmall &args, hipStream_t stream);
 hipError_t launch_finalize(const FinArgs &args, hipStream_t stream);
 // exact emulation of the reference's overflowing 50-term likelihood product over (a band of) one residual buffer (rare; see
 // k_ll_overflow): wave segments [seg_first, seg_first + n_segs) of seg_px pixels each, seg_prefix = the pass's prefix table

@@ -155,9 +155,12 @@ int dvo_amd_context_device(const dvo_amd_context *ctx, int *device);
  *     1 ulp: the same on every machine.
  *   DVO_AMD_RCP_HOST_SSE: both are THIS HOST's _mm_rcp_ps, bit for bit, from a table probed on the host when the mode is
  *     switched on (2^11 or 2^12 entries on the Xeons / EPYCs seen so far): residuals and validity decisions are then
- *     bit-identical to the reference's SSE path as this host runs it, and so is every t-distribution weight except the last
- *     V mod 4 of an iteration (the reference divides exactly there, :702-706; here every weight uses the table: <= 3 pixels
- *     of ~200 000, a stated deviation -- whole-match parity in this mode is therefore not bit-for-bit).  Returns
+ *     bit-identical to the reference's SSE path as this host runs it, and so is every t-distribution weight: the body of a
+ *     pass as 7 rcpps(5 + d) with d formed product by product (:669-700), the last V mod 4 by computeWeight's exact division
+ *     (:702-706, Q7 -- a small kernel between the two kernels of a tick finds those pixels once the pass has counted V and
+ *     leaves what their exact weights add to the pair sums and the moments).  The one exception: a pair tile-sharded over
+ *     SEVERAL GPUs keeps the table's weight for those <= 3 pixels (no rank sees the whole level's counts before the
+ *     exchange).  Sums are still taken in this library's order, so whole-match parity stays at tolerance level.  Returns
  *     DVO_AMD_ERR_INVALID_ARGUMENT with a reason in dvo_amd_last_error() if the host's instruction does not have the
  *     structure the table assumes, or under DVO_AMD_ACCUM=valu (the mode is built for the default accumulator only); refused
  *     while pairs are queued.

@@ -64,6 +64,26 @@ int dvo_amd_debug_iteration(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dv
                             const float *T, const float *precision_in, const float *precision_eval,
                             dvo_amd_iteration_probe *out);
 
+/* Host-rcpps mode only (dvo_amd_set_reciprocal_mode): the t-distribution weights of ONE residual pass at the float transform T
+ * under the column-major 2x2 precision_in, as the product kernels form them -- the residual pass stores every pixel's weight
+ * (weights[n pixels of the level], NaN where the pixel is no constraint) -- together with what k_q7_tail did about the pass's
+ * last V mod 4 pixels (Q7, dense_tracking_impl.cpp:702-706: computeWeightsSse divides exactly there): which pixels, the weight
+ * the pass gave them, computeWeight's, and what the difference adds to the pair sums and the 87 moments (k_finalize has added it
+ * to the record by the time this returns).  The parity tests compare all of it with computeWeightsSse as this host runs it. */
+typedef struct {
+  int n_tail;             /* V mod 4 */
+  int valid_constraints;  /* V of the record */
+  int valid_counted;      /* V as k_q7_tail counted it from the block records */
+  int recomputed_equal;   /* the tail pixels' recomputed residuals are the spilled ones, bit for bit */
+  int pixel[3];           /* index in the level's scan order, ascending; -1 beyond n_tail */
+  float weight_table[3];  /* 7 rcpps(5 + d) */
+  float weight_exact[3];  /* (float)((2.0 + 5.0f) / (5.0f + d)) */
+  double scale_sums_delta[3];
+  double moments_delta[87];
+} dvo_amd_q7_probe;
+int dvo_amd_debug_weights(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, int level, const float *T,
+                          const float *precision_in, float *weights, dvo_amd_q7_probe *tail);
+
 /* Micro-benchmark of the dominant kernel alone (used by bench.py for the roofline figure and by the tuning scripts):
  * `reps` timed repetitions of the fused residual pass over `n_items` copies of one (reference level, current level) pair
  * at the float transform T (column-major 4x4), `rounds` 256-pixel rounds (four 64-pixel steps each) per wave segment (1, 2, 4, 8 or 16; 0 = the driver's choice).

@@ -7,6 +7,7 @@ probed on the host it runs on.  Checked here against the oracle's RCP_SSE mode, 
 
   * the table reciprocal == _mm_rcp_ps on this host, bit for bit, for every class of input;
   * residuals and validity decisions bit-exact at every level;
+  * every t-distribution weight of a pass bit-exact, the exact-division tail (Q7) included;
   * match(): same-path poses <= 1e-5, forks under the self-distance rule; the three flavours of "the reference SSE path"
     (portable oracle with rcpps, natively built FMA-contracting oracle with rcpps, exact-reciprocal oracle) on one line.
 """
@@ -123,6 +124,101 @@ def test_residuals_bit_exact_against_the_oracles_rcpps_mode(capi, orc, synth, pa
         both = m & ~np.isnan(e)
         differs_from_exact += int((P._bits(g[both]) != P._bits(e[both])).sum())
     assert differs_from_exact > 0  # (the two reciprocals are different functions: the mode is really on)
+
+
+_Q7_SEEN = set()
+
+
+@pytest.mark.parametrize("level", [3, 2, 1, 0])
+def test_every_weight_is_computeWeightsSse_as_this_host_runs_it(capi, orc, synth, pair, level, capsys):
+    """computeWeightsSse (dense_tracking_impl.cpp:657-707) forms the first 4 floor(V / 4) weights of a pass as 7 rcpps(5 + d), d
+    product by product, and the last V mod 4 by computeWeight's exact division in double (Q7).  In the host-rcpps mode the HIP path
+    does the same: the residual pass weights every pixel with the table, k_q7_tail finds the pass's last V mod 4 valid pixels once
+    V is known, recomputes them and leaves what their exact weights add to the pair sums and the 87 moments (k_finalize adds it to
+    the record).  Checked on the product kernels' own weights (dvo_amd_debug_weights: the residual pass stores them): every weight
+    of the body and every tail weight against the oracle's tdist_weights on the same residuals, bit for bit; the tail's pixels;
+    the additions against a float64 restatement from the oracle's point records."""
+    import ctypes as C
+
+    trk = _tracker(capi, FirstLevel=3, LastLevel=0)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+    poses = [np.eye(4), pair["Tgt"], np.linalg.inv(pair["Tgt"]), synth.se3_exp([0.05, -0.08, 0.1, 0.03, -0.02, 0.04]),
+             synth.se3_exp([0.004, 0.002, -0.003, 0.001, -0.002, 0.0015]), synth.se3_exp([-0.01, 0.006, 0.002, -0.003, 0.001, 0.002])]
+    for T in poses:
+        g, V = trk.residuals(pair["gr"], pair["gc"], level, T)
+        m = ~np.isnan(g[..., 0])
+        assert int(m.sum()) == V
+        res = np.ascontiguousarray(g[m])  # row-major = scan order = the reference's compacted list (bit-exact: the test above)
+        # a realistic precision: the one the pass's own unit-weight scale gives
+        w_unit, cov, P_in = np.zeros(V, np.float32), np.zeros(4, np.float32), np.zeros(4, np.float32)
+        orc.lib().orc_weights_scale_loglik(fp(res), V, fp(P_in), 1, orc.RCP_SSE, fp(w_unit), fp(cov), fp(P_in))
+        w_ref, cov2, P2 = np.zeros(V, np.float32), np.zeros(4, np.float32), np.zeros(4, np.float32)
+        orc.lib().orc_weights_scale_loglik(fp(res), V, fp(P_in), 0, orc.RCP_SSE, fp(w_ref), fp(cov2), fp(P2))
+        w_img, q = trk.weights_probe(pair["gr"], pair["gc"], level, T, P_in.reshape(2, 2).T)
+        assert np.array_equal(np.isnan(w_img), ~m)
+        w_gpu = w_img[m]
+        t = V % 4
+        _Q7_SEEN.add(t)
+        assert q["n"] == V and q["n_counted"] == V and q["n_tail"] == t and q["recomputed_equal"]
+        # the body: rcpps weights, bit for bit
+        assert np.array_equal(P._bits(w_gpu[: V - t]), P._bits(w_ref[: V - t]))
+        # the tail: the pass gave those pixels the table's weight; k_q7_tail found them and formed computeWeight's
+        flat = np.flatnonzero(m.ravel())
+        w_all_table = np.float32(7.0) * orc.host_rcp(np.float32(5.0) + _mahalanobis(res, P_in))
+        for j in range(t):
+            k = V - t + j
+            assert q["pixel"][j] == flat[k]
+            assert P._bits(q["w_table"][j : j + 1])[0] == P._bits(w_gpu[k : k + 1])[0] == P._bits(w_all_table[k : k + 1])[0]
+            assert P._bits(q["w_exact"][j : j + 1])[0] == P._bits(w_ref[k : k + 1])[0]
+        assert all(px == -1 for px in q["pixel"][t:])
+        # what the exact weights add: pair sums (Q5: an odd rank weights its partner's residual) and moments, in float64
+        pe, r_o, _ = orc.compute_residuals(pair["orr"], pair["occ"], level, T, orc.RCP_SSE)
+        assert np.array_equal(P._bits(r_o), P._bits(res))
+        dS, dM = np.zeros(3), np.zeros(87)
+        for j in range(t):
+            k = V - t + j
+            dw = float(w_ref[k]) - float(w_gpu[k])
+            a = res[k] if j % 2 == 0 else res[V - t]
+            dS += dw * np.array([float(a[0] * a[0]), float(a[0] * a[1]), float(a[1] * a[1])])
+            dM += dw * _moments_of_point(orc, pe[k], res[k])
+        assert np.allclose(q["scale_sums_delta"], dS, rtol=1e-12, atol=0.0)
+        assert np.allclose(q["moments_delta"], dM, rtol=1e-4, atol=1e-6 * np.abs(dM).max() if t else 0.0)
+        if t == 0:
+            assert not q["scale_sums_delta"].any() and not q["moments_delta"].any()
+    if level == 0:
+        with capsys.disabled():
+            print(f"\n[Q7] V mod 4 of the passes checked: {sorted(_Q7_SEEN)}")
+        assert _Q7_SEEN >= {1, 2, 3}, "add poses: a tail length is not covered"
+
+
+def _mahalanobis(res, P_colmajor):
+    """r^T P r as computeWeightsSse evaluates it (float32, product by product)"""
+    r0, r1 = res[:, 0], res[:, 1]
+    p = P_colmajor.astype(np.float32)
+    t0 = (r0 * p[0]).astype(np.float32) + (r1 * p[1]).astype(np.float32)
+    t1 = (r0 * p[2]).astype(np.float32) + (r1 * p[3]).astype(np.float32)
+    return ((t0 * r0).astype(np.float32) + (t1 * r1).astype(np.float32)).astype(np.float32)
+
+
+def _moments_of_point(orc, pe, r):
+    """the 87 P-free moments of one point with unit weight (layout: csrc/dvo_types.h kAcc*), from the oracle's point record"""
+    import ctypes as C
+
+    Jw, Jz = np.zeros(12, np.float32), np.zeros(6, np.float32)
+    p3 = np.ascontiguousarray(pe[:3], np.float32)
+    f = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+    orc.lib().orc_jacobian(f(p3), f(Jw), f(Jz))
+    Jw, Jz = Jw.astype(np.float64), Jz.astype(np.float64)
+    gi0, gi1, gz0, gz1 = (float(x) for x in pe[6:10])  # e[2..5]: the gradient terms (dense_tracking.cpp:333-339)
+    Ja = gi0 * Jw[:6] + gi1 * Jw[6:]
+    Jb = gz0 * Jw[:6] + gz1 * Jw[6:] - Jz
+    out, t = np.zeros(87), 0
+    for i in range(6):
+        for c in range(i, 6):
+            out[t], out[21 + t], out[42 + t] = Ja[i] * Ja[c], Ja[i] * Jb[c] + Jb[i] * Ja[c], Jb[i] * Jb[c]
+            t += 1
+        out[63 + i], out[69 + i], out[75 + i], out[81 + i] = Ja[i] * r[0], Ja[i] * r[1], Jb[i] * r[0], Jb[i] * r[1]
+    return out
 
 
 def test_match_against_the_three_flavours_of_the_reference_sse_path(capi, orc, synth, pair, capsys):
