@@ -605,7 +605,9 @@ def main():
                             "form": trackers[0].reciprocal_form()[0],
                             "table_mantissa_bits": trackers[0].reciprocal_mode()[1],
                             "what": "dvo_amd_set_reciprocal_mode(DVO_AMD_RCP_HOST_SSE): 1 / z of the projection and the reciprocal of "
-                                    "the t-distribution weights are this host's _mm_rcp_ps from a device-resident table"}
+                                    "the t-distribution weights are this host's _mm_rcp_ps (the device's own reciprocal plus 4-bit "
+                                    "corrections in LDS, or a device-resident table: `form`); every weight of a pass is computeWeightsSse's, "
+                                    "its exact-division tail included (k_q7_tail: one more small dispatch per tick)"}
                 finally:
                     for t_ in trackers:
                         t_.set_reciprocal_mode("exact")
