@@ -473,7 +473,7 @@ def main():
             "single_pair_latency": {
                 "ms": single_ms, "configuration": "segment_geometry = DVO_AMD_GEOMETRY_LATENCY (levels 3..0 in 1/2/2/4 steps per wave)",
                 "ms_with_the_batch_configuration": single_ms_batch_geometry,
-                "batch_configuration": "segment_geometry = DVO_AMD_GEOMETRY_THROUGHPUT (4/4/8/8), what the timed region runs",
+                "batch_configuration": "segment_geometry = DVO_AMD_GEOMETRY_THROUGHPUT (4/4/16/16), what the timed region runs",
                 "what": "one dvo_amd_match() at a time through the Python binding, median of three rounds of ten pairs; the geometry "
                         "is a field of the tracker's configuration and part of what a result is a function of"},
             "prep_ms_per_frame": prep_ms,
@@ -515,14 +515,16 @@ def main():
         try:
             if args.no_extras:  # (a counter / trace pass must not find batch-form k_tick launches behind the timing pass)
                 raise RuntimeError("skipped under --no-extras")
-            # (8 steps per wave: what suits a launch that has the GPU to itself; the driver's own choice for this many pixels is
-            # 16, tuned for launches that share the GPU with three others)
-            ms_i, ab_i, nl_i = trk.bench_residual_pass(ref, curs[0], 0, cur_pose(0), 36, 2, reps=20)
+            # (the level's own geometry -- 16 steps of 64 pixels per wave for a 640x480 level 0 since the end of round 5 -- and, beside
+            # it, 8 steps: what suits a launch that has the GPU to itself)
+            ms_i, ab_i, nl_i = trk.bench_residual_pass(ref, curs[0], 0, cur_pose(0), 36, 0, reps=20)
+            ms_8, ab_8, nl_8 = trk.bench_residual_pass(ref, curs[0], 0, cur_pose(0), 36, 2, reps=20)
             line["roofline_isolated_kernel"] = {
-                "what": "the residual pass alone: level 0, 36 pairs in one launch (one launch's worth of resident pairs), 8 steps "
-                        "of 64 pixels per wave",
+                "what": "the residual pass alone: level 0, 36 pairs in one launch (one launch's worth of resident pairs), the wave "
+                        "segments match() gives this level (segment_geometry = DVO_AMD_GEOMETRY_THROUGHPUT)",
                 "achieved": ab_i / ms_i / 1e6, "unit": "GB/s", "frac": ab_i / ms_i / 1e6 / HBM_PEAK_GBS,
-                "launch_us": ms_i * 1e3 / nl_i, "alg_bytes_per_launch": ab_i / nl_i}
+                "launch_us": ms_i * 1e3 / nl_i, "alg_bytes_per_launch": ab_i / nl_i,
+                "with_8_steps_per_wave": {"frac": ab_8 / ms_8 / 1e6 / HBM_PEAK_GBS, "launch_us": ms_8 * 1e3 / nl_8}}
             # the timed region against what the kernel body reaches on its best case in this very run (the level-0 pass alone on
             # the GPU sits on the kernel's practical issue ceiling): how much of that the whole job keeps
             line["roofline"]["concurrent"]["fraction_of_the_isolated_kernel"] = (

@@ -169,21 +169,28 @@ struct dvo_amd_context {
   // Wave-step counts OF A LEVEL (its pixels / 64) from which its wave segments take 2 / 4 / 8 / 16 steps: the geometry of a
   // residual pass -- and with it the order every fp32 sum of the pass is taken in -- is a function of the level alone, never
   // of what else is resident in the tick (level_steps below).  DVO_AMD_LEVEL_STEPS_AT="a,b,c,d", read when the context is
-  // created (a tuning knob: it changes results in the last bits like any other summation order would).
-  // Default (DVO_AMD_GEOMETRY_THROUGHPUT) since round 5: 640x480 levels 3..0 (75 / 300 / 1 200 / 4 800 wave steps) take 4 / 4 / 8 / 8
-  // steps per wave, a 1280x960 level 0 (19 200) takes 16.  Until round 4 the table was 2 / 4 / 8 / 8 (thresholds 70, 250, 1000,
-  // 9600): one table had to serve the batch and the single match(); now the latency-first table is a configuration of its own
-  // (segment_geometry) and this one is the fastest for batches: interleaved runs of the streaming bench in round 5
-  // (profiles/r05_geometry_ab.txt; pairs/s): 2/4/8/8 52.1 / 51.7 k, 4/4/8/8 52.8 / 53.4 k, 4/8/8/8 53.0 / 53.0 k.  Round 4's runs
+  // created (a tuning knob: it changes results in the last bits like any other summation order would; a fifth value e: 32
+  // steps from e).
+  // Default (DVO_AMD_GEOMETRY_THROUGHPUT) since the end of round 5: 640x480 levels 3..0 (75 / 300 / 1 200 / 4 800 wave steps) take
+  // 4 / 4 / 16 / 16 steps per wave -- every level of 1 000 wave steps or more takes 16.  Until round 4 the table was 2 / 4 / 8 / 8
+  // (thresholds 70, 250, 1000, 9600): one table had to serve the batch and the single match(); now the latency-first table is a
+  // configuration of its own (segment_geometry) and this one is the fastest for batches.  Interleaved runs of the streaming bench
+  // in round 5 (pairs/s): profiles/r05_geometry_and_persistent_ab.txt 2/4/8/8 52.1 / 51.7 k, 4/4/8/8 52.8 / 53.4 k, 4/8/8/8 53.0 /
+  // 53.0 k; profiles/r05_geometry_ab_16_steps.txt 4/4/8/8 52.3 / 52.2 / 52.4 / 52.5 k, 4/4/8/16 52.5 / 52.8 k, 4/4/16/16 53.9 /
+  // 54.1 / 54.1 / 54.6 k, 4/8/16/16 54.3 / 54.3 k, 8/8/16/16 54.3 / 54.5 k, 4/16/16/16 54.6 / 54.4 / 54.2 / 54.0 k, 4/16/16/32
+  // 52.6 / 52.9 k, 4/16/32/32 52.0 / 51.6 k: sixteen steps on the two fine levels is worth +3.5 %, thirty-two lose it again (a
+  // nine-tile block's prologue and epilogue are ~400 vector instructions per wave: an eighth of a 16-step segment's work, a
+  // quarter of an 8-step one's; longer blocks make a launch's tail longer -- the per-launch figure of a launch ALONE on the GPU
+  // drops from 0.385 to 0.352 of the HBM roofline while the timed region rises from 0.485 to 0.502).  Round 4's runs
   // (gpurun_out/r4b, r4c; pairs/s | single-pair latency): 4/8/8/8 46.6 k | 0.83 ms; 8/8/8/8 45.9 k | 0.84; 2/4/8/8 46.2 k | 0.76;
   // 2/4/4/8 45.2 k | 0.72; 1/2/4/8 44.5 k | 0.70; 8/8/8/16 46.1 k | 0.84; 1/1/1/4 (a single pair until round 3) 35.8 k | 0.71.
-  long long level_steps_at[4] = {18, 70, 1000, 9600};
+  long long level_steps_at[5] = {18, 70, 1000, 1000, 1LL << 40};
   // dvo_amd_config::segment_geometry = DVO_AMD_GEOMETRY_LATENCY: 640x480 levels 3..0 take 1 / 2 / 2 / 4 steps per wave (1280x960
   // levels 4..0: 1 / 2 / 2 / 4 / 4): short segments spread a level over more waves -- the shortest single match() of the tables
   // measured (profiles/r05_latency_geometries.txt: 0.60 ms against 0.63 for 1/2/4/8 and 0.66 for the batch's 4/4/8/8) --, a
   // configuration of the tracker honoured by match(), the batched forms, the queue, the validator's stages and the band pipeline
   // alike (round 5)
-  long long level_steps_at_latency[4] = {250, 4000, 38400, 999999};
+  long long level_steps_at_latency[5] = {250, 4000, 38400, 999999, 1LL << 40};
   int fault_slot_alloc = -1;           // DVO_AMD_FAULT_SLOT_ALLOC: fail the allocation of this slot once (tests of the error path)
   bool fin_stamps = false;             // DVO_AMD_FIN_STAMPS=1: k_finalize records phase stamps (diagnostic)
   bool sort_items = true;              // longest-lived blocks first inside a launch (DVO_AMD_SORT_ITEMS=0: slot order)

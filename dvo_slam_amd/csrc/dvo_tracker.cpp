@@ -390,7 +390,7 @@ int ensure_slots(dvo_amd_context *ctx, int n_jobs, int n_pad) {
 int level_steps(const dvo_amd_context *ctx, int n_px) {
   const long long waves = n_px / kStepPx;
   const long long *t = ctx->cfg.segment_geometry == DVO_AMD_GEOMETRY_LATENCY ? ctx->level_steps_at_latency : ctx->level_steps_at;
-  int steps = waves >= t[3] ? 16 : waves >= t[2] ? 8 : waves >= t[1] ? 4 : waves >= t[0] ? 2 : 1;
+  int steps = waves >= t[4] ? 32 : waves >= t[3] ? 16 : waves >= t[2] ? 8 : waves >= t[1] ? 4 : waves >= t[0] ? 2 : 1;
   while (steps < kMaxSteps && (n_px + kStepPx * kWavesPerBlock * steps - 1) / (kStepPx * kWavesPerBlock * steps) > 2048) steps *= 2;
   return steps;
 }
@@ -1168,8 +1168,8 @@ int dvo_amd_context_create(int device, const dvo_amd_config *cfg, dvo_amd_contex
   if (const char *sl = getenv("DVO_AMD_SPEC_LEVELS")) ctx->spec_levels = sl[0] == '1' ? 1 : 0;
   if (const char *fs2 = getenv("DVO_AMD_FAULT_SLOT_ALLOC")) ctx->fault_slot_alloc = atoi(fs2);
   if (const char *sa = getenv("DVO_AMD_LEVEL_STEPS_AT"))
-    (void)sscanf(sa, "%lld,%lld,%lld,%lld", &ctx->level_steps_at[0], &ctx->level_steps_at[1], &ctx->level_steps_at[2],
-                 &ctx->level_steps_at[3]);
+    (void)sscanf(sa, "%lld,%lld,%lld,%lld,%lld", &ctx->level_steps_at[0], &ctx->level_steps_at[1], &ctx->level_steps_at[2],
+                 &ctx->level_steps_at[3], &ctx->level_steps_at[4]);
   if (const char *lm = getenv("DVO_AMD_LL_MERGE")) {
     const int v = atoi(lm);
     if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ctx->ll_merge = v;
