@@ -136,7 +136,7 @@ def plumbing_only(args):
                           "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "none (plumbing rehearsal: no alignment ran)",
-                          "config": {"workload": "plumbing only", "pairs_total": pairs}}), flush=True)
+                          "config": {"workload": "plumbing only", "pairs_total": pairs}}), file=OUT, flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -186,9 +186,23 @@ def workload_cur_frame(synth, W, H, rank, i):
     return synth.render(W, H, workload_cur_pose(synth, i), frame_id=2 * rank + 1 + 2 * i)
 
 
+OUT = sys.stdout
+
+
+def private_stdout():
+    """The one JSON line gets a private copy of the process's stdout; file descriptor 1 itself is pointed at stderr for everything
+    else, so that whatever a library prints there (RCCL's version block on some boxes, seen in front of the line of the
+    --tile-shard leg in round 5) cannot end up in front of it."""
+    global OUT
+    sys.stdout.flush()
+    OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+
 def main():
     args = parse()
     maybe_spawn_ranks(args)
+    private_stdout()
     if args.plumbing_only:
         return plumbing_only(args)
     from dvo_slam_amd import sharding
@@ -627,7 +641,7 @@ def main():
                     line[name] = fn()
                 except Exception as exc:  # pragma: no cover - side measurements never fail the bench line
                     line[name] = {"error": repr(exc)}
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=OUT, flush=True)
     if side_hung:  # a thread of this process is stuck inside a collective: no orderly teardown is possible
         sys.stdout.flush()
         os._exit(0)
@@ -728,7 +742,8 @@ def tile_shard_measure(args, capi, synth, dist, rank, world, device, K, levels, 
                   for i in range(4)]
     ref = capi.RgbdImagePyramid(ref_frame[0], ref_frame[1], K, levels, device=device)
     curs = [capi.RgbdImagePyramid(f[0], f[1], K, levels, device=device) for f in cur_frames]
-    cfg = capi.Config(FirstLevel=first_level, LastLevel=0)
+    # one pair at a time is a latency workload: the latency-first wave segments (a field of the configuration, include/dvo_amd.h)
+    cfg = capi.Config(FirstLevel=first_level, LastLevel=0, SegmentGeometry=capi.GEOMETRY_LATENCY)
     want = os.environ.get("DVO_AMD_EXCHANGE", "auto")
     pairs_per_step = 8
 
@@ -759,7 +774,8 @@ def tile_shard_measure(args, capi, synth, dist, rank, world, device, K, levels, 
 
     out = {"ranks": world, "pairs_per_step": pairs_per_step, "steps": steps,
            "what": f"ONE synthetic {args.width}x{args.height} pair at a time, every pyramid level tile-sharded over {world} GPU(s) "
-                   "(bands of scan-order blocks), per-tick exchange of the 784-byte band records (BASELINE config 4); strong scaling, "
+                   "(bands of scan-order blocks; segment_geometry = DVO_AMD_GEOMETRY_LATENCY), per-tick exchange of the 784-byte band records "
+                   "(BASELINE config 4); strong scaling, "
                    "expected to be slower than one GPU at this size (a tick is ~24 us, so is a small-message exchange)"}
     poses = {}
     if want in ("auto", "rccl"):
@@ -811,7 +827,7 @@ def tile_shard_bench(args, capi, synth, sharding, dist, rank, world, device, ref
             "config": {"workload": m["what"], "exchange": m["quoted"],
                        "sharding": "tile-shard with per-iteration exchange of the band records (BASELINE config 4)"},
             "us_per_tick": m["us_per_tick"], "tile_shard": m,
-        }), flush=True)
+        }), file=OUT, flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
