@@ -89,7 +89,10 @@ def parse():
     if args.threads is None:
         args.threads = 8 if big else 6
     if args.in_flight is None:
-        args.in_flight = 72 if big else 124  # two groups of 62 pairs per tracker: every tick one full launch (kMaxItemsPerLaunch)
+        # one group of 62 pairs per tracker: every tick one full launch (kMaxItemsPerLaunch).  Until the end of round 5: 124 = two
+        # groups per tracker; with 16-step wave segments one is +1.0 ... +1.5 % in interleaved runs on three boxes and needs half
+        # the resident scratch (profiles/r05_residency_ab.txt)
+        args.in_flight = 72 if big else 62
     return args
 
 
@@ -884,7 +887,7 @@ TRAFFIC_FILE = "r05_traffic.json"
 def profiled_workload(args):
     """The counter passes ran the default workload (the driver's command): their figure says nothing about another one."""
     return (args.width, args.height, args.batch, args.distinct, args.distinct_refs, args.threads, args.in_flight) == \
-           (640, 480, 1152, 96, 12, 6, 124) and not args.no_stats and not args.drain_between_steps
+           (640, 480, 1152, 96, 12, 6, 62) and not args.no_stats and not args.drain_between_steps
 
 
 def roofline_traffic(args, world, line):

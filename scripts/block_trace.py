@@ -1,6 +1,6 @@
 """Where does a block's life go, and how full are the block slots?  Needs a library built with the block trace:
     scripts/variant.sh trace -DDVO_TRACE_BLOCKS      ->  DVO_AMD_LIB=dvo_slam_amd/libdvo_amd_var_trace.so python scripts/block_trace.py
-Runs (a) the streaming batch of bench.py (6 threads x TRACE_IN_FLIGHT (default 124) resident pairs, every step queued behind the previous one) and (b) the
+Runs (a) the streaming batch of bench.py (6 threads x TRACE_IN_FLIGHT (default 62) resident pairs, every step queued behind the previous one) and (b) the
 residual pass alone (level 0, 36 pairs per launch), reads the per-block trace {start, after the first step, end} and prints: the
 average number of resident k_tick blocks against the 1024 block slots of the GPU, and per kind of block the median duration, time to
 the end of the first step (prologue + one step) and time per further step."""
@@ -159,7 +159,7 @@ def lone_launches(tr, event_us):
 def main():
     W, H = 640, 480
     K = synth.intrinsics_for(W, H)
-    n_refs, n_curs, B, T, RES = 12, 96, 1152, int(os.environ.get("TRACE_THREADS", 6)), int(os.environ.get("TRACE_IN_FLIGHT", 124))
+    n_refs, n_curs, B, T, RES = 12, 96, 1152, int(os.environ.get("TRACE_THREADS", 6)), int(os.environ.get("TRACE_IN_FLIGHT", 62))
 
     def cur_pose(i):
         return synth.se3_exp(synth.XI_GT_PAIR * (0.5 + 0.9 * ((i * 7) % 13) / 13.0) * (1 if i % 2 == 0 else -1)
