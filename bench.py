@@ -85,14 +85,14 @@ def parse():
         args.no_extras = args.no_cpu_baseline = True
     if args.no_extras:
         args.no_live_counters = True  # (the counter passes are a side measurement of the full line)
-    big = args.width >= 1280
     if args.threads is None:
-        args.threads = 8 if big else 6
+        args.threads = 6
     if args.in_flight is None:
-        # one group of 62 pairs per tracker: every tick one full launch (kMaxItemsPerLaunch).  Until the end of round 5: 124 = two
-        # groups per tracker; with 16-step wave segments one is +1.0 ... +1.5 % in interleaved runs on three boxes and needs half
-        # the resident scratch (profiles/r05_residency_ab.txt)
-        args.in_flight = 72 if big else 62
+        # one group of up to 62 pairs per tracker: every tick one launch as large as the argument block allows
+        # (kMaxItemsPerLaunch).  Until the end of round 5: 6 x 124 = two groups per tracker (8 x 72 for 1280x960); with 16-step
+        # wave segments one group is +1.0 ... +1.9 % in interleaved runs on three boxes (1280x960, 288 pairs per step: +5.5 %) and
+        # needs half the resident scratch (profiles/r05_residency_ab.txt)
+        args.in_flight = 62
     return args
 
 

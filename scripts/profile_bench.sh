@@ -18,7 +18,7 @@ for s in $steps; do
       rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA -d "$R/$out/pmc_issue" -o pmc --output-format csv -- python3 "$R/scripts/issue_counts.py" run "$R/$out/issue_run.json" > "$R/$out/issue.log" 2>&1 || exit 1
       rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA -d "$R/$out/pmc_issue_iso" -o pmc --output-format csv -- python3 "$R/scripts/kernel_one.py" 0 36 0 10 > "$R/$out/issue_iso.log" 2>&1 || exit 1 ;;
     t1plain) python3 "$R/bench.py" --threads 1 --batch 72 --in-flight 36 --steps 10 --warmup 2 --no-extras --no-cpu-baseline --no-live-counters > "$R/$out/bench_t1_plain.json" 2> "$R/$out/bench_t1_plain.err" || exit 1 ;;
-    big) python3 "$R/bench.py" --width 1280 --height 960 --batch 288 --distinct 48 --distinct-refs 6 --threads 8 --in-flight 72 --steps 8 --warmup 2 --no-extras --no-live-counters --cpu-seconds 8 > "$R/$out/bench_1280x960.json" 2> "$R/$out/bench_1280x960.err" || exit 1 ;;
+    big) python3 "$R/bench.py" --width 1280 --height 960 --batch 288 --distinct 48 --distinct-refs 6 --steps 8 --warmup 2 --no-extras --no-live-counters --cpu-seconds 8 > "$R/$out/bench_1280x960.json" 2> "$R/$out/bench_1280x960.err" || exit 1 ;;
     shard)
       DVO_AMD_EXCHANGE=peer python3 "$R/bench.py" --tile-shard --steps 8 --warmup 3 > "$R/$out/bench_tileshard_peer.json" 2> "$R/$out/bench_tileshard_peer.err" || exit 1
       DVO_AMD_EXCHANGE=rccl python3 "$R/bench.py" --tile-shard --steps 8 --warmup 3 > "$R/$out/bench_tileshard_rccl.json" 2> "$R/$out/bench_tileshard_rccl.err" || exit 1 ;;
