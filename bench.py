@@ -263,7 +263,13 @@ def main():
 
     T = max(1, min(args.threads, args.batch))
     cfg = capi.Config(FirstLevel=first_level, LastLevel=0)
-    trackers = [capi.DenseTracker(cfg, device=device) for _ in range(T)]
+    # (diagnostic, DVO_BENCH_FOREIGN_STREAMS=n: n streams of "the application" -- idle contexts -- created in front of every
+    #  tracker: how much of the throughput rests on the runtime's stream -> hardware queue assignment,
+    #  profiles/r05_stream_queue_assignment_ab.txt)
+    foreign, trackers = [], []
+    for _ in range(T):
+        foreign += [capi.DenseTracker(cfg, device=device) for _ in range(int(os.environ.get("DVO_BENCH_FOREIGN_STREAMS", "0")))]
+        trackers.append(capi.DenseTracker(cfg, device=device))
     trk = trackers[0]
     B = args.batch
     ref_pyrs = [ref]

@@ -35,7 +35,7 @@ EXPORTS = [
     "dvo_amd_exchange_create", "dvo_amd_exchange_attach", "dvo_amd_exchange_destroy",
     "dvo_amd_match_submit", "dvo_amd_match_wait", "dvo_amd_match_poll", "dvo_amd_debug_next_seq",
     "dvo_amd_set_reciprocal_mode", "dvo_amd_get_reciprocal_mode", "dvo_amd_debug_rcp", "dvo_amd_debug_block_trace",
-    "dvo_amd_debug_ll_overflow", "dvo_amd_debug_marker", "dvo_amd_debug_rcp_form", "dvo_amd_debug_weights",
+    "dvo_amd_debug_ll_overflow", "dvo_amd_debug_marker", "dvo_amd_debug_rcp_form", "dvo_amd_debug_weights", "dvo_amd_debug_hw_queue",
 ]
 
 
@@ -179,6 +179,7 @@ def lib():
     L.dvo_amd_residuals.argtypes = [vp, vp, vp, C.c_int, fp, fp, C.POINTER(C.c_int)]
     L.dvo_amd_error_image.argtypes = [vp, vp, vp, dp, C.c_int, fp]
     L.dvo_amd_debug_iteration.argtypes = [vp, vp, vp, C.c_int, fp, fp, fp, C.POINTER(CIterationProbe)]
+    L.dvo_amd_debug_hw_queue.argtypes = [vp, C.POINTER(C.c_int)]
     L.dvo_amd_debug_weights.argtypes = [vp, vp, vp, C.c_int, fp, fp, fp, C.POINTER(CQ7Probe)]
     L.dvo_amd_kernel_timing.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_longlong), C.c_int]
     L.dvo_amd_bench_residual_pass.argtypes = [vp, vp, vp, C.c_int, fp, C.c_int, C.c_int, C.c_int, dp, dp,
@@ -644,6 +645,12 @@ class DenseTracker:
                 "precision": np.array(pr.precision[:], np.float32).reshape(2, 2).T.copy(), "ll": float(pr.loglik),
                 "A": np.array(pr.information[:]).reshape(6, 6).T.copy(), "b": np.array(pr.rhs[:]),
                 "moments": np.array(pr.moments[:]), "scale_sums": np.array(pr.scale_sums[:]), "ll_sum": pr.loglik_sum}
+
+    def hw_queue(self) -> int:
+        """(diagnostic, dvo_amd_debug.h) pipe << 3 | queue of the hardware queue this tracker's main stream runs on, asked of the GPU"""
+        q = C.c_int(-2)
+        _check(lib().dvo_amd_debug_hw_queue(self._h, C.byref(q)), "dvo_amd_debug_hw_queue")
+        return q.value
 
     def weights_probe(self, reference: RgbdImagePyramid, current: RgbdImagePyramid, level: int, T, precision_in):
         """(test entry, dvo_amd_debug.h; host-rcpps mode only) the t-distribution weights of one residual pass at T under the 2x2

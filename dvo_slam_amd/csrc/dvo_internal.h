@@ -346,6 +346,7 @@ int level_steps(const dvo_amd_context *ctx, int n_px);
 int level_ll_merge(const dvo_amd_context *ctx, int res_steps);
 int timing_begin(dvo_amd_context *ctx, size_t *slot);
 int tick_stream(dvo_amd_context *ctx, size_t index, hipStream_t *out);
+int probe_hw_queue(dvo_amd_context *ctx, int *pipe_queue);  // the hardware queue the main stream runs on, asked of the GPU
 int timing_collect(dvo_amd_context *ctx);
 int take_wire(const FinWire *w, FinOut *dst_record, unsigned seq, int from_piece);
 int take_record(dvo_amd_context *ctx, size_t slot, unsigned seq, int from_piece);

@@ -1845,6 +1845,19 @@ hipError_t launch_marker(unsigned tag, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// Which hardware queue does the runtime run this stream on?  One thread reports HW_ID's PIPE_ID (bits 7:6) and QUEUE_ID (bits
+// 26:24) of the wave it runs in (context creation: host::pick_balanced_stream).
+__global__ void k_queue_probe(unsigned *out) {
+  unsigned hw;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  if (threadIdx.x == 0) __hip_atomic_store(out, 0x80000000u | (((hw >> 6) & 3u) << 3) | ((hw >> 24) & 7u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_queue_probe(unsigned *out_pinned, hipStream_t stream) {
+  LaunchGuard guard;
+  hipLaunchKernelGGL(k_queue_probe, dim3(1), dim3(64), 0, stream, out_pinned);
+  return hipGetLastError();
+}
+
 hipError_t launch_rcp_midpoint_probe(int k, unsigned *out_rn, unsigned *out_rtz, hipStream_t stream) {
   LaunchGuard guard;
   hipLaunchKernelGGL(k_rcp_midpoint_probe, dim3((unsigned)(((1 << k) + 255) / 256)), dim3(256), 0, stream, k, out_rn, out_rtz);

@@ -271,6 +271,14 @@ int dvo_amd_debug_weights(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_
   return DVO_AMD_OK;
 }
 
+int dvo_amd_debug_hw_queue(dvo_amd_context *ctx, int *pipe_queue) {
+  if (!ctx || !pipe_queue) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  int rc = queue_must_be_idle(ctx, "dvo_amd_debug_hw_queue");
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(ctx->device));
+  return probe_hw_queue(ctx, pipe_queue);
+}
+
 int dvo_amd_error_image(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, const double *T,
                         int level, float *image) {
   if (!ctx || !reference || !current || !T || !image || level < 0) return DVO_AMD_ERR_INVALID_ARGUMENT;

@@ -430,6 +430,29 @@ int tick_stream(dvo_amd_context *ctx, size_t index, hipStream_t *out) {
   return DVO_AMD_OK;
 }
 
+// ---- which hardware queue does a context's stream run on? --------------------------------------------------------------------
+// The runtime maps streams onto GPU_MAX_HW_QUEUES (4) hardware queues, and a hardware queue runs one kernel at a time: how the
+// trackers of a GPU are spread over them decides up to a third of a batch's throughput (six trackers: 55-56 k pairs/s as the
+// runtime places them when they are created back to back -- two per queue on three queues, neighbours together --, 51 k with the
+// same two per queue but every other tracker together, 47 k on two queues, 39 k on one:
+// profiles/r05_stream_queue_assignment_ab.txt).  The library takes the stream the runtime deals it: a context that picked among
+// candidate streams by probing them was built and measured at the end of round 5 and made the common case worse (the probe is a
+// stream's first use and changes what the runtime does next: 53.2 k), so what is left of it is the probe as a diagnostic
+// (dvo_amd_debug_hw_queue) and the advice in INTEGRATION.md: create the trackers of a GPU back to back.
+int probe_hw_queue(dvo_amd_context *ctx, int *pipe_queue) {
+  unsigned *word = nullptr, *word_dev = nullptr;
+  HIP_TRY(hipHostMalloc((void **)&word, 64, hipHostMallocMapped | hipHostMallocCoherent));
+  __atomic_store_n(word, 0u, __ATOMIC_RELEASE);
+  hipError_t e = hipHostGetDevicePointer((void **)&word_dev, word, 0);
+  if (e == hipSuccess) e = launch_queue_probe(word_dev, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  const unsigned v = __atomic_load_n(word, __ATOMIC_ACQUIRE);
+  (void)hipHostFree(word);
+  if (e != hipSuccess) return fail_hip("dvo_amd_debug_hw_queue", e);
+  *pipe_queue = (v & 0x80000000u) ? (int)(v & 0xFFu) : -1;
+  return DVO_AMD_OK;
+}
+
 int timing_collect(dvo_amd_context *ctx) {
   for (size_t i = 0; i < ctx->events_used; ++i) {
     float ms = 0.0f;

@@ -347,7 +347,9 @@ hipError_t launch_rcp_table_probe(const RcpTable &rcp, const float *in, float *o
 // out_rn[i] / out_rtz[i] = bits of v_rcp_f32(midpoint of cell i of [1, 2)) under round-to-nearest / round-toward-zero, i < 1 << k
 hipError_t launch_rcp_midpoint_probe(int k, unsigned *out_rn, unsigned *out_rtz, hipStream_t stream);
 
-hipError_t launch_marker(unsigned tag, hipStream_t stream);  // a no-op dispatch named k_marker (profile bracketing)
+hipError_t launch_marker(unsigned tag, hipStream_t stream);
+// the hardware queue a stream runs on: *out_pinned (pinned host word, zeroed by the caller) = 0x80000000 | pipe << 3 | queue
+hipError_t launch_queue_probe(unsigned *out_pinned, hipStream_t stream);  // a no-op dispatch named k_marker (profile bracketing)
 int acc_mode();  // 1: Gram matrix on the matrix pipe (default); 0: DVO_AMD_ACCUM=valu, the 87-register cross-check form
 
 // prep (pyramid construction) kernels

@@ -84,6 +84,13 @@ typedef struct {
 int dvo_amd_debug_weights(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, int level, const float *T,
                           const float *precision_in, float *weights, dvo_amd_q7_probe *tail);
 
+/* Diagnostic: the hardware queue the context's main stream runs on, asked of the GPU by a one-wave kernel on that stream (HW_ID:
+ * pipe << 3 | queue).  The runtime maps streams onto its four hardware queues and a hardware queue runs one kernel at a time, so
+ * how the trackers of a GPU are spread over them decides up to a third of a batch's throughput
+ * (profiles/r05_stream_queue_assignment_ab.txt); the library takes the stream the runtime deals it (create the
+ * trackers of a GPU back to back) and this entry lets an integrator look at the outcome.  Refused while pairs are queued. */
+int dvo_amd_debug_hw_queue(dvo_amd_context *ctx, int *pipe_queue);
+
 /* Micro-benchmark of the dominant kernel alone (used by bench.py for the roofline figure and by the tuning scripts):
  * `reps` timed repetitions of the fused residual pass over `n_items` copies of one (reference level, current level) pair
  * at the float transform T (column-major 4x4), `rounds` 256-pixel rounds (four 64-pixel steps each) per wave segment (1, 2, 4, 8 or 16; 0 = the driver's choice).

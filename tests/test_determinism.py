@@ -209,3 +209,21 @@ def test_the_latency_geometry_is_a_configuration_like_any_other(capi, synth, fra
     # an unknown geometry is refused like any insane configuration
     with pytest.raises(capi.DvoAmdError):
         capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0, SegmentGeometry=7))
+
+
+def test_trackers_created_back_to_back_are_spread_over_the_hardware_queues(capi, capsys):
+    """The runtime maps streams onto its four hardware queues and a hardware queue runs one kernel at a time: how the trackers of a
+    GPU are spread over them decides up to a third of a batch's throughput (profiles/r05_stream_queue_assignment_ab.txt: 55-56 k
+    pairs/s for six trackers two to a queue with neighbours together, 47 k on two queues, 39 k on one).  The library takes the stream
+    the runtime deals it (a context that chose among probed candidates made the common case worse); this is the diagnostic that shows
+    the outcome -- the hardware queue of a tracker's stream, asked of the GPU -- on six trackers created back to back, as
+    INTEGRATION.md advises: no queue may carry more than two of them."""
+    from collections import Counter
+
+    cfg = capi.Config(FirstLevel=3, LastLevel=0)
+    trackers = [capi.DenseTracker(cfg) for _ in range(6)]
+    queues = [t.hw_queue() for t in trackers]
+    with capsys.disabled():
+        print(f"\n[hardware queues] six trackers created back to back: pipe << 3 | queue = {queues}")
+    assert all(0 <= q < 64 for q in queues)
+    assert max(Counter(queues).values()) <= 2
