@@ -270,6 +270,10 @@ def main():
     for _ in range(T):
         foreign += [capi.DenseTracker(cfg, device=device) for _ in range(int(os.environ.get("DVO_BENCH_FOREIGN_STREAMS", "0")))]
         trackers.append(capi.DenseTracker(cfg, device=device))
+    if os.environ.get("DVO_BENCH_TRACKER_PERM"):  # (diagnostic) host thread t drives the tracker created perm[t]-th
+        perm = [int(x) for x in os.environ["DVO_BENCH_TRACKER_PERM"].split(",")]
+        if sorted(perm) == list(range(T)):
+            trackers = [trackers[i] for i in perm]
     trk = trackers[0]
     B = args.batch
     ref_pyrs = [ref]
