@@ -433,8 +433,8 @@ int tick_stream(dvo_amd_context *ctx, size_t index, hipStream_t *out) {
 // ---- which hardware queue does a context's stream run on? --------------------------------------------------------------------
 // The runtime maps streams onto GPU_MAX_HW_QUEUES (4) hardware queues, and a hardware queue runs one kernel at a time: how the
 // trackers of a GPU are spread over them decides up to a third of a batch's throughput (six trackers: 55-56 k pairs/s as the
-// runtime places them when they are created back to back -- two per queue on three queues --, 51-55 k for other two-per-queue
-// arrangements forced by an experiment build, 47 k on two queues, 39 k on one:
+// runtime places them when they are created back to back -- two per queue on three queues, neighbours together --, 51 k with the
+// same two per queue but every other tracker together, 47 k on two queues, 39 k on one:
 // profiles/r05_stream_queue_assignment_ab.txt).  The library takes the stream the runtime deals it: a context that picked among
 // candidate streams by probing them was built and measured at the end of round 5 and made the common case worse (the probe is a
 // stream's first use and changes what the runtime does next: 53.2 k), so what is left of it is the probe as a diagnostic
