@@ -181,7 +181,9 @@ struct dvo_amd_context {
   // 52.6 / 52.9 k, 4/16/32/32 52.0 / 51.6 k: sixteen steps on the two fine levels is worth +3.5 %, thirty-two lose it again (a
   // nine-tile block's prologue and epilogue are ~400 vector instructions per wave: an eighth of a 16-step segment's work, a
   // quarter of an 8-step one's; longer blocks make a launch's tail longer -- the per-launch figure of a launch ALONE on the GPU
-  // drops from 0.385 to 0.352 of the HBM roofline while the timed region rises from 0.485 to 0.502).  Round 4's runs
+  // drops from 0.385 to 0.352 of the HBM roofline while the timed region rises from 0.485 to 0.502) -- and where the table says
+  // 16, level_steps makes the segment a whole number of image rows when it can (ten steps for 640x480's two fine levels): see there.
+  // Round 4's runs
   // (gpurun_out/r4b, r4c; pairs/s | single-pair latency): 4/8/8/8 46.6 k | 0.83 ms; 8/8/8/8 45.9 k | 0.84; 2/4/8/8 46.2 k | 0.76;
   // 2/4/4/8 45.2 k | 0.72; 1/2/4/8 44.5 k | 0.70; 8/8/8/16 46.1 k | 0.84; 1/1/1/4 (a single pair until round 3) 35.8 k | 0.71.
   long long level_steps_at[5] = {18, 70, 1000, 1000, 1LL << 40};
@@ -191,6 +193,7 @@ struct dvo_amd_context {
   // configuration of the tracker honoured by match(), the batched forms, the queue, the validator's stages and the band pipeline
   // alike (round 5)
   long long level_steps_at_latency[5] = {250, 4000, 38400, 999999, 1LL << 40};
+  int fine_steps = 0;                  // DVO_AMD_FINE_STEPS: 0 = row-aligned segments on the levels the table gives 16 steps (level_steps), n = n steps
   int fault_slot_alloc = -1;           // DVO_AMD_FAULT_SLOT_ALLOC: fail the allocation of this slot once (tests of the error path)
   bool fin_stamps = false;             // DVO_AMD_FIN_STAMPS=1: k_finalize records phase stamps (diagnostic)
   bool sort_items = true;              // longest-lived blocks first inside a launch (DVO_AMD_SORT_ITEMS=0: slot order)
@@ -342,7 +345,7 @@ void process_loglik(Job &j, const FinOut *outs, bool ll_overflowed = false);
 void release_slots(dvo_amd_context *ctx);
 int ensure_slots_impl(dvo_amd_context *ctx, int n_jobs, int n_pad);
 int ensure_slots(dvo_amd_context *ctx, int n_jobs, int n_pad);
-int level_steps(const dvo_amd_context *ctx, int n_px);
+int level_steps(const dvo_amd_context *ctx, const LevelData &lv);
 int level_ll_merge(const dvo_amd_context *ctx, int res_steps);
 int timing_begin(dvo_amd_context *ctx, size_t *slot);
 int tick_stream(dvo_amd_context *ctx, size_t index, hipStream_t *out);

@@ -85,7 +85,7 @@ int single_tick(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyrami
   w.ref = sel->ref_desc + level;
   w.cur = current->cur_desc + level;
   w.slot = ctx->slot_desc;
-  const int steps = level_steps(ctx, R.n);
+  const int steps = level_steps(ctx, R);
   item_set_steps(w, steps, steps);
   const int nb = blocks_for(R.n, steps);
   if (unit_weights) w.flags |= kItemUnitWeights;
@@ -214,7 +214,7 @@ int dvo_amd_debug_iteration(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dv
   out->loglik_sum = ctx->out_host[0].ll_sum;
   bool overflowed = false;
   if (ctx->out_host[0].ll_qmax >= kLlOverflowScreen) {
-    const int st = level_steps(ctx, R.n);  // (the geometry single_tick used)
+    const int st = level_steps(ctx, R);  // (the geometry single_tick used)
     rc = ll_overflowed(ctx, ctx->slots[0].res[0], ctx->slots[0].seg_prefix[0], blocks_for(R.n, st), st, 50 * (o.valid / 50), P, nullptr, 0,
                        &overflowed);
     if (rc) return rc;
@@ -322,7 +322,7 @@ int dvo_amd_bench_residual_pass_pairs(dvo_amd_context *ctx, int n_items, dvo_amd
   if (rc) return rc;
   // `rounds` of the public interface = 256-pixel rounds per wave segment (four steps each); 0 = the driver's choice
   if (rounds != 0 && rounds != 1 && rounds != 2 && rounds != 4 && rounds != 8 && rounds != 16) return DVO_AMD_ERR_INVALID_ARGUMENT;
-  int steps = rounds <= 0 ? level_steps(ctx, R.n) : rounds * 4;
+  int steps = rounds <= 0 ? level_steps(ctx, R) : rounds * 4;
   while (steps < kMaxSteps && blocks_for(R.n, steps) > 2048) steps *= 2;
   TickItem proto;
   std::memset(&proto, 0, sizeof(proto));

@@ -387,10 +387,34 @@ int ensure_slots(dvo_amd_context *ctx, int n_jobs, int n_pad) {
 // The trade-off the table settles: a step is a dependent chain (reference scalars -> projection -> gathers -> arithmetic ->
 // staging, ~1.5 us when nothing else hides it), so short segments make a single pair's tick shorter; a block's prologue and
 // epilogue (descriptors, seven wave reductions, the Gram tile, the block record) are amortised over long ones.
-int level_steps(const dvo_amd_context *ctx, int n_px) {
+int level_steps(const dvo_amd_context *ctx, const LevelData &lv) {
+  const int n_px = lv.n;
   const long long waves = n_px / kStepPx;
   const long long *t = ctx->cfg.segment_geometry == DVO_AMD_GEOMETRY_LATENCY ? ctx->level_steps_at_latency : ctx->level_steps_at;
   int steps = waves >= t[4] ? 32 : waves >= t[3] ? 16 : waves >= t[2] ? 8 : waves >= t[1] ? 4 : waves >= t[0] ? 2 : 1;
+  // Row-aligned segments (end of round 5): on the levels the table gives its longest segments, a wave segment is a whole number
+  // of image rows when the row is a whole number of steps -- ten steps for a 640-pixel row, ten (two rows) for 320, twenty for
+  // 1280.  The four waves of a block then walk the SAME columns one row (or two) apart: the lower bilinear row of one wave is
+  // the upper row of the next at the same step, and the gathers of a block share their lines while they are in L1 -- L2-miss
+  // traffic 0.83 x the algorithmic bytes against 1.11 x with 16-step and 0.98 x with 8-step segments, a launch alone 0.40 of the
+  // HBM roofline against 0.36 / 0.385, the batch +1 % on 16 steps (profiles/r05_row_aligned_segments_ab.txt).  Only where the last
+  // block of the level still lies inside the planes' padding; DVO_AMD_FINE_STEPS=n forces a length, =16 turns the rule off.
+  if (steps == 16 && ctx->cfg.segment_geometry != DVO_AMD_GEOMETRY_LATENCY) {
+    int want = ctx->fine_steps;
+    if (want == 0 && lv.w % kStepPx == 0) {
+      want = lv.w / kStepPx;
+      if (want % 2) want *= 2;
+      while (want < 8) want *= 2;
+    }
+    TickItem probe_item;
+    std::memset(&probe_item, 0, sizeof(probe_item));
+    if (want >= 2 && want <= 32 && want % 2 == 0) {
+      item_set_steps(probe_item, want, 1);
+      const long long block_px = (long long)kStepPx * kWavesPerBlock * want;
+      if (item_res_steps(probe_item) == want && (n_px + block_px - 1) / block_px * block_px <= lv.n_pad && (n_px + block_px - 1) / block_px <= 2048)
+        return want;
+    }
+  }
   while (steps < kMaxSteps && (n_px + kStepPx * kWavesPerBlock * steps - 1) / (kStepPx * kWavesPerBlock * steps) > 2048) steps *= 2;
   return steps;
 }
@@ -575,7 +599,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
     f.seg_prefix_out = j.slot->seg_prefix[0], f.out = j.slot->out, f.out_dev = nullptr, f.seq = seq;
     f.ll_qmax_off = j.slot->ll_qmax_off;
     if (j.have_b) {
-      j.b.steps = level_steps(ctx, j.ref->lv[j.level].n);  // the level's own geometry, whatever else this tick carries
+      j.b.steps = level_steps(ctx, j.ref->lv[j.level]);  // the level's own geometry, whatever else this tick carries
       j.b.n_blocks = blocks_for(j.ref->lv[j.level].n, j.b.steps);
     }
     if (j.have_a) {
@@ -612,7 +636,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
       // iteration a ends its level whatever its likelihood says: start the next level in this tick, assuming acceptance
       const int nl = j.level - 1;
       speculate_next_level(j, j.spec_b);
-      j.spec_b.steps = level_steps(ctx, j.ref->lv[nl].n);
+      j.spec_b.steps = level_steps(ctx, j.ref->lv[nl]);
       j.spec_b.n_blocks = blocks_for(j.ref->lv[nl].n, j.spec_b.steps);
       w.ref = j.sel->ref_desc + nl;  // the likelihood pass only uses the slot's buffers
       w.cur = j.cur->cur_desc + nl;
@@ -1193,6 +1217,7 @@ int dvo_amd_context_create(int device, const dvo_amd_config *cfg, dvo_amd_contex
   if (const char *sa = getenv("DVO_AMD_LEVEL_STEPS_AT"))
     (void)sscanf(sa, "%lld,%lld,%lld,%lld,%lld", &ctx->level_steps_at[0], &ctx->level_steps_at[1], &ctx->level_steps_at[2],
                  &ctx->level_steps_at[3], &ctx->level_steps_at[4]);
+  if (const char *fsx = getenv("DVO_AMD_FINE_STEPS")) ctx->fine_steps = atoi(fsx);  // (tuning) see level_steps
   if (const char *lm = getenv("DVO_AMD_LL_MERGE")) {
     const int v = atoi(lm);
     if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ctx->ll_merge = v;

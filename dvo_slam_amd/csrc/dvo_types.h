@@ -134,14 +134,22 @@ struct TickItem {
   float P[4];                      // column-major 2x2 precision: of the iteration whose likelihood is evaluated, which is
                                    // also the one the residual pass of the next iteration takes its weights from
 };
-__host__ __device__ inline int item_res_steps(const TickItem &it) { return 1 << (it.steps_log2 & 15); }
-__host__ __device__ inline int item_ll_steps(const TickItem &it) { return 1 << (it.steps_log2 >> 4); }
+// step codes: 0..6 = 1 << code; 7.. = segment lengths that are no power of two (an image row of 640 pixels is ten steps)
+__host__ __device__ inline int steps_of_code(int c) {
+  return c < 7 ? 1 << c : c == 7 ? 10 : c == 8 ? 20 : c == 9 ? 12 : c == 10 ? 14 : c == 11 ? 6 : c == 12 ? 18 : c == 13 ? 24 : c == 14 ? 40 : 30;
+}
+__host__ __device__ inline int item_res_steps(const TickItem &it) { return steps_of_code(it.steps_log2 & 15); }
+__host__ __device__ inline int item_ll_steps(const TickItem &it) { return steps_of_code(it.steps_log2 >> 4); }
 __host__ __device__ inline int item_ll_merge_log2(const TickItem &it) { return (it.flags >> 4) & 7; }
 inline void item_set_steps(TickItem &it, int res_steps, int ll_steps) {
-  int a = 0, b = 0;
-  while ((1 << a) < res_steps) ++a;
-  while ((1 << b) < ll_steps) ++b;
-  it.steps_log2 = (uint8_t)(a | (b << 4));
+  auto code = [](int steps) {
+    for (int c = 0; c < 16; ++c)
+      if (steps_of_code(c) == steps) return c;
+    int c = 0;
+    while ((1 << c) < steps) ++c;
+    return c;
+  };
+  it.steps_log2 = (uint8_t)(code(res_steps) | (code(ll_steps) << 4));
 }
 inline void item_set_ll_merge(TickItem &it, int merge) {
   int m = 0;

@@ -70,8 +70,10 @@ typedef struct {
    * residual pass are cut.  Like every other field of this struct it is part of what a result is a function of: two trackers
    * with different values agree to summation noise, not bit for bit; under ONE value match(), the batched forms, the queue, the
    * validator's workers and every band count agree bit for bit (tests/test_determinism.py runs under both).
-   *   DVO_AMD_GEOMETRY_THROUGHPUT (default): 640x480 levels 3..0 run 4 / 4 / 16 / 16 steps of 64 pixels per wave (every level
-   *     of 64 000 pixels or more: 16) -- long segments amortise a block's prologue and epilogue: the most pairs per second;
+   *   DVO_AMD_GEOMETRY_THROUGHPUT (default): 640x480 levels 3..0 run 4 / 4 / 10 / 10 steps of 64 pixels per wave -- on a level
+   *     of 64 000 pixels or more a wave segment is a whole number of image rows (ten steps for a 640-pixel row, twenty for 1280;
+   *     16 steps where the row is no whole number of steps): long segments amortise a block's prologue and epilogue, and the
+   *     four waves of a block, one row apart, share the lines they gather -- the most pairs per second;
    *   DVO_AMD_GEOMETRY_LATENCY: 1 / 2 / 2 / 4 -- short segments spread a coarse level over more waves: the shortest single
    *     match() (the reference's default deployment is one match() per frame, dvo_ros/src/camera_dense_tracking.cpp:269), a few
    *     per cent fewer pairs per second in large batches. */
