@@ -19,6 +19,8 @@ L = capi.lib()
 L.dvo_amd_debug_block_trace.restype = C.c_longlong
 L.dvo_amd_debug_block_trace.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_longlong]
 CAP = 1 << 22
+# step codes of a work item (csrc/dvo_types.h: steps_of_code): 0..6 = 1 << code, then the lengths that are no power of two
+STEPS_OF_CODE = np.array([1, 2, 4, 8, 16, 32, 64, 10, 20, 12, 14, 6, 18, 24, 40, 30], np.int64)
 
 
 def read_trace(trk):
@@ -33,7 +35,7 @@ def analyse(tr, label, wall_s=None):
     t0, tf, te = tr[:, 0].astype(np.int64), tr[:, 1].astype(np.int64), tr[:, 2].astype(np.int64)
     info = (tr[:, 3] & np.uint64(0xFFFFFFFF)).astype(np.int64)
     hw = (tr[:, 3] >> np.uint64(32)).astype(np.int64)
-    steps = 1 << (info & 15)
+    steps = STEPS_OF_CODE[info & 15]
     is_ll = (info >> 4) & 1
     width = ((info >> 8) & 255) * 8
     xcc = (hw >> 28) & 15
@@ -120,7 +122,7 @@ def lone_launches(tr, event_us):
     tr = tr[np.argsort(tr[:, 0])]
     t0, tf, te = tr[:, 0].astype(np.int64), tr[:, 1].astype(np.int64), tr[:, 2].astype(np.int64)
     info = (tr[:, 3] & np.uint64(0xFFFFFFFF)).astype(np.int64)
-    steps, is_ll = 1 << (info & 15), (info >> 4) & 1
+    steps, is_ll = STEPS_OF_CODE[info & 15], (info >> 4) & 1
     end_so_far = np.maximum.accumulate(te)
     cuts = np.flatnonzero(t0[1:] > end_so_far[:-1]) + 1  # a block that starts behind every earlier block's end opens a launch
     bounds = np.concatenate([[0], cuts, [len(tr)]])
