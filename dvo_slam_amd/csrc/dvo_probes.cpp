@@ -271,6 +271,14 @@ int dvo_amd_debug_weights(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_
   return DVO_AMD_OK;
 }
 
+int dvo_amd_debug_level_geometry(const dvo_amd_context *ctx, const dvo_amd_pyramid *reference, int level, int *steps, int *blocks) {
+  if (!ctx || !reference || !steps || !blocks || level < 0) return DVO_AMD_ERR_INVALID_ARGUMENT;
+  if (level >= reference->n_levels) return DVO_AMD_ERR_TOO_FEW_LEVELS;
+  *steps = level_steps(ctx, reference->lv[level]);
+  *blocks = blocks_for(reference->lv[level].n, *steps);
+  return DVO_AMD_OK;
+}
+
 int dvo_amd_debug_hw_queue(dvo_amd_context *ctx, int *pipe_queue) {
   if (!ctx || !pipe_queue) return DVO_AMD_ERR_INVALID_ARGUMENT;
   int rc = queue_must_be_idle(ctx, "dvo_amd_debug_hw_queue");

@@ -211,6 +211,35 @@ def test_the_latency_geometry_is_a_configuration_like_any_other(capi, synth, fra
         capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0, SegmentGeometry=7))
 
 
+def test_the_segment_tables_are_the_documented_ones(capi, synth, frames):
+    """dvo_amd.h documents what dvo_amd_config::segment_geometry selects; dvo_amd_debug_level_geometry reads it back.  Throughput:
+    640x480 levels 3..0 in 4 / 4 / 10 / 10 steps of 64 pixels per wave -- on a level of 64 000 pixels or more a wave segment is a
+    whole number of image rows (ten steps = one 640-pixel row = two 320-pixel rows, twenty for 1280), 16 steps where a row is no
+    whole number of steps; latency: 1 / 2 / 2 / 4 (1280x960 levels 4..0: 1 / 2 / 2 / 4 / 4).  A function of the level's size and
+    the configuration alone: two trackers of one configuration agree, whatever they ran before."""
+    thr = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0))
+    lat = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0, SegmentGeometry=capi.GEOMETRY_LATENCY))
+    vga = frames[0]
+    assert [thr.level_geometry(vga, l)[0] for l in (3, 2, 1, 0)] == [4, 4, 10, 10]
+    assert [lat.level_geometry(vga, l)[0] for l in (3, 2, 1, 0)] == [1, 2, 2, 4]
+    for trk in (thr, lat):
+        for l in range(4):
+            steps, blocks = trk.level_geometry(vga, l)
+            n = (640 >> l) * (480 >> l)
+            assert (blocks - 1) * steps * 256 < n <= blocks * steps * 256  # the blocks cover the level, none is empty
+    big = capi.RgbdImagePyramid(*synth.render(1280, 960, frame_id=40), synth.intrinsics_for(1280, 960), 5)
+    assert [thr.level_geometry(big, l)[0] for l in (4, 3, 2, 1, 0)] == [4, 4, 10, 10, 20]
+    assert [lat.level_geometry(big, l)[0] for l in (4, 3, 2, 1, 0)] == [1, 2, 2, 4, 4]
+    # a row that is no whole number of steps keeps the table's 16 (600 = 9.375 steps; level 1: 300 pixels)
+    odd = capi.RgbdImagePyramid(*synth.render(600, 450, frame_id=41), synth.intrinsics_for(600, 450), 3)
+    assert [thr.level_geometry(odd, l)[0] for l in (1, 0)] == [16, 16]
+    thr.match(frames[1], frames[2])
+    other = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0))
+    assert [thr.level_geometry(vga, l) for l in range(4)] == [other.level_geometry(vga, l) for l in range(4)]
+    with pytest.raises(capi.DvoAmdError):
+        thr.level_geometry(vga, 4)
+
+
 def test_trackers_created_back_to_back_are_spread_over_the_hardware_queues(capi, capsys):
     """The runtime maps streams onto its four hardware queues and a hardware queue runs one kernel at a time: how the trackers of a
     GPU are spread over them decides up to a third of a batch's throughput (profiles/r05_stream_queue_assignment_ab.txt: 55-56 k
