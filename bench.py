@@ -283,7 +283,7 @@ def main():
         ref_frames_extra.append(fr)
         ref_pyrs.append(capi.RgbdImagePyramid(fr[0], fr[1], K, levels, device=device))
     n_pyramids = len(ref_pyrs) + len(curs)
-    pyramid_bytes = n_pyramids * 48.0 * sum((W >> l) * (H >> l) for l in range(levels))
+    pyramid_bytes = n_pyramids * 76.0 * sum((W >> l) * (H >> l) for l in range(levels))
     idx = [pair_index(i, n_refs, n_curs) for i in range(B)]
     refs = [ref_pyrs[r] for r, _ in idx]
     curb = [curs[c] for _, c in idx]

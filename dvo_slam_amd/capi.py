@@ -181,7 +181,7 @@ def lib():
     L.dvo_amd_error_image.argtypes = [vp, vp, vp, dp, C.c_int, fp]
     L.dvo_amd_debug_iteration.argtypes = [vp, vp, vp, C.c_int, fp, fp, fp, C.POINTER(CIterationProbe)]
     L.dvo_amd_debug_hw_queue.argtypes = [vp, C.POINTER(C.c_int)]
-    L.dvo_amd_debug_level_geometry.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.dvo_amd_debug_level_geometry.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.dvo_amd_debug_weights.argtypes = [vp, vp, vp, C.c_int, fp, fp, fp, C.POINTER(CQ7Probe)]
     L.dvo_amd_kernel_timing.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_longlong), C.c_int]
     L.dvo_amd_bench_residual_pass.argtypes = [vp, vp, vp, C.c_int, fp, C.c_int, C.c_int, C.c_int, dp, dp,
@@ -655,12 +655,12 @@ class DenseTracker:
         return q.value
 
     def level_geometry(self, reference: RgbdImagePyramid, level: int):
-        """(test entry, dvo_amd_debug.h) (64-pixel steps per wave segment, blocks of four segments) of the residual pass on one
-        level of `reference` under this tracker's configuration"""
-        steps, blocks = C.c_int(0), C.c_int(0)
-        _check(lib().dvo_amd_debug_level_geometry(self._h, reference._h, level, C.byref(steps), C.byref(blocks)),
+        """(test entry, dvo_amd_debug.h) (64-point steps per wave segment, blocks of four segments, points the pass walks) of the
+        residual pass on one level of `reference` under this tracker's configuration"""
+        steps, blocks, points = C.c_int(0), C.c_int(0), C.c_int(0)
+        _check(lib().dvo_amd_debug_level_geometry(self._h, reference._h, level, C.byref(steps), C.byref(blocks), C.byref(points)),
                "dvo_amd_debug_level_geometry")
-        return steps.value, blocks.value
+        return steps.value, blocks.value, points.value
 
     def weights_probe(self, reference: RgbdImagePyramid, current: RgbdImagePyramid, level: int, T, precision_in):
         """(test entry, dvo_amd_debug.h; host-rcpps mode only) the t-distribution weights of one residual pass at T under the 2x2

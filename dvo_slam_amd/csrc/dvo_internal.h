@@ -52,10 +52,18 @@ using namespace dvo_amd;  // (an internal header of four translation units that 
 // pyramid
 // ------------------------------------------------------------------------------------------------------------------
 
+// the compacted selection of one level (k_compact): seven arrays of n_pad entries each, point p = the p-th selected pixel
+struct CompactLevel {
+  float *z, *i, *ix, *iy, *tx, *ty;
+  int *pix;  // pixel index of the point (-1 in the padding): how per-point results find their way back to the image
+};
+constexpr size_t kCompactBytesPerPoint = 7 * sizeof(float);
 struct Selection {
   float ti, td;
-  float *zsel[DVO_AMD_MAX_LEVELS];
+  float *zsel[DVO_AMD_MAX_LEVELS];        // pixel space: depth where selected, NaN elsewhere (the mask; the source of the compaction)
+  CompactLevel pts[DVO_AMD_MAX_LEVELS];   // what the residual pass reads
   int count[DVO_AMD_MAX_LEVELS];  // PointSelection size (includes an odd trailing point)
+  int n_pts[DVO_AMD_MAX_LEVELS];  // points the passes walk: count without an odd trailing point (Q3)
   int last[DVO_AMD_MAX_LEVELS];   // index of the last selected pixel
   RefLevelDesc *ref_desc;         // device, [levels]
   void *desc_entry = nullptr;     // arena entry holding ref_desc (null: shares the pyramid's entry)
@@ -72,6 +80,7 @@ struct LevelData {
   float *r_i, *r_ix, *r_iy;
   float *tx, *ty;
   float *zsel0;  // room for the first selection
+  char *pts0;    // ... and for its compacted arrays (kCompactBytesPerPoint * n_pad)
 };
 
 struct dvo_amd_pyramid {
@@ -84,6 +93,7 @@ struct dvo_amd_pyramid {
   size_t slab_bytes = 0;
   int *counters = nullptr;  // device, [levels][2], inside the slab
   int2 *sel_partials = nullptr;  // device scratch of the selection kernels (level 0's block count), inside the slab
+  int *sel_prefix = nullptr;     // ... and the exclusive prefix of the partials' counts (k_select_prefix)
   void *desc_entry = nullptr;         // this pyramid's entry of the device's descriptor arena
   CurLevelDesc *cur_desc = nullptr;   // device, [levels], in desc_entry
   RefLevelDesc *ref_desc0 = nullptr;  // device, [levels], in desc_entry: room for the first selection's descriptors
@@ -337,6 +347,7 @@ void start_level(Job &j);
 void speculate_next_level(const Job &j, IterCtx &b_out);
 void make_kt(const LevelData &C, const SE3 &estimate, float kt[12]);
 int blocks_for(int n, int steps);
+int level_blocks(const Selection *sel, int level, int steps);
 void scale_and_precision(const FinOut &o, int n, float cov[4], float P[4]);
 void system_from_moments(const FinOut &o, const float P[4], double mu, const double xi_initial[6], double A[36], double b[6]);
 float loglik_from_sum(int n, const float P[4], double ll_sum, bool overflowed = false);

@@ -314,7 +314,10 @@ __host__ __device__ constexpr int gram_pair(int ci, int cj) { return ci == 0 ? c
 #endif
 #define DVO_KEEP(x) asm volatile("" ::"v"(x))
 
-// The fused residual pass.  A wave walks its segment in steps of 64 consecutive pixels, one pixel per lane, so that every
+// The fused residual pass.  It walks the SELECTED pixels of the reference level in scan order -- the compacted arrays k_compact
+// builds, as the reference walks PointSelection's dense array (dense_tracking_impl.cpp:169-171) -- so its cost follows the
+// selection, not the image (round 5, end; until then every pixel of the level took a lane and unselected ones carried a NaN depth).
+// A wave walks its segment in steps of 64 consecutive points, one point per lane: neighbouring selected pixels, so that every
 // gather instruction of a step touches ~64 neighbouring pixels of the current image (whole cache lines, reused by the
 // other three neighbour loads of the same step while they are still in L1).
 //
@@ -345,11 +348,8 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d_in, con
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
   const int seg = lb * kWavesPerBlock + wave;
-  const int w = d.w;
-  const int steps = item_res_steps(it);  // a segment is steps * 64 pixels
-  unsigned idx = (unsigned)(seg * (kStepPx * steps) + lane);
-  unsigned prow = idx / (unsigned)w;
-  unsigned pcol = idx - prow * (unsigned)w;
+  const int steps = item_res_steps(it);  // a segment is steps * 64 points
+  unsigned idx = (unsigned)(seg * (kStepPx * steps) + lane);  // a POINT of the compacted selection (k_compact), not a pixel
 
   float acc[ACC == 0 ? kNumAcc : 1];
 #pragma unroll
@@ -389,13 +389,12 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d_in, con
                          *const p_tx = (const DVO_GLOBAL void *)d.tx, *const p_ty = (const DVO_GLOBAL void *)d.ty;
   DVO_GLOBAL char *const p_res = (DVO_GLOBAL char *)((it.flags & kItemResBuf) ? d.res[1] : d.res[0]);  // no dynamic index: keeps d in registers
 
-  // reference scalars of the step about to be processed (loaded one step ahead); all accesses are uniform base + 32-bit offset
+  // the points of the step about to be processed (depth, intensity, derivatives, ray: six coalesced dword loads, one step ahead);
+  // all accesses are uniform base + 32-bit offset
   // (a two-step lead with two alternating register sets was measured: +10 VGPRs, +9 VALU per step, no gain in or out of cache)
   float n_z = ld_off<float>(p_z, 4u * idx), n_i = ld_off<float>(p_i, 4u * idx), n_ix = ld_off<float>(p_ix, 4u * idx),
         n_iy = ld_off<float>(p_iy, 4u * idx);
-  const unsigned last_row = (unsigned)d.h - 1u;   // rows past the image (the padding of the planes) read the last ray: their depth is NaN
-  const bool wide = w >= kWave;                   // block uniform
-  float n_tx = ld_off<float>(p_tx, 4u * pcol), n_ty = ld_off<float>(p_ty, 4u * (prow < last_row ? prow : last_row));
+  float n_tx = ld_off<float>(p_tx, 4u * idx), n_ty = ld_off<float>(p_ty, 4u * idx);  // the point's ray (padding: zeros under a NaN depth)
 
   // Operand fetch of the Gram-matrix accumulation: lane l supplies component l & 15 of points 4 m + (l >> 4), m = 0..15, of
   // the 64 points a step staged.  With the write swizzle below, chunk (comp >> 2) of point p sits at chunk position
@@ -438,7 +437,7 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d_in, con
     }
   };
 
-  // One step = 64 consecutive pixels, one per lane.  The loop is unrolled by two (a segment always has a multiple of four
+  // One step = 64 consecutive points of the compacted selection, one per lane.  The loop is unrolled by two (a segment always has a multiple of four
   // steps) so that the staging-buffer parity q is a compile-time constant and the one-step-ahead prefetch registers need
   // no rotation moves.
   auto do_step = [&](const int step, const int q, const bool prefetch) __attribute__((always_inline)) {
@@ -448,18 +447,10 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d_in, con
     float x = n_tx * z, y = n_ty * z;
     // prefetch the next step's reference scalars; they are consumed a whole step later
     idx += kWave;
-    pcol += kWave;
-    {  // one wrap, branch free (unsigned: pcol - w wraps around when pcol < w) ...
-      const unsigned wrapped = pcol - (unsigned)w;
-      prow += wrapped < pcol ? 1u : 0u;
-      pcol = wrapped < pcol ? wrapped : pcol;
-    }
-    if (!wide)  // ... and only a level narrower than a step (block uniform) can need more
-      while (pcol >= (unsigned)w) pcol -= (unsigned)w, ++prow;
     auto prefetch_next = [&]() __attribute__((always_inline)) {
       n_z = ld_off<float>(p_z, 4u * idx), n_i = ld_off<float>(p_i, 4u * idx), n_ix = ld_off<float>(p_ix, 4u * idx),
       n_iy = ld_off<float>(p_iy, 4u * idx);
-      n_tx = ld_off<float>(p_tx, 4u * pcol), n_ty = ld_off<float>(p_ty, 4u * (prow < last_row ? prow : last_row));
+      n_tx = ld_off<float>(p_tx, 4u * idx), n_ty = ld_off<float>(p_ty, 4u * idx);
     };
     if (prefetch) prefetch_next();
 
@@ -1199,9 +1190,8 @@ __device__ __forceinline__ void q7_tail_wave(const Args &args) {
     const int k = n_tail - 1 - j;
     const unsigned idx = (unsigned)sh_idx[k];
     my_idx = (int)idx;
-    const unsigned prow = idx / (unsigned)d.w, pcol = idx - prow * (unsigned)d.w;
     float z = ((gcf)d.r_zsel)[idx], ri = ((gcf)d.r_i)[idx], rix = ((gcf)d.r_ix)[idx], riy = ((gcf)d.r_iy)[idx];
-    float x = ((gcf)d.tx)[pcol] * z, y = ((gcf)d.ty)[prow] * z;
+    float x = ((gcf)d.tx)[idx] * z, y = ((gcf)d.ty)[idx] * z;
     float kt[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) kt[i] = it.kt[i];
@@ -2071,6 +2061,69 @@ hipError_t launch_select(const float *z_plane, const float4 *c_a, const float2 *
   hipLaunchKernelGGL(k_select, dim3((unsigned)n_blocks), dim3(256), 0, stream, z_plane, c_a, c_b, n, n_pad, ti, td, zsel,
                      block_partials);
   hipLaunchKernelGGL(k_select_finish, dim3(1), dim3(256), 0, stream, (const int2 *)block_partials, n_blocks, zsel, counters);
+  return hipGetLastError();
+}
+
+// The selected pixels of a level in scan order, compacted (round 5, end): what the residual pass walks.  The reference compacts
+// too -- PointSelection::select fills a dense array of the selected points (point_selection.cpp:119-152) and computeResidualsSse
+// walks that array -- so the pass's cost follows the selection, not the image.  One exclusive prefix over k_select's per-block
+// counts (one block), then every 256-pixel block writes its selected pixels behind the blocks before it: depth, intensity and its
+// derivatives, the pixel's ray (tx[column], ty[row]: the residual pass no longer tracks rows and columns) and the pixel index (the
+// debug entries scatter per-point results back to the image with it).  Entries from the even point count (Q3, see
+// k_select_finish) up to n_pad are padding: depth NaN, everything else zero.
+__global__ __launch_bounds__(256) void k_select_prefix(const int2 *__restrict__ block_partials, int n_blocks, int *__restrict__ prefix) {
+  const int chunk = (n_blocks + 255) / 256;
+  const int b0 = (int)threadIdx.x * chunk, b1 = b0 + chunk < n_blocks ? b0 + chunk : n_blocks;
+  int c = 0;
+  for (int b = b0; b < b1; ++b) c += block_partials[b].x;
+  __shared__ int sh[256];
+  sh[threadIdx.x] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int t = 0; t < 256; ++t) {
+      const int v = sh[t];
+      sh[t] = run, run += v;
+    }
+  }
+  __syncthreads();
+  int run = sh[threadIdx.x];
+  for (int b = b0; b < b1; ++b) prefix[b] = run, run += block_partials[b].x;
+}
+
+__global__ __launch_bounds__(256) void k_compact(const float *__restrict__ zsel, const float *__restrict__ r_i, const float *__restrict__ r_ix,
+                                                 const float *__restrict__ r_iy, const float *__restrict__ tx, const float *__restrict__ ty,
+                                                 int w, int n, int n_pad, const int *__restrict__ prefix, const int *__restrict__ counters,
+                                                 float *__restrict__ cz, float *__restrict__ ci, float *__restrict__ cix,
+                                                 float *__restrict__ ciy, float *__restrict__ ctx, float *__restrict__ cty,
+                                                 int *__restrict__ cpix) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n_pts = counters[0] & ~1;  // Q3: an odd trailing point is never looked at (its zsel entry is NaN already)
+  const float z = i < n ? zsel[i] : u2f(0x7fc00000u);
+  const bool ok = z == z;
+  const unsigned long long m = __ballot(ok);
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  __shared__ int sh_cnt[4];
+  if (lane == 0) sh_cnt[wave] = __popcll(m);
+  __syncthreads();
+  int before = prefix[blockIdx.x];
+  for (int k = 0; k < wave; ++k) before += sh_cnt[k];
+  if (ok) {
+    const int p = before + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    const int row = i / w, col = i - row * w;
+    cz[p] = z, ci[p] = r_i[i], cix[p] = r_ix[i], ciy[p] = r_iy[i], ctx[p] = tx[col], cty[p] = ty[row], cpix[p] = i;
+  }
+  if (i >= n_pts && i < n_pad) cz[i] = u2f(0x7fc00000u), ci[i] = 0.0f, cix[i] = 0.0f, ciy[i] = 0.0f, ctx[i] = 0.0f, cty[i] = 0.0f, cpix[i] = -1;
+}
+
+hipError_t launch_compact(const float *zsel, const float *r_i, const float *r_ix, const float *r_iy, const float *tx, const float *ty, int w,
+                          int n, int n_pad, const int2 *block_partials, int *prefix, const int *counters, float *cz, float *ci, float *cix,
+                          float *ciy, float *ctx, float *cty, int *cpix, hipStream_t stream) {
+  LaunchGuard guard;
+  const int n_blocks = (n_pad + 255) / 256;
+  hipLaunchKernelGGL(k_select_prefix, dim3(1), dim3(256), 0, stream, block_partials, n_blocks, prefix);
+  hipLaunchKernelGGL(k_compact, dim3((unsigned)n_blocks), dim3(256), 0, stream, zsel, r_i, r_ix, r_iy, tx, ty, w, n, n_pad,
+                     (const int *)prefix, counters, cz, ci, cix, ciy, ctx, cty, cpix);
   return hipGetLastError();
 }
 

@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
+#include <vector>
 
 #include "dvo_internal.h"
 
@@ -87,7 +89,7 @@ int single_tick(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyrami
   w.slot = ctx->slot_desc;
   const int steps = level_steps(ctx, R);
   item_set_steps(w, steps, steps);
-  const int nb = blocks_for(R.n, steps);
+  const int nb = level_blocks(sel, level, steps);
   if (unit_weights) w.flags |= kItemUnitWeights;
   if (P) std::memcpy(w.P, P, sizeof(w.P));
   FinArgs fa;
@@ -131,6 +133,33 @@ int single_tick(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyrami
   return DVO_AMD_OK;
 }
 
+// Per-point results of a pass (the residual pass walks the compacted selection, k_compact) back in the image: `floats_per` floats
+// per point from device memory to their pixels, NaN everywhere else -- the layout the entries below have always returned.
+int scatter_points_to_image(dvo_amd_context *ctx, const Selection *sel, int level, int n_pixels, const float *points_dev, int floats_per,
+                            float *image, std::vector<int> *pix_out = nullptr) {
+  const int n_pts = sel->n_pts[level];
+  std::vector<int> pix((size_t)std::max(n_pts, 1));
+  std::vector<float> pts((size_t)std::max(n_pts, 1) * floats_per);
+  if (n_pts > 0) {
+    HIP_TRY(hipMemcpyAsync(pix.data(), sel->pts[level].pix, sizeof(int) * (size_t)n_pts, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(pts.data(), points_dev, sizeof(float) * (size_t)n_pts * floats_per, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (image) {
+    const float qnan = std::numeric_limits<float>::quiet_NaN();
+    std::fill(image, image + (size_t)n_pixels * floats_per, qnan);
+    for (int p = 0; p < n_pts; ++p) {
+      if (pix[p] < 0 || pix[p] >= n_pixels) {
+        g_last_error = "compacted selection: a point without a pixel";
+        return DVO_AMD_ERR_HIP;
+      }
+      for (int k = 0; k < floats_per; ++k) image[(size_t)pix[p] * floats_per + k] = pts[(size_t)p * floats_per + k];
+    }
+  }
+  if (pix_out) pix.resize((size_t)n_pts), pix_out->swap(pix);
+  return DVO_AMD_OK;
+}
+
 int check_level_pair(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyramid *current, int level) {
   if (level >= reference->n_levels || level >= current->n_levels) return DVO_AMD_ERR_TOO_FEW_LEVELS;
   if (reference->device != ctx->device || current->device != ctx->device) return DVO_AMD_ERR_DEVICE_MISMATCH;
@@ -160,8 +189,10 @@ int dvo_amd_residuals(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_
   if (rc) return rc;
   rc = single_tick(ctx, reference, current, level, sel, T, nullptr, true, true, false, 0);
   if (rc) return rc;
-  if (residuals)
-    HIP_TRY(hipMemcpyAsync(residuals, ctx->slots[0].res[0], sizeof(float2) * R.n, hipMemcpyDeviceToHost, ctx->stream));
+  if (residuals) {  // (the spill is per point of the compacted selection; an unselected pixel reads NaN as it always has)
+    rc = scatter_points_to_image(ctx, sel, level, R.n, (const float *)ctx->slots[0].res[0], 2, residuals);
+    if (rc) return rc;
+  }
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   rc = take_record_synced(ctx, 0, ctx->tick_seq);
   if (rc) return rc;
@@ -215,7 +246,7 @@ int dvo_amd_debug_iteration(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dv
   bool overflowed = false;
   if (ctx->out_host[0].ll_qmax >= kLlOverflowScreen) {
     const int st = level_steps(ctx, R);  // (the geometry single_tick used)
-    rc = ll_overflowed(ctx, ctx->slots[0].res[0], ctx->slots[0].seg_prefix[0], blocks_for(R.n, st), st, 50 * (o.valid / 50), P, nullptr, 0,
+    rc = ll_overflowed(ctx, ctx->slots[0].res[0], ctx->slots[0].seg_prefix[0], level_blocks(sel, level, st), st, 50 * (o.valid / 50), P, nullptr, 0,
                        &overflowed);
     if (rc) return rc;
   }
@@ -259,23 +290,31 @@ int dvo_amd_debug_weights(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_
   if (e_off != hipSuccess) return fail_hip("dvo_amd_debug_weights", e_off);
   rc = take_record_synced(ctx, 0, ctx->tick_seq);
   if (rc) return rc;
-  HIP_TRY(hipMemcpy(weights, ctx->dbg_w_dev, sizeof(float) * (size_t)R.n, hipMemcpyDeviceToHost));
+  std::vector<int> pix;
+  rc = scatter_points_to_image(ctx, sel, level, R.n, ctx->dbg_w_dev, 1, weights, &pix);
+  if (rc) return rc;
   Q7Rec q;
   HIP_TRY(hipMemcpy(&q, ctx->slots[0].q7, sizeof(q), hipMemcpyDeviceToHost));
   std::memset(tail, 0, sizeof(*tail));
   tail->n_tail = q.n_tail, tail->valid_constraints = ctx->out_host[0].valid, tail->recomputed_equal = q.recomputed_equal;
   for (int i = 0; i < 3; ++i)
-    tail->pixel[i] = q.idx[i], tail->weight_table[i] = q.w_table[i], tail->weight_exact[i] = q.w_exact[i], tail->scale_sums_delta[i] = q.S[i];
+    tail->pixel[i] = (q.idx[i] >= 0 && q.idx[i] < (int)pix.size()) ? pix[(size_t)q.idx[i]] : -1, tail->weight_table[i] = q.w_table[i], tail->weight_exact[i] = q.w_exact[i], tail->scale_sums_delta[i] = q.S[i];
   for (int i = 0; i < kNumAcc; ++i) tail->moments_delta[i] = q.acc[i];
   tail->valid_counted = q.valid;
   return DVO_AMD_OK;
 }
 
-int dvo_amd_debug_level_geometry(const dvo_amd_context *ctx, const dvo_amd_pyramid *reference, int level, int *steps, int *blocks) {
-  if (!ctx || !reference || !steps || !blocks || level < 0) return DVO_AMD_ERR_INVALID_ARGUMENT;
+int dvo_amd_debug_level_geometry(dvo_amd_context *ctx, dvo_amd_pyramid *reference, int level, int *steps, int *blocks, int *points) {
+  if (!ctx || !reference || !steps || !blocks || !points || level < 0) return DVO_AMD_ERR_INVALID_ARGUMENT;
   if (level >= reference->n_levels) return DVO_AMD_ERR_TOO_FEW_LEVELS;
+  if (reference->device != ctx->device) return DVO_AMD_ERR_DEVICE_MISMATCH;
+  HIP_TRY(hipSetDevice(ctx->device));
+  const Selection *sel = nullptr;
+  int rc = pyramid_selection(reference, ctx->cfg.intensity_derivative_threshold, ctx->cfg.depth_derivative_threshold, &sel);
+  if (rc) return rc;
   *steps = level_steps(ctx, reference->lv[level]);
-  *blocks = blocks_for(reference->lv[level].n, *steps);
+  *blocks = level_blocks(sel, level, *steps);
+  *points = sel->n_pts[level];
   return DVO_AMD_OK;
 }
 
@@ -335,7 +374,8 @@ int dvo_amd_bench_residual_pass_pairs(dvo_amd_context *ctx, int n_items, dvo_amd
   TickItem proto;
   std::memset(&proto, 0, sizeof(proto));
   item_set_steps(proto, steps, 1);
-  proto.res_blocks = (uint16_t)blocks_for(R.n, steps);
+  int max_blocks = 1;  // (an item's blocks cover its compacted selection: level_blocks)
+  for (int i = 0; i < n_items; ++i) max_blocks = std::max(max_blocks, level_blocks(sels[(size_t)i], level, steps));
   proto.flags = 0;
   proto.P[0] = 1500.0f, proto.P[3] = 7000.0f;  // a typical precision: the weights take the non-trivial branch
   const int launches = (n_items + kMaxItemsPerLaunch - 1) / kMaxItemsPerLaunch;
@@ -353,6 +393,7 @@ int dvo_amd_bench_residual_pass_pairs(dvo_amd_context *ctx, int n_items, dvo_amd
       for (int i = 0; i < ta.n_items; ++i) {
         TickItem &w = ta.items[i];
         w = proto;
+        w.res_blocks = (uint16_t)level_blocks(sels[(size_t)(first + i)], level, steps);
         const LevelData &C = currents[first + i]->lv[level];
         w.ref = sels[(size_t)(first + i)]->ref_desc + level;
         w.cur = currents[first + i]->cur_desc + level;
@@ -362,7 +403,7 @@ int dvo_amd_bench_residual_pass_pairs(dvo_amd_context *ctx, int n_items, dvo_amd
           for (int cc = 0; cc < 4; ++cc)
             w.kt[r * 4 + cc] = (K[r * 3 + 0] * T[cc * 4 + 0] + K[r * 3 + 1] * T[cc * 4 + 1]) + K[r * 3 + 2] * T[cc * 4 + 2];
       }
-      hipError_t e = launch_tick(ta, proto.res_blocks, ctx->stream, e0, e1);  // stamped by the dispatch itself
+      hipError_t e = launch_tick(ta, max_blocks, ctx->stream, e0, e1);  // stamped by the dispatch itself
       if (e != hipSuccess) return fail_hip("launch_tick", e);
       HIP_TRY(hipEventSynchronize(e1));
       float ms = 0.0f;

@@ -103,11 +103,13 @@ size_t pyramid_layout(dvo_amd_pyramid *p, char *base) {
     L.r_ix = (float *)carve(sizeof(float) * L.n_pad);
     L.r_iy = (float *)carve(sizeof(float) * L.n_pad);
     L.zsel0 = (float *)carve(sizeof(float) * L.n_pad);
+    L.pts0 = carve(kCompactBytesPerPoint * L.n_pad);
     L.tx = (float *)carve(sizeof(float) * L.w);
     L.ty = (float *)carve(sizeof(float) * L.h);
   }
   p->counters = (int *)carve(sizeof(int) * 2 * DVO_AMD_MAX_LEVELS);
   p->sel_partials = (int2 *)carve(sizeof(int2) * (size_t)(p->lv[0].n_pad / 256 + 1));
+  p->sel_prefix = (int *)carve(sizeof(int) * (size_t)(p->lv[0].n_pad / 256 + 1));
   static_assert(sizeof(CurLevelDesc) * DVO_AMD_MAX_LEVELS <= 640 && 640 + sizeof(RefLevelDesc) * DVO_AMD_MAX_LEVELS <= kDescEntryBytes,
                 "a pyramid's level descriptors fit one arena entry");
   return off;
@@ -276,12 +278,19 @@ int pyramid_selection(dvo_amd_pyramid *p, float ti, float td, const Selection **
   std::unique_ptr<Selection> sp(new Selection());
   Selection &s = *sp;
   s.ti = ti, s.td = td, s.extra_slab = nullptr, s.extra_bytes = 0;
+  auto compact_at = [](char *base, int n_pad) {
+    CompactLevel c;
+    float *f = (float *)base;
+    c.z = f, c.i = f + n_pad, c.ix = f + 2 * (size_t)n_pad, c.iy = f + 3 * (size_t)n_pad, c.tx = f + 4 * (size_t)n_pad,
+    c.ty = f + 5 * (size_t)n_pad, c.pix = (int *)(f + 6 * (size_t)n_pad);
+    return c;
+  };
   if (p->selections.empty()) {
-    for (int l = 0; l < p->n_levels; ++l) s.zsel[l] = p->lv[l].zsel0;
+    for (int l = 0; l < p->n_levels; ++l) s.zsel[l] = p->lv[l].zsel0, s.pts[l] = compact_at(p->lv[l].pts0, p->lv[l].n_pad);
     s.ref_desc = p->ref_desc0;
   } else {
     size_t bytes = 0;
-    for (int l = 0; l < p->n_levels; ++l) bytes += align_up(sizeof(float) * p->lv[l].n_pad, 256);
+    for (int l = 0; l < p->n_levels; ++l) bytes += align_up((sizeof(float) + kCompactBytesPerPoint) * p->lv[l].n_pad, 256);
     rc = desc_alloc(p->device, &s.desc_entry);
     if (rc) return rc;
     const hipError_t em = hipMalloc(&s.extra_slab, bytes);
@@ -294,7 +303,8 @@ int pyramid_selection(dvo_amd_pyramid *p, float ti, float td, const Selection **
     size_t off = 0;
     for (int l = 0; l < p->n_levels; ++l) {
       s.zsel[l] = (float *)((char *)s.extra_slab + off);
-      off += align_up(sizeof(float) * p->lv[l].n_pad, 256);
+      s.pts[l] = compact_at((char *)s.extra_slab + off + sizeof(float) * p->lv[l].n_pad, p->lv[l].n_pad);
+      off += align_up((sizeof(float) + kCompactBytesPerPoint) * p->lv[l].n_pad, 256);
     }
   }
   // any failure below must not leak the selection's own allocation
@@ -307,10 +317,9 @@ int pyramid_selection(dvo_amd_pyramid *p, float ti, float td, const Selection **
   RefLevelDesc ref_host[DVO_AMD_MAX_LEVELS];
   std::memset(ref_host, 0, sizeof(ref_host));
   for (int l = 0; l < p->n_levels; ++l) {
-    const LevelData &R = p->lv[l];
-    ref_host[l].r_zsel = s.zsel[l];
-    ref_host[l].r_i = R.r_i, ref_host[l].r_ix = R.r_ix, ref_host[l].r_iy = R.r_iy;
-    ref_host[l].tx = R.tx, ref_host[l].ty = R.ty;
+    ref_host[l].r_zsel = s.pts[l].z;
+    ref_host[l].r_i = s.pts[l].i, ref_host[l].r_ix = s.pts[l].ix, ref_host[l].r_iy = s.pts[l].iy;
+    ref_host[l].tx = s.pts[l].tx, ref_host[l].ty = s.pts[l].ty;
   }
   hipError_t e = hipMemcpyAsync(s.ref_desc, ref_host, sizeof(RefLevelDesc) * p->n_levels, hipMemcpyHostToDevice, st);
   if (e != hipSuccess) return fail("selection descriptors", e);
@@ -318,13 +327,17 @@ int pyramid_selection(dvo_amd_pyramid *p, float ti, float td, const Selection **
     const LevelData &L = p->lv[l];
     e = launch_select(L.z_plane, L.c_a, L.c_b, L.n, L.n_pad, ti, td, s.zsel[l], p->counters + 2 * l, p->sel_partials, st);
     if (e != hipSuccess) return fail("select", e);
+    // (the partials and the prefix are scratch of the pyramid shared by its levels: the prep stream runs them in order)
+    e = launch_compact(s.zsel[l], L.r_i, L.r_ix, L.r_iy, L.tx, L.ty, L.w, L.n, L.n_pad, p->sel_partials, p->sel_prefix, p->counters + 2 * l,
+                       s.pts[l].z, s.pts[l].i, s.pts[l].ix, s.pts[l].iy, s.pts[l].tx, s.pts[l].ty, s.pts[l].pix, st);
+    if (e != hipSuccess) return fail("compact", e);
   }
   int host_counters[2 * DVO_AMD_MAX_LEVELS];
   e = hipMemcpyAsync(host_counters, p->counters, sizeof(int) * 2 * p->n_levels, hipMemcpyDeviceToHost, st);
   if (e != hipSuccess) return fail("selection counters", e);
   e = hipStreamSynchronize(st);  // (also keeps ref_host alive until the copy has read it)
   if (e != hipSuccess) return fail("selection", e);
-  for (int l = 0; l < p->n_levels; ++l) s.count[l] = host_counters[2 * l], s.last[l] = host_counters[2 * l + 1];
+  for (int l = 0; l < p->n_levels; ++l) s.count[l] = host_counters[2 * l], s.n_pts[l] = s.count[l] & ~1, s.last[l] = host_counters[2 * l + 1];
   p->selections.push_back(std::move(sp));
   *out = p->selections.back().get();
   return DVO_AMD_OK;

@@ -162,6 +162,10 @@ int blocks_for(int n, int steps) {
   return (n + px_per_block - 1) / px_per_block;
 }
 
+// blocks of the residual pass over the compacted selection of a level (at least one: an empty selection still runs a block of
+// padding, whose pixels are all invalid -- the driver's TooFewConstraints path needs its record)
+int level_blocks(const Selection *sel, int level, int steps) { return std::max(1, blocks_for(sel->n_pts[level], steps)); }
+
 // computeScaleSse's 1/(n-2-1) and the 2x2 inverse (dense_tracking.cpp:295); S holds the unscaled pair sums
 void scale_and_precision(const FinOut &o, int n, float cov[4], float P[4]) {
   const float scale = 1.0f / (float)(size_t)(n - 2 - 1);
@@ -600,7 +604,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
     f.ll_qmax_off = j.slot->ll_qmax_off;
     if (j.have_b) {
       j.b.steps = level_steps(ctx, j.ref->lv[j.level]);  // the level's own geometry, whatever else this tick carries
-      j.b.n_blocks = blocks_for(j.ref->lv[j.level].n, j.b.steps);
+      j.b.n_blocks = level_blocks(j.sel, j.level, j.b.steps);
     }
     if (j.have_a) {
       if (j.a.buf) w.flags |= kItemLlBuf;
@@ -637,7 +641,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
       const int nl = j.level - 1;
       speculate_next_level(j, j.spec_b);
       j.spec_b.steps = level_steps(ctx, j.ref->lv[nl]);
-      j.spec_b.n_blocks = blocks_for(j.ref->lv[nl].n, j.spec_b.steps);
+      j.spec_b.n_blocks = level_blocks(j.sel, nl, j.spec_b.steps);
       w.ref = j.sel->ref_desc + nl;  // the likelihood pass only uses the slot's buffers
       w.cur = j.cur->cur_desc + nl;
       w.res_blocks = (uint16_t)j.spec_b.n_blocks;

@@ -92,10 +92,13 @@ __host__ __device__ inline void ll_block_range(int nb, int m_log2, int lb, int *
 
 // Static descriptors, resident in device memory next to what they describe and read by every block through scalar loads.
 // They are written once (pyramid build / point selection / scratch allocation); nothing is uploaded per match or per tick.
-struct RefLevelDesc {  // one per (pyramid, selection thresholds, level): the reference side of a pair
-  const float *r_zsel;  // depth where the pixel is selected, NaN elsewhere and in the padding (planes padded to kPlanePad)
-  const float *r_i, *r_ix, *r_iy;
-  const float *tx, *ty;  // ((float)x - ox)/fx, ((float)y - oy)/fy
+// The reference side of a pair: the SELECTED pixels of the level in scan order, compacted (k_compact; round 5, end -- until then
+// these were the level's planes with NaN depth at unselected pixels, and the pass walked every pixel).  Point p of the arrays is
+// the p-th selected pixel; entries from the (even) point count up to n_pad are padding with NaN depth.
+struct RefLevelDesc {  // one per (pyramid, selection thresholds, level)
+  const float *r_zsel;              // depth of the point (NaN in the padding)
+  const float *r_i, *r_ix, *r_iy;   // intensity and its derivatives at the point
+  const float *tx, *ty;             // the point's ray: ((float)x - ox)/fx, ((float)y - oy)/fy of its pixel (rgbd_image.cpp:198-199)
 };
 struct CurLevelDesc {  // one per (pyramid, level): the current side of a pair
   const float4 *c_a;  // {I, Z, Ix, Iy} per pixel (gather layout)
@@ -375,6 +378,9 @@ hipError_t launch_select(const float *z_plane, const float4 *c_a, const float2 *
 hipError_t launch_ingest(const unsigned char *img, int channels, int img_stride_bytes, const unsigned short *raw_z,
                          int z_stride, float z_scale, float *i_plane, float *z_plane, int w, int h, hipStream_t stream);
 hipError_t launch_copy_strided(const float *src, int stride, float *dst, int w, int h, hipStream_t stream);
+hipError_t launch_compact(const float *zsel, const float *r_i, const float *r_ix, const float *r_iy, const float *tx, const float *ty, int w,
+                          int n, int n_pad, const int2 *block_partials, int *prefix, const int *counters, float *cz, float *ci, float *cix,
+                          float *ciy, float *ctx, float *cty, int *cpix, hipStream_t stream);
 hipError_t launch_mask_from_zsel(const float *zsel, int n, int last_dropped, unsigned char *mask, hipStream_t stream);
 hipError_t launch_unpack_plane(const float4 *c_a, const float2 *c_b, int plane, int n, float *dst, hipStream_t stream);
 

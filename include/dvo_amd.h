@@ -67,13 +67,15 @@ typedef struct {
   float intensity_derivative_threshold; /* IntensityDerivativeThreshold, default 0 */
   float depth_derivative_threshold;     /* DepthDerivativeThreshold, default 0 */
   /* NOT a field of the reference (ABI version 3): how a pyramid level is cut into wave segments -- where the fp32 sums of a
-   * residual pass are cut.  Like every other field of this struct it is part of what a result is a function of: two trackers
-   * with different values agree to summation noise, not bit for bit; under ONE value match(), the batched forms, the queue, the
-   * validator's workers and every band count agree bit for bit (tests/test_determinism.py runs under both).
-   *   DVO_AMD_GEOMETRY_THROUGHPUT (default): 640x480 levels 3..0 run 4 / 4 / 10 / 10 steps of 64 pixels per wave -- on a level
-   *     of 64 000 pixels or more a wave segment is a whole number of image rows (ten steps for a 640-pixel row, twenty for 1280;
-   *     16 steps where the row is no whole number of steps): long segments amortise a block's prologue and epilogue, and the
-   *     four waves of a block, one row apart, share the lines they gather -- the most pairs per second;
+   * residual pass are cut.  The pass walks the level's SELECTED pixels in scan order (the points PointSelection keeps, compacted
+   * like the reference's own array), a wave takes a run of consecutive points in steps of 64.  Like every other field of this
+   * struct it is part of what a result is a function of: two trackers with different values agree to summation noise, not bit for
+   * bit; under ONE value match(), the batched forms, the queue, the validator's workers and every band count agree bit for bit
+   * (tests/test_determinism.py runs under both).
+   *   DVO_AMD_GEOMETRY_THROUGHPUT (default): 640x480 levels 3..0 run 4 / 4 / 10 / 10 steps per wave -- on a level of 64 000
+   *     pixels or more a wave segment holds as many points as an image row has pixels (ten steps for a 640-pixel row, twenty for
+   *     1280; 16 steps where a row is no whole number of steps): long segments amortise a block's prologue and epilogue, and the
+   *     four waves of a block, about a row apart, share the lines they gather -- the most pairs per second;
    *   DVO_AMD_GEOMETRY_LATENCY: 1 / 2 / 2 / 4 -- short segments spread a coarse level over more waves: the shortest single
    *     match() (the reference's default deployment is one match() per frame, dvo_ros/src/camera_dense_tracking.cpp:269), a few
    *     per cent fewer pairs per second in large batches. */

@@ -91,10 +91,11 @@ int dvo_amd_debug_weights(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_
  * trackers of a GPU back to back) and this entry lets an integrator look at the outcome.  Refused while pairs are queued. */
 int dvo_amd_debug_hw_queue(dvo_amd_context *ctx, int *pipe_queue);
 
-/* (test entry) the residual pass's geometry on one pyramid level under the context's configuration: `steps` 64-pixel steps per
- * wave segment and `blocks` blocks of four segments -- what dvo_amd_config::segment_geometry documents (dvo_amd.h), a function of
- * the level's size and the configuration alone (tests/test_determinism.py pins the tables). */
-int dvo_amd_debug_level_geometry(const dvo_amd_context *ctx, const dvo_amd_pyramid *reference, int level, int *steps, int *blocks);
+/* (test entry) the residual pass's geometry on one pyramid level under the context's configuration: `steps` 64-point steps per
+ * wave segment -- what dvo_amd_config::segment_geometry documents (dvo_amd.h), a function of the level's size and the configuration
+ * alone --, `points` the points the pass walks (the pixels the configuration's thresholds select, without an odd trailing one) and
+ * `blocks` the blocks of four segments that cover them (tests/test_determinism.py pins the tables). */
+int dvo_amd_debug_level_geometry(dvo_amd_context *ctx, dvo_amd_pyramid *reference, int level, int *steps, int *blocks, int *points);
 
 /* Micro-benchmark of the dominant kernel alone (used by bench.py for the roofline figure and by the tuning scripts):
  * `reps` timed repetitions of the fused residual pass over `n_items` copies of one (reference level, current level) pair

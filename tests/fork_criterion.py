@@ -241,12 +241,27 @@ def judge_flip(orc, ocfg, o_ref, o_cur, G, O, li, k):
         if margin <= band_x:
             return (f"{where}: stop / continue flipped by SUMMATION NOISE -- | |x|_inf - Precision | = {margin:.3g} on the "
                     f"oracle, its increment is {band_x:.3g} from the one exact sums give")
-        ping = None if k == 0 else Lg["iters"][k - 1]["P"]
-        o2 = orc.iteration(o_ref, o_cur, level, ig["T"], ping, rcp, *sel)
-        assert o2["n"] == ig["V"], (where, "constraint counts at the GPU's pose", o2["n"], ig["V"])
-        prior_g = mu * np.asarray(orc.se3_log(ig["initial"])) if mu else np.zeros(6)
-        x2 = np.linalg.solve(np.asarray(o2["A"], np.float64) + mu * np.eye(6), np.asarray(o2["b"], np.float64) + prior_g)
-        _, _, band2 = _noise_band(orc, o_ref, o_cur, level, ig["T"], ping, o2["ll"], x_ref=x2, mu=mu, prior=prior_g, sel=sel, rcp=rcp)
+        # The reference arithmetic at the GPU's own poses.  Its summation-noise band on this level is the LARGEST distance between
+        # its increment and the one exact sums give over the level's last iterations up to k (at most four), not the distance at
+        # iteration k alone: one realised rounding error is a draw that can land near zero -- the sequential fp32 sums' errors are
+        # largely common to A and b and cancel in the solve to a varying degree -- and a yardstick that happens to be a third of
+        # its usual size fails a GPU increment that is as close to the exact one as ever (seen on the bench workload's sensor
+        # pairs when the summation order changed: 1.2e-9 at the iteration against 3e-9 ... 2e-8 on its neighbours).  A fixed rule,
+        # nothing is resampled.
+        x2, band2 = None, 0.0
+        for jj in range(max(0, k - 3), k + 1):
+            igj = Lg["iters"][jj]
+            if not igj["has_inc"]:
+                continue
+            pj = None if jj == 0 else Lg["iters"][jj - 1]["P"]
+            o2 = orc.iteration(o_ref, o_cur, level, igj["T"], pj, rcp, *sel)
+            assert o2["n"] == igj["V"], (where, "constraint counts at the GPU's pose of iteration", jj, o2["n"], igj["V"])
+            prior_g = mu * np.asarray(orc.se3_log(igj["initial"])) if mu else np.zeros(6)
+            xj = np.linalg.solve(np.asarray(o2["A"], np.float64) + mu * np.eye(6), np.asarray(o2["b"], np.float64) + prior_g)
+            _, _, bj = _noise_band(orc, o_ref, o_cur, level, igj["T"], pj, o2["ll"], x_ref=xj, mu=mu, prior=prior_g, sel=sel, rcp=rcp)
+            band2 = max(band2, bj)
+            if jj == k:
+                x2 = xj
         assert np.abs(x2 - ig["inc"]).max() <= 2 * band2 + 1e-12, (where, "GPU increment", ig["inc"], "reference arithmetic", x2, band2)
         assert (np.abs(x2).max() > precision) == cont_g or abs(np.abs(x2).max() - precision) <= band2, \
             (where, "at the GPU's pose the reference arithmetic gives |x|_inf", np.abs(x2).max(), "GPU continued:", cont_g)

@@ -224,14 +224,15 @@ def test_the_segment_tables_are_the_documented_ones(capi, synth, frames):
     assert [lat.level_geometry(vga, l)[0] for l in (3, 2, 1, 0)] == [1, 2, 2, 4]
     for trk in (thr, lat):
         for l in range(4):
-            steps, blocks = trk.level_geometry(vga, l)
+            steps, blocks, points = trk.level_geometry(vga, l)
             n = (640 >> l) * (480 >> l)
-            assert (blocks - 1) * steps * 256 < n <= blocks * steps * 256  # the blocks cover the level, none is empty
+            assert 0 < points <= n and points % 2 == 0  # the selected pixels, without an odd trailing one (Q3)
+            assert (blocks - 1) * steps * 256 < points <= blocks * steps * 256  # the blocks cover the points, none is empty
     big = capi.RgbdImagePyramid(*synth.render(1280, 960, frame_id=40), synth.intrinsics_for(1280, 960), 5)
     assert [thr.level_geometry(big, l)[0] for l in (4, 3, 2, 1, 0)] == [4, 4, 10, 10, 20]
     assert [lat.level_geometry(big, l)[0] for l in (4, 3, 2, 1, 0)] == [1, 2, 2, 4, 4]
-    # a row that is no whole number of steps keeps the table's 16 (600 = 9.375 steps; level 1: 300 pixels)
-    odd = capi.RgbdImagePyramid(*synth.render(600, 450, frame_id=41), synth.intrinsics_for(600, 450), 3)
+    # a row that is no whole number of steps keeps the table's 16 (600 = 9.375 steps; level 1: 300 x 224 pixels)
+    odd = capi.RgbdImagePyramid(*synth.render(600, 448, frame_id=41), synth.intrinsics_for(600, 448), 2)
     assert [thr.level_geometry(odd, l)[0] for l in (1, 0)] == [16, 16]
     thr.match(frames[1], frames[2])
     other = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0))
