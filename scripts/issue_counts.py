@@ -45,9 +45,13 @@ def fit(run_json, batch_csv, isolated_csv, isolated_steps_per_launch):
     b = json.load(open(run_json))
     iso, iso_n = counters(isolated_csv)
     launches = iso_n["SQ_INSTS_VALU"]
-    mfma_per = iso["SQ_INSTS_MFMA"] / launches / isolated_steps_per_launch
-    valu_per = (iso["SQ_INSTS_VALU"] - iso["SQ_INSTS_MFMA"]) / launches / isolated_steps_per_launch  # SQ_INSTS_VALU counts MFMA too
     tot, _ = counters(batch_csv)
+    # The isolated pass walks the compacted selection (since the end of round 5): its steps per launch are no longer pixels / 64.
+    # The batch logs its steps launch by launch, so the matrix instructions per step are known from it (36: nine tiles x four
+    # groups; 16 for the 16x16x4 form) -- and the isolated pass's step count follows from its own matrix-instruction count.
+    mfma_per = float(round(tot["SQ_INSTS_MFMA"] / max(b["res_steps"], 1.0)))
+    isolated_steps_per_launch = iso["SQ_INSTS_MFMA"] / launches / mfma_per
+    valu_per = (iso["SQ_INSTS_VALU"] - iso["SQ_INSTS_MFMA"]) / launches / isolated_steps_per_launch  # SQ_INSTS_VALU counts MFMA too
     valu_batch = tot["SQ_INSTS_VALU"] - tot["SQ_INSTS_MFMA"]
     ll_per = (valu_batch - valu_per * b["res_steps"]) / max(b["ll_steps"], 1.0)
     print(json.dumps({
@@ -58,7 +62,7 @@ def fit(run_json, batch_csv, isolated_csv, isolated_steps_per_launch):
         "mfma_check_batch": tot["SQ_INSTS_MFMA"] / max(b["res_steps"], 1.0),
         "source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA: isolated level-0 residual pass (36 pairs per launch, prologue / "
                   "epilogue amortised over the steps) and one 72-pair batch in timing mode (scripts/issue_counts.py)",
-        "batch": b}, indent=1))
+        "isolated_steps_per_launch": isolated_steps_per_launch, "batch": b}, indent=1))
 
 
 if __name__ == "__main__":
