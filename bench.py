@@ -500,7 +500,7 @@ def main():
             "single_pair_latency": {
                 "ms": single_ms, "configuration": "segment_geometry = DVO_AMD_GEOMETRY_LATENCY (levels 3..0 in 1/2/2/4 steps per wave)",
                 "ms_with_the_batch_configuration": single_ms_batch_geometry,
-                "batch_configuration": "segment_geometry = DVO_AMD_GEOMETRY_THROUGHPUT (4/4/9/9 on these frames: a wave segment of a fine level holds the selected points of an image row), what the timed region runs",
+                "batch_configuration": "segment_geometry = DVO_AMD_GEOMETRY_THROUGHPUT (4/4/10/10: row-aligned segments on the fine levels), what the timed region runs",
                 "what": "one dvo_amd_match() at a time through the Python binding, median of three rounds of ten pairs; the geometry "
                         "is a field of the tracker's configuration and part of what a result is a function of"},
             "prep_ms_per_frame": prep_ms,
@@ -542,8 +542,8 @@ def main():
         try:
             if args.no_extras:  # (a counter / trace pass must not find batch-form k_tick launches behind the timing pass)
                 raise RuntimeError("skipped under --no-extras")
-            # (the level's own geometry -- nine steps of 64 points per wave, the selected points of one image row, for a 640x480 level 0
-            # of these frames since the end of round 5 -- and, beside it, 8 steps)
+            # (the level's own geometry -- ten steps of 64 pixels per wave, one image row, for a 640x480 level 0 since the end of round 5
+            # -- and, beside it, 8 steps)
             ms_i, ab_i, nl_i = trk.bench_residual_pass(ref, curs[0], 0, cur_pose(0), 36, 0, reps=20)
             ms_8, ab_8, nl_8 = trk.bench_residual_pass(ref, curs[0], 0, cur_pose(0), 36, 2, reps=20)
             line["roofline_isolated_kernel"] = {

@@ -356,7 +356,7 @@ void process_loglik(Job &j, const FinOut *outs, bool ll_overflowed = false);
 void release_slots(dvo_amd_context *ctx);
 int ensure_slots_impl(dvo_amd_context *ctx, int n_jobs, int n_pad);
 int ensure_slots(dvo_amd_context *ctx, int n_jobs, int n_pad);
-int level_steps(const dvo_amd_context *ctx, const LevelData &lv, int n_pts);
+int level_steps(const dvo_amd_context *ctx, const LevelData &lv);
 int level_ll_merge(const dvo_amd_context *ctx, int res_steps);
 int timing_begin(dvo_amd_context *ctx, size_t *slot);
 int tick_stream(dvo_amd_context *ctx, size_t index, hipStream_t *out);

@@ -437,7 +437,7 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d_in, con
     }
   };
 
-  // One step = 64 consecutive points of the compacted selection, one per lane.  The loop is unrolled by two (a segment usually has an even number of
+  // One step = 64 consecutive points of the compacted selection, one per lane.  The loop is unrolled by two (a segment always has a multiple of four
   // steps) so that the staging-buffer parity q is a compile-time constant and the one-step-ahead prefetch registers need
   // no rotation moves.
   auto do_step = [&](const int step, const int q, const bool prefetch) __attribute__((always_inline)) {
@@ -642,12 +642,7 @@ __device__ void residual_pass(const TickItem &it, const LevelPairDesc &d_in, con
 #ifdef DVO_TRACE_BLOCKS
       bool marked = false;
 #endif
-      int step = 0;
-      if (steps & 1) {  // an odd segment length: one leading step into buffer 1, then pairs as below (buffer 0, buffer 1)
-        do_step(0, 1, true);
-        step = 1;
-      }
-      for (; step + 2 < steps; step += 2) {
+      for (int step = 0; step + 2 < steps; step += 2) {
         do_step(step, 0, true);
 #if defined(DVO_TRACE_BLOCKS) && !defined(DVO_TRACE_DESC)
         if (!marked && threadIdx.x == 0) trace_first = trace_clock();

@@ -87,7 +87,7 @@ int single_tick(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dvo_amd_pyrami
   w.ref = sel->ref_desc + level;
   w.cur = current->cur_desc + level;
   w.slot = ctx->slot_desc;
-  const int steps = level_steps(ctx, R, sel->n_pts[level]);
+  const int steps = level_steps(ctx, R);
   item_set_steps(w, steps, steps);
   const int nb = level_blocks(sel, level, steps);
   if (unit_weights) w.flags |= kItemUnitWeights;
@@ -245,7 +245,7 @@ int dvo_amd_debug_iteration(dvo_amd_context *ctx, dvo_amd_pyramid *reference, dv
   out->loglik_sum = ctx->out_host[0].ll_sum;
   bool overflowed = false;
   if (ctx->out_host[0].ll_qmax >= kLlOverflowScreen) {
-    const int st = level_steps(ctx, R, sel->n_pts[level]);  // (the geometry single_tick used)
+    const int st = level_steps(ctx, R);  // (the geometry single_tick used)
     rc = ll_overflowed(ctx, ctx->slots[0].res[0], ctx->slots[0].seg_prefix[0], level_blocks(sel, level, st), st, 50 * (o.valid / 50), P, nullptr, 0,
                        &overflowed);
     if (rc) return rc;
@@ -312,7 +312,7 @@ int dvo_amd_debug_level_geometry(dvo_amd_context *ctx, dvo_amd_pyramid *referenc
   const Selection *sel = nullptr;
   int rc = pyramid_selection(reference, ctx->cfg.intensity_derivative_threshold, ctx->cfg.depth_derivative_threshold, &sel);
   if (rc) return rc;
-  *steps = level_steps(ctx, reference->lv[level], sel->n_pts[level]);
+  *steps = level_steps(ctx, reference->lv[level]);
   *blocks = level_blocks(sel, level, *steps);
   *points = sel->n_pts[level];
   return DVO_AMD_OK;
@@ -369,16 +369,13 @@ int dvo_amd_bench_residual_pass_pairs(dvo_amd_context *ctx, int n_items, dvo_amd
   if (rc) return rc;
   // `rounds` of the public interface = 256-pixel rounds per wave segment (four steps each); 0 = the driver's choice
   if (rounds != 0 && rounds != 1 && rounds != 2 && rounds != 4 && rounds != 8 && rounds != 16) return DVO_AMD_ERR_INVALID_ARGUMENT;
-  // (0 = the driver's choice: every item the geometry match() gives its pair -- level_steps is a function of the selection too)
-  auto steps_of_item = [&](int i) {
-    int st = rounds <= 0 ? level_steps(ctx, R, sels[(size_t)i]->n_pts[level]) : rounds * 4;
-    while (st < kMaxSteps && blocks_for(R.n, st) > 2048) st *= 2;
-    return st;
-  };
+  int steps = rounds <= 0 ? level_steps(ctx, R) : rounds * 4;
+  while (steps < kMaxSteps && blocks_for(R.n, steps) > 2048) steps *= 2;
   TickItem proto;
   std::memset(&proto, 0, sizeof(proto));
+  item_set_steps(proto, steps, 1);
   int max_blocks = 1;  // (an item's blocks cover its compacted selection: level_blocks)
-  for (int i = 0; i < n_items; ++i) max_blocks = std::max(max_blocks, level_blocks(sels[(size_t)i], level, steps_of_item(i)));
+  for (int i = 0; i < n_items; ++i) max_blocks = std::max(max_blocks, level_blocks(sels[(size_t)i], level, steps));
   proto.flags = 0;
   proto.P[0] = 1500.0f, proto.P[3] = 7000.0f;  // a typical precision: the weights take the non-trivial branch
   const int launches = (n_items + kMaxItemsPerLaunch - 1) / kMaxItemsPerLaunch;
@@ -396,8 +393,7 @@ int dvo_amd_bench_residual_pass_pairs(dvo_amd_context *ctx, int n_items, dvo_amd
       for (int i = 0; i < ta.n_items; ++i) {
         TickItem &w = ta.items[i];
         w = proto;
-        item_set_steps(w, steps_of_item(first + i), 1);
-        w.res_blocks = (uint16_t)level_blocks(sels[(size_t)(first + i)], level, steps_of_item(first + i));
+        w.res_blocks = (uint16_t)level_blocks(sels[(size_t)(first + i)], level, steps);
         const LevelData &C = currents[first + i]->lv[level];
         w.ref = sels[(size_t)(first + i)]->ref_desc + level;
         w.cur = currents[first + i]->cur_desc + level;

@@ -261,7 +261,7 @@ int run_tick_banded(dvo_amd_context *ctx, Job &j, int n_bands, int band_first, i
   const unsigned seq = ctx->tick_seq = next_seq(ctx->tick_seq);
   if (!j.have_a && !j.have_b) return DVO_AMD_OK;
   // the level's own segment length (level_steps): the same for every band count and rank, and the unsharded driver's
-  const int steps_level = level_steps(ctx, j.ref->lv[j.level], j.sel->n_pts[j.level]);
+  const int steps_level = level_steps(ctx, j.ref->lv[j.level]);
   const int nb_level = level_blocks(j.sel, j.level, steps_level);
   TickArgs ta;
   FinArgs fa;

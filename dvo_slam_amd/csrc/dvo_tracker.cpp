@@ -384,50 +384,38 @@ int ensure_slots(dvo_amd_context *ctx, int n_jobs, int n_pad) {
 // Steps per wave segment of a residual pass over a level of n_px pixels.  A pair's result must depend on its inputs only
 // (the reference runs independent match() calls under tbb::parallel_reduce / parallel_invoke, keyframe_graph.cpp:587-590,
 // local_tracker.cpp:184: whatever runs beside a pair cannot change it), and the segment length decides where the fp32 sums of
-// a pass are cut.  So it is a function of the level's size and of its selection alone: the same for a single match(), a pair in a batch of any
+// a pass are cut.  So it is a function of the level's size alone: the same for a single match(), a pair in a batch of any
 // residency, the submit queue, every validator worker and every band count.  Until round 3 it was picked per tick from the
 // pixels of everything resident (short segments for small ticks, long ones for saturating launches), and a batched result
 // moved by up to 5.8e-5 from the same pair's single match().
 // The trade-off the table settles: a step is a dependent chain (reference scalars -> projection -> gathers -> arithmetic ->
 // staging, ~1.5 us when nothing else hides it), so short segments make a single pair's tick shorter; a block's prologue and
 // epilogue (descriptors, seven wave reductions, the Gram tile, the block record) are amortised over long ones.
-int level_steps(const dvo_amd_context *ctx, const LevelData &lv, int n_pts) {
+int level_steps(const dvo_amd_context *ctx, const LevelData &lv) {
   const int n_px = lv.n;
   const long long waves = n_px / kStepPx;
   const long long *t = ctx->cfg.segment_geometry == DVO_AMD_GEOMETRY_LATENCY ? ctx->level_steps_at_latency : ctx->level_steps_at;
   int steps = waves >= t[4] ? 32 : waves >= t[3] ? 16 : waves >= t[2] ? 8 : waves >= t[1] ? 4 : waves >= t[0] ? 2 : 1;
-  // A wave segment = the selected points of an image row (end of round 5).  On the levels the table gives its longest segments the
-  // four waves of a block should walk the SAME columns one row apart: the lower bilinear row of one wave is then the upper row of
-  // the next at the same step, and the gathers of a block share their lines while they are in L1.  When the pass walked every
-  // pixel that was "ten steps for a 640-pixel row" (L2-miss traffic 0.83 x the algorithmic bytes against 1.11 x with 16-step
-  // segments, a launch alone 0.40 of the HBM roofline against 0.36, profiles/r05_row_aligned_segments_ab.txt); since it walks the
-  // compacted selection a row is n_pts / h points: nine steps where nine pixels in ten are selected, seven where seven in ten are
-  // (profiles/r05_row_of_points_ab.txt: 9 against 10 steps +1 % pairs/s and 0.43-0.44 against 0.42 per launch alone on the
-  // bench's frames; 7 and 11 lose 5 % and 2 %).  Rows shorter than 6.5 steps are taken two, three, ... at a time; the length is
-  // the nearest one a work item can name (steps_of_code: 7 ... 14, 16, 18, 20).  A function of the level and of the selection's
-  // size -- of the pair's inputs and the tracker's configuration, like everything else a result depends on.  Only where the last
-  // block still lies inside the arrays' padding; DVO_AMD_FINE_STEPS=n forces a length, =16 turns the rule off.
+  // Row-aligned segments (end of round 5): on the levels the table gives its longest segments, a wave segment is a whole number
+  // of image rows when the row is a whole number of steps -- ten steps for a 640-pixel row, ten (two rows) for 320, twenty for
+  // 1280.  The four waves of a block then walk the SAME columns one row (or two) apart: the lower bilinear row of one wave is
+  // the upper row of the next at the same step, and the gathers of a block share their lines while they are in L1 -- L2-miss
+  // traffic 0.83 x the algorithmic bytes against 1.11 x with 16-step and 0.98 x with 8-step segments, a launch alone 0.40 of the
+  // HBM roofline against 0.36 / 0.385, the batch +1 % on 16 steps (profiles/r05_row_aligned_segments_ab.txt).  Only where the last
+  // block of the level still lies inside the planes' padding; DVO_AMD_FINE_STEPS=n forces a length, =16 turns the rule off.
   if (steps == 16 && ctx->cfg.segment_geometry != DVO_AMD_GEOMETRY_LATENCY) {
     int want = ctx->fine_steps;
-    if (want == 0 && n_pts > 0 && lv.h > 0) {
-      const double row_steps = (double)n_pts / (double)lv.h / (double)kStepPx;  // steps the selected points of one row fill
-      if (row_steps <= 20.5) {
-        int rows = 1;
-        while (rows * row_steps < 6.5) ++rows;
-        const double ideal = rows * row_steps;
-        static const int kNameable[] = {7, 8, 9, 10, 11, 12, 13, 14, 16, 18, 20};
-        double best = 1e9;
-        for (int v : kNameable)
-          if (std::fabs(v - ideal) < best - 1e-12) best = std::fabs(v - ideal), want = v;  // (ties go to the shorter segment)
-      }
+    if (want == 0 && lv.w % kStepPx == 0) {
+      want = lv.w / kStepPx;
+      if (want % 2) want *= 2;
+      while (want < 8) want *= 2;
     }
     TickItem probe_item;
     std::memset(&probe_item, 0, sizeof(probe_item));
-    if (want >= 2 && want <= 32) {
+    if (want >= 2 && want <= 32 && want % 2 == 0) {
       item_set_steps(probe_item, want, 1);
       const long long block_px = (long long)kStepPx * kWavesPerBlock * want;
-      const long long n_walk = n_pts > 0 ? n_pts : n_px;
-      if (item_res_steps(probe_item) == want && (n_walk + block_px - 1) / block_px * block_px <= lv.n_pad && (n_walk + block_px - 1) / block_px <= 2048)
+      if (item_res_steps(probe_item) == want && (n_px + block_px - 1) / block_px * block_px <= lv.n_pad && (n_px + block_px - 1) / block_px <= 2048)
         return want;
     }
   }
@@ -615,7 +603,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
     f.seg_prefix_out = j.slot->seg_prefix[0], f.out = j.slot->out, f.out_dev = nullptr, f.seq = seq;
     f.ll_qmax_off = j.slot->ll_qmax_off;
     if (j.have_b) {
-      j.b.steps = level_steps(ctx, j.ref->lv[j.level], j.sel->n_pts[j.level]);  // the level's own geometry, whatever else this tick carries
+      j.b.steps = level_steps(ctx, j.ref->lv[j.level]);  // the level's own geometry, whatever else this tick carries
       j.b.n_blocks = level_blocks(j.sel, j.level, j.b.steps);
     }
     if (j.have_a) {
@@ -652,7 +640,7 @@ int submit_tick(dvo_amd_context *ctx, std::vector<Job> &jobs, GroupTick &grp) {
       // iteration a ends its level whatever its likelihood says: start the next level in this tick, assuming acceptance
       const int nl = j.level - 1;
       speculate_next_level(j, j.spec_b);
-      j.spec_b.steps = level_steps(ctx, j.ref->lv[nl], j.sel->n_pts[nl]);
+      j.spec_b.steps = level_steps(ctx, j.ref->lv[nl]);
       j.spec_b.n_blocks = level_blocks(j.sel, nl, j.spec_b.steps);
       w.ref = j.sel->ref_desc + nl;  // the likelihood pass only uses the slot's buffers
       w.cur = j.cur->cur_desc + nl;

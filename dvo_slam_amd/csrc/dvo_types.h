@@ -137,10 +137,9 @@ struct TickItem {
   float P[4];                      // column-major 2x2 precision: of the iteration whose likelihood is evaluated, which is
                                    // also the one the residual pass of the next iteration takes its weights from
 };
-// step codes: 0..6 = 1 << code; 7.. = the segment lengths that are no power of two which level_steps may pick (a row of selected
-// points: 7 ... 14, 18, 20 steps)
+// step codes: 0..6 = 1 << code; 7.. = segment lengths that are no power of two (an image row of 640 pixels is ten steps)
 __host__ __device__ inline int steps_of_code(int c) {
-  return c < 7 ? 1 << c : c == 7 ? 10 : c == 8 ? 20 : c == 9 ? 9 : c == 10 ? 7 : c == 11 ? 12 : c == 12 ? 18 : c == 13 ? 13 : c == 14 ? 11 : 14;
+  return c < 7 ? 1 << c : c == 7 ? 10 : c == 8 ? 20 : c == 9 ? 12 : c == 10 ? 14 : c == 11 ? 6 : c == 12 ? 18 : c == 13 ? 24 : c == 14 ? 40 : 30;
 }
 __host__ __device__ inline int item_res_steps(const TickItem &it) { return steps_of_code(it.steps_log2 & 15); }
 __host__ __device__ inline int item_ll_steps(const TickItem &it) { return steps_of_code(it.steps_log2 >> 4); }

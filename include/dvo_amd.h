@@ -72,12 +72,10 @@ typedef struct {
    * struct it is part of what a result is a function of: two trackers with different values agree to summation noise, not bit for
    * bit; under ONE value match(), the batched forms, the queue, the validator's workers and every band count agree bit for bit
    * (tests/test_determinism.py runs under both).
-   *   DVO_AMD_GEOMETRY_THROUGHPUT (default): the coarse levels of 640x480 run 4 / 4 steps per wave; on a level of 64 000 pixels
-   *     or more a wave segment holds the selected points of an image row (of two or three rows where a row fills fewer than 6.5
-   *     steps; rounded to 7 ... 14, 16, 18 or 20 steps): nine steps on a 640-pixel level where nine pixels in ten are selected,
-   *     seven where seven in ten are.  Long segments amortise a block's prologue and epilogue, and the four waves of a block, a
-   *     row apart, share the lines they gather -- the most pairs per second.  The length is a function of the level and of the
-   *     selection's size, i.e. of the pair's inputs and this configuration;
+   *   DVO_AMD_GEOMETRY_THROUGHPUT (default): 640x480 levels 3..0 run 4 / 4 / 10 / 10 steps per wave -- on a level of 64 000
+   *     pixels or more a wave segment holds as many points as an image row has pixels (ten steps for a 640-pixel row, twenty for
+   *     1280; 16 steps where a row is no whole number of steps): long segments amortise a block's prologue and epilogue, and the
+   *     four waves of a block, about a row apart, share the lines they gather -- the most pairs per second;
    *   DVO_AMD_GEOMETRY_LATENCY: 1 / 2 / 2 / 4 -- short segments spread a coarse level over more waves: the shortest single
    *     match() (the reference's default deployment is one match() per frame, dvo_ros/src/camera_dense_tracking.cpp:269), a few
    *     per cent fewer pairs per second in large batches. */

@@ -20,7 +20,7 @@ L.dvo_amd_debug_block_trace.restype = C.c_longlong
 L.dvo_amd_debug_block_trace.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_longlong]
 CAP = 1 << 22
 # step codes of a work item (csrc/dvo_types.h: steps_of_code): 0..6 = 1 << code, then the lengths that are no power of two
-STEPS_OF_CODE = np.array([1, 2, 4, 8, 16, 32, 64, 10, 20, 9, 7, 12, 18, 13, 11, 14], np.int64)
+STEPS_OF_CODE = np.array([1, 2, 4, 8, 16, 32, 64, 10, 20, 12, 14, 6, 18, 24, 40, 30], np.int64)
 
 
 def read_trace(trk):

@@ -211,34 +211,16 @@ def test_the_latency_geometry_is_a_configuration_like_any_other(capi, synth, fra
         capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0, SegmentGeometry=7))
 
 
-def _row_of_points_steps(points, h):
-    """level_steps' rule for the levels the throughput table gives its longest segments: a wave segment holds the selected points
-    of one image row (of two, three, ... rows where a row fills fewer than 6.5 steps of 64 points), rounded to the nearest length a
-    work item can name, ties to the shorter"""
-    row = points / h / 64.0
-    rows = 1
-    while rows * row < 6.5:
-        rows += 1
-    best = None
-    for v in (7, 8, 9, 10, 11, 12, 13, 14, 16, 18, 20):
-        if best is None or abs(v - rows * row) < abs(best - rows * row) - 1e-12:
-            best = v
-    return best
-
-
-def test_the_segment_tables_are_the_documented_ones(capi, synth, frames, capsys):
+def test_the_segment_tables_are_the_documented_ones(capi, synth, frames):
     """dvo_amd.h documents what dvo_amd_config::segment_geometry selects; dvo_amd_debug_level_geometry reads it back.  Throughput:
-    the coarse levels of 640x480 run 4 / 4 steps of 64 points per wave; on a level of 64 000 pixels or more a wave segment holds the
-    selected points of an image row -- nine steps on these frames' two fine levels, where nine pixels in ten are selected (one
-    640-pixel row, two 320-pixel rows).  Latency: 1 / 2 / 2 / 4 (1280x960 levels 4..0: 1 / 2 / 2 / 4 / 4).  A function of the
-    level's size, the selection's size and the configuration alone: two trackers of one configuration agree, whatever they ran."""
+    640x480 levels 3..0 in 4 / 4 / 10 / 10 steps of 64 pixels per wave -- on a level of 64 000 pixels or more a wave segment is a
+    whole number of image rows (ten steps = one 640-pixel row = two 320-pixel rows, twenty for 1280), 16 steps where a row is no
+    whole number of steps; latency: 1 / 2 / 2 / 4 (1280x960 levels 4..0: 1 / 2 / 2 / 4 / 4).  A function of the level's size and
+    the configuration alone: two trackers of one configuration agree, whatever they ran before."""
     thr = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0))
     lat = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0, SegmentGeometry=capi.GEOMETRY_LATENCY))
     vga = frames[0]
-    got = [thr.level_geometry(vga, l) for l in (3, 2, 1, 0)]
-    assert [g[0] for g in got[:2]] == [4, 4]
-    assert got[2][0] == _row_of_points_steps(got[2][2], 240) and got[3][0] == _row_of_points_steps(got[3][2], 480)
-    assert got[3][0] == 9 and got[2][0] == 9, got  # these analytic frames: nine pixels in ten selected
+    assert [thr.level_geometry(vga, l)[0] for l in (3, 2, 1, 0)] == [4, 4, 10, 10]
     assert [lat.level_geometry(vga, l)[0] for l in (3, 2, 1, 0)] == [1, 2, 2, 4]
     for trk in (thr, lat):
         for l in range(4):
@@ -247,26 +229,16 @@ def test_the_segment_tables_are_the_documented_ones(capi, synth, frames, capsys)
             assert 0 < points <= n and points % 2 == 0  # the selected pixels, without an odd trailing one (Q3)
             assert (blocks - 1) * steps * 256 < points <= blocks * steps * 256  # the blocks cover the points, none is empty
     big = capi.RgbdImagePyramid(*synth.render(1280, 960, frame_id=40), synth.intrinsics_for(1280, 960), 5)
-    gb = [thr.level_geometry(big, l) for l in (4, 3, 2, 1, 0)]
-    assert [g[0] for g in gb[:2]] == [4, 4]
-    assert [g[0] for g in gb[2:]] == [_row_of_points_steps(gb[2][2], 240), _row_of_points_steps(gb[3][2], 480), _row_of_points_steps(gb[4][2], 960)]
+    assert [thr.level_geometry(big, l)[0] for l in (4, 3, 2, 1, 0)] == [4, 4, 10, 10, 20]
     assert [lat.level_geometry(big, l)[0] for l in (4, 3, 2, 1, 0)] == [1, 2, 2, 4, 4]
-    # a sparser selection (thresholds on the derivatives): shorter rows of points, the same rule
-    sparse = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0, IntensityDerivativeThreshold=6.0, DepthDerivativeThreshold=0.05))
-    gs = sparse.level_geometry(vga, 0)
-    assert gs[2] < got[3][2] and gs[0] == _row_of_points_steps(gs[2], 480), (gs, got[3])
-    # a width that is no multiple of 64: the rule counts points, not pixels
+    # a row that is no whole number of steps keeps the table's 16 (600 = 9.375 steps; level 1: 300 x 224 pixels)
     odd = capi.RgbdImagePyramid(*synth.render(600, 448, frame_id=41), synth.intrinsics_for(600, 448), 2)
-    go = [thr.level_geometry(odd, l) for l in (1, 0)]
-    assert [g[0] for g in go] == [_row_of_points_steps(go[0][2], 224), _row_of_points_steps(go[1][2], 448)]
+    assert [thr.level_geometry(odd, l)[0] for l in (1, 0)] == [16, 16]
     thr.match(frames[1], frames[2])
     other = capi.DenseTracker(capi.Config(FirstLevel=3, LastLevel=0))
     assert [thr.level_geometry(vga, l) for l in range(4)] == [other.level_geometry(vga, l) for l in range(4)]
     with pytest.raises(capi.DvoAmdError):
         thr.level_geometry(vga, 4)
-    with capsys.disabled():
-        print(f"\n[geometry] 640x480 levels 3..0: {[g[0] for g in got]} steps over {[g[2] for g in got]} points; 1280x960 levels 4..0: "
-              f"{[g[0] for g in gb]}; thresholds 6 / 0.05: level 0 {gs[0]} steps over {gs[2]} points; 600x448 levels 1, 0: {[g[0] for g in go]}")
 
 
 def test_trackers_created_back_to_back_are_spread_over_the_hardware_queues(capi, capsys):
