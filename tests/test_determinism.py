@@ -227,6 +227,8 @@ def test_the_segment_tables_are_the_documented_ones(capi, synth, frames):
             steps, blocks, points = trk.level_geometry(vga, l)
             n = (640 >> l) * (480 >> l)
             assert 0 < points <= n and points % 2 == 0  # the selected pixels, without an odd trailing one (Q3)
+            count, mask = vga.select(l)  # PointSelection::select through the boundary: the same pixels, counted before Q3
+            assert count == int(mask.sum()) and points == count - (count & 1)
             assert (blocks - 1) * steps * 256 < points <= blocks * steps * 256  # the blocks cover the points, none is empty
     big = capi.RgbdImagePyramid(*synth.render(1280, 960, frame_id=40), synth.intrinsics_for(1280, 960), 5)
     assert [thr.level_geometry(big, l)[0] for l in (4, 3, 2, 1, 0)] == [4, 4, 10, 10, 20]
