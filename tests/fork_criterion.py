@@ -458,6 +458,11 @@ def adjudicate(orc, synth, ocfg, o_ref, o_cur, T_init, rg, ro, err, pose_tol, co
     report = [f"pose error vs the free-running oracle {err:.2e} (for the record; the bar is {pose_tol:g} against the continuation "
               f"from the GPU's state behind the last fork)"]
     T_final, final, n_resync, per_level = None, None, 0, {}
+    # the result must be the pose its own recorded iterations end on (dense_tracking.cpp:371: Transformation = estimate.inverse()):
+    # everything below judges the iterations
+    own_end = np.linalg.inv(walk(orc, G, ocfg, T_init)[-1]["estimate"])
+    assert synth.pose_error(own_end, rg.Transformation) <= 1e-9, \
+        ("the result is not the pose its own iteration statistics end on", synth.pose_error(own_end, rg.Transformation))
     while True:
         fk = first_fork(G, O)
         if fk is None:
